@@ -1,0 +1,55 @@
+// Shared device-side helpers and the error convention of the kernel shim.
+// Kernel shim entry points return 0 on success (like ggml_status /
+// ggml_backend_graph_compute, reference src/mlblock.c:301-307) and <0 on error;
+// the message is retrievable with mlsd_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define MLSD_API __attribute__((visibility("default")))
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+extern "C" {
+int mlsd_set_error(int code, const char* fmt, ...);
+int mlsd_check_launch(const char* what);
+}
+
+#define MLSD_HIP_TRY(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return mlsd_set_error(-(int)e_ - 1000, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- small device helpers -------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// tanh-approximation GELU (ggml_gelu)
+__device__ __forceinline__ float gelu_tanh_f(float x)
+{
+    const float c = 0.7978845608028654f, a = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(c * x * (1.0f + a * x * x)));
+}
+__device__ __forceinline__ float gelu_quick_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

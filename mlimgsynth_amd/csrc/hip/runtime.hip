@@ -1,0 +1,202 @@
+// Device runtime plumbing of the kernel shim: memory, streams, events, graphs.
+// Replaces the ggml-backend data-movement call sites of the reference
+// (ggml_backend_tensor_set/get: src/localtensor.h:96-106, src/mlblock.c:257,
+//  src/unet.c:375-384) and ggml_backend_init_* (src/mlimgsynth.c:1131-1161).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+extern "C" {
+
+int mlsd_set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int mlsd_check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlsd_set_error(-(int)e - 1000, "launch %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+MLSD_API const char* mlsd_last_error(void) { return g_err; }
+
+MLSD_API int mlsd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+MLSD_API int mlsd_device_set(int dev)
+{
+    MLSD_HIP_TRY(hipSetDevice(dev));
+    return 0;
+}
+
+// name: buffer of >=256 bytes. Returns 0 and fills fields.
+MLSD_API int mlsd_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu,
+                              size_t* mem_total, size_t* mem_free)
+{
+    hipDeviceProp_t p;
+    MLSD_HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name) snprintf(name, name_len, "%s", p.name);
+    if (arch) snprintf(arch, arch_len, "%s", p.gcnArchName);
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    size_t f = 0, t = 0;
+    int cur = 0;
+    MLSD_HIP_TRY(hipGetDevice(&cur));
+    if (cur != dev) MLSD_HIP_TRY(hipSetDevice(dev));
+    MLSD_HIP_TRY(hipMemGetInfo(&f, &t));
+    if (cur != dev) MLSD_HIP_TRY(hipSetDevice(cur));
+    if (mem_total) *mem_total = t;
+    if (mem_free) *mem_free = f;
+    return 0;
+}
+
+MLSD_API int mlsd_malloc(void** out, size_t nbytes)
+{
+    *out = NULL;
+    MLSD_HIP_TRY(hipMalloc(out, nbytes ? nbytes : 16));
+    return 0;
+}
+
+MLSD_API int mlsd_free(void* p)
+{
+    if (p) MLSD_HIP_TRY(hipFree(p));
+    return 0;
+}
+
+MLSD_API int mlsd_host_alloc(void** out, size_t nbytes)
+{
+    *out = NULL;
+    MLSD_HIP_TRY(hipHostMalloc(out, nbytes ? nbytes : 16, hipHostMallocDefault));
+    return 0;
+}
+
+MLSD_API int mlsd_host_free(void* p)
+{
+    if (p) MLSD_HIP_TRY(hipHostFree(p));
+    return 0;
+}
+
+MLSD_API int mlsd_memset(void* dst, int value, size_t nbytes, void* stream)
+{
+    MLSD_HIP_TRY(hipMemsetAsync(dst, value, nbytes, (hipStream_t)stream));
+    return 0;
+}
+
+// kind: 0 = host->device, 1 = device->host, 2 = device->device
+MLSD_API int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind, void* stream)
+{
+    hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    MLSD_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, k, (hipStream_t)stream));
+    return 0;
+}
+
+MLSD_API int mlsd_stream_create(void** out)
+{
+    hipStream_t s;
+    MLSD_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void*)s;
+    return 0;
+}
+
+MLSD_API int mlsd_stream_destroy(void* s)
+{
+    if (s) MLSD_HIP_TRY(hipStreamDestroy((hipStream_t)s));
+    return 0;
+}
+
+MLSD_API int mlsd_stream_sync(void* s)
+{
+    MLSD_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+
+MLSD_API int mlsd_device_sync(void)
+{
+    MLSD_HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+MLSD_API int mlsd_event_create(void** out)
+{
+    hipEvent_t e;
+    MLSD_HIP_TRY(hipEventCreate(&e));
+    *out = (void*)e;
+    return 0;
+}
+
+MLSD_API int mlsd_event_destroy(void* e)
+{
+    if (e) MLSD_HIP_TRY(hipEventDestroy((hipEvent_t)e));
+    return 0;
+}
+
+MLSD_API int mlsd_event_record(void* e, void* stream)
+{
+    MLSD_HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)stream));
+    return 0;
+}
+
+MLSD_API int mlsd_event_sync(void* e)
+{
+    MLSD_HIP_TRY(hipEventSynchronize((hipEvent_t)e));
+    return 0;
+}
+
+MLSD_API int mlsd_event_elapsed_ms(void* e0, void* e1, float* ms)
+{
+    MLSD_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)e0, (hipEvent_t)e1));
+    return 0;
+}
+
+MLSD_API int mlsd_stream_wait_event(void* stream, void* e)
+{
+    MLSD_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0));
+    return 0;
+}
+
+// ---- hipGraph capture of a launch sequence (one UNet evaluation) ----------
+MLSD_API int mlsd_capture_begin(void* stream)
+{
+    MLSD_HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+
+MLSD_API int mlsd_capture_end(void* stream, void** graph_exec)
+{
+    hipGraph_t g = NULL;
+    *graph_exec = NULL;
+    MLSD_HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge = NULL;
+    hipError_t e = hipGraphInstantiate(&ge, g, NULL, NULL, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return mlsd_set_error(-(int)e - 1000, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *graph_exec = (void*)ge;
+    return 0;
+}
+
+MLSD_API int mlsd_graph_launch(void* graph_exec, void* stream)
+{
+    MLSD_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+
+MLSD_API int mlsd_graph_destroy(void* graph_exec)
+{
+    if (graph_exec) MLSD_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+}  // extern "C"
