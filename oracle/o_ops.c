@@ -1,0 +1,271 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * Op restatements.  Each function cites the reference call site it follows and the
+ * ggml semantics it assumes (ggml itself is absent => unpinned).
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <float.h>
+#include <omp.h>
+
+/* mlb_nn_linear, src/mlblock_nn.c:16-28: ggml_mul_mat(w, x) [+ ggml_add(bias)].
+ * x [n_in, T, N, 1], w [n_in, n_out] -> [n_out, T, N, 1].
+ * ggml semantics: with an F16 weight the CPU backend converts the activation row to
+ * F16 before the dot product (vec_dot type of F16 is F16); accumulation in fp32. */
+OT* orc_linear(const OT* x, const OParam* w, const OParam* b)
+{
+	int64_t n_in = x->ne[0], T = x->ne[1]*x->ne[2]*x->ne[3], n_out = w->ne[1];
+	if (w->ne[0] != n_in) { fprintf(stderr, "orc_linear: shape mismatch %ld vs %ld\n", (long)w->ne[0], (long)n_in); return NULL; }
+	OT *y = ot_new(n_out, x->ne[1], x->ne[2], x->ne[3]);
+	const float *xs = x->d;
+	float *xr = NULL;
+	if (w->type == ORC_F16) {
+		xr = (float*)malloc((size_t)n_in*T*sizeof(float));
+		memcpy(xr, x->d, (size_t)n_in*T*sizeof(float));
+		orc_round_f16(xr, n_in*T);
+		xs = xr;
+	}
+	orc_sgemm_nt(T, n_out, n_in, xs, n_in, w->d, n_in, y->d, n_out);
+	free(xr);
+	if (b) {
+		#pragma omp parallel for schedule(static) if (T*n_out > 65536)
+		for (int64_t t=0; t<T; ++t)
+			for (int64_t j=0; j<n_out; ++j) y->d[t*n_out+j] += b->d[j];
+	}
+	return y;
+}
+
+/* mlb_nn_conv2d, src/mlblock_nn.c:31-55: ggml_conv_2d(w, x, s,s, p,p, 1,1) [+ bias [1,1,C,1]].
+ * x [W,H,Cin,N], w [KW,KH,Cin,Cout] (F16 always, :42-43) -> [OW,OH,Cout,N].
+ * ggml semantics: im2col into an F16 matrix (activations rounded to F16), mul_mat with fp32
+ * accumulation; zero padding on both sides. */
+OT* orc_conv2d(const OT* x, const OParam* w, const OParam* b, int s, int p)
+{
+	const int64_t W=x->ne[0], H=x->ne[1], Cin=x->ne[2], N=x->ne[3];
+	const int64_t KW=w->ne[0], KH=w->ne[1], Cout=w->ne[3];
+	if (w->ne[2] != Cin) { fprintf(stderr, "orc_conv2d: Cin mismatch %ld vs %ld\n", (long)w->ne[2], (long)Cin); return NULL; }
+	const int64_t OW = (W + 2*p - KW)/s + 1, OH = (H + 2*p - KH)/s + 1;
+	const int64_t K = Cin*KH*KW, M = OW*OH;
+	OT *y = ot_new(OW, OH, Cout, N);
+	float *col = (float*)malloc((size_t)M*K*sizeof(float));
+	for (int64_t n=0; n<N; ++n) {
+		const float *xn = x->d + n*W*H*Cin;
+		#pragma omp parallel for schedule(static)
+		for (int64_t m=0; m<M; ++m) {
+			int64_t oh = m/OW, ow = m%OW;
+			float *c = col + m*K;
+			for (int64_t ci=0; ci<Cin; ++ci)
+			for (int64_t kh=0; kh<KH; ++kh)
+			for (int64_t kw=0; kw<KW; ++kw) {
+				int64_t ih = oh*s + kh - p, iw = ow*s + kw - p;
+				float v = 0;
+				if (ih>=0 && ih<H && iw>=0 && iw<W) v = xn[(ci*H + ih)*W + iw];
+				c[(ci*KH + kh)*KW + kw] = v;
+			}
+		}
+		orc_round_f16(col, M*K);  /* im2col target type is F16 */
+		/* out[Cout][M] = w[Cout][K] . col[M][K]^T */
+		orc_sgemm_nt(Cout, M, K, w->d, K, col, K, y->d + n*M*Cout, M);
+	}
+	free(col);
+	if (b) {
+		for (int64_t n=0; n<N; ++n)
+		for (int64_t co=0; co<Cout; ++co) {
+			float bv = b->d[co], *yp = y->d + (n*Cout+co)*M;
+			for (int64_t m=0; m<M; ++m) yp[m] += bv;
+		}
+	}
+	return y;
+}
+
+/* mlb_nn_groupnorm, src/mlblock_nn.c:78-103: ggml_group_norm(x, n_grp, eps) then *w, +b
+ * reshaped [1,1,C,1].  ggml semantics: per batch element, groups of C/G consecutive
+ * channels, population variance over W*H*C/G, sums accumulated in double. */
+OT* orc_group_norm(const OT* x, int G, float eps, const OParam* w, const OParam* b)
+{
+	const int64_t HW=x->ne[0]*x->ne[1], C=x->ne[2], N=x->ne[3];
+	const int64_t cg = (C + G - 1)/G;
+	OT *y = ot_new(x->ne[0], x->ne[1], C, N);
+	#pragma omp parallel for collapse(2) schedule(static)
+	for (int64_t n=0; n<N; ++n)
+	for (int64_t g=0; g<G; ++g) {
+		int64_t c0 = g*cg, c1 = c0+cg < C ? c0+cg : C;
+		if (c0 >= c1) continue;
+		const float *xp = x->d + (n*C + c0)*HW;
+		float *yp = y->d + (n*C + c0)*HW;
+		int64_t cnt = (c1-c0)*HW;
+		double sum = 0;
+		for (int64_t i=0;i<cnt;++i) sum += xp[i];
+		float mean = (float)(sum / cnt);
+		double sum2 = 0;
+		for (int64_t i=0;i<cnt;++i) { float v = xp[i]-mean; yp[i] = v; sum2 += (double)(v*v); }
+		float variance = (float)(sum2 / cnt);
+		float scale = 1.0f / sqrtf(variance + eps);
+		for (int64_t i=0;i<cnt;++i) yp[i] *= scale;
+		if (w) for (int64_t c=c0;c<c1;++c) {
+			float wv = w->d[c], bv = b ? b->d[c] : 0.f, *yc = y->d + (n*C + c)*HW;
+			for (int64_t i=0;i<HW;++i) yc[i] = yc[i]*wv + bv;
+		}
+	}
+	return y;
+}
+
+/* mlb_nn_layer_norm, src/mlblock_nn.c:58-75: ggml_norm over ne[0], eps 1e-5 default, *w, +b */
+OT* orc_layer_norm(const OT* x, float eps, const OParam* w, const OParam* b)
+{
+	if (!(eps > 0)) eps = 1e-5f;
+	const int64_t d=x->ne[0], T=x->ne[1]*x->ne[2]*x->ne[3];
+	OT *y = ot_new(d, x->ne[1], x->ne[2], x->ne[3]);
+	#pragma omp parallel for schedule(static) if (T*d > 65536)
+	for (int64_t t=0;t<T;++t) {
+		const float *xp = x->d + t*d; float *yp = y->d + t*d;
+		double sum=0; for (int64_t i=0;i<d;++i) sum += xp[i];
+		float mean = (float)(sum/d);
+		double sum2=0; for (int64_t i=0;i<d;++i) { float v=xp[i]-mean; yp[i]=v; sum2 += (double)(v*v); }
+		float scale = 1.0f/sqrtf((float)(sum2/d) + eps);
+		for (int64_t i=0;i<d;++i) {
+			float v = yp[i]*scale;
+			if (w) v *= w->d[i];
+			if (b) v += b->d[i];
+			yp[i] = v;
+		}
+	}
+	return y;
+}
+
+/* ggml_nn_attention, src/ggml_extend.c:200-222, reached through mlb_attn_mhead
+ * (src/mlblock_nn.c:190-231) after the head split.  q [d_embed, Tq, 1], k,v [d_embed, Tk, 1]
+ * already projected; heads are consecutive d_head slices of ne[0].  All fp32 (both mul_mat
+ * operands are F32): scores materialised, scaled by 1/sqrt(d_head), optional causal mask
+ * (key index > query index -> -inf), max-subtracted softmax over keys, then P.V.
+ * Returns [d_embed, Tq, 1] with heads merged back (mlblock_nn.c:224-227). */
+OT* orc_attention(const OT* q, const OT* k, const OT* v, int n_head, int causal)
+{
+	const int64_t D=q->ne[0], Tq=q->ne[1], Tk=k->ne[1];
+	const int64_t dh = D/n_head;
+	const float scale = 1.0f/sqrtf((float)dh);
+	OT *o = ot_new(D, Tq, 1, 1);
+	float *S = (float*)malloc((size_t)Tq*Tk*sizeof(float));
+	float *vt = (float*)malloc((size_t)dh*Tk*sizeof(float));
+	float *oh = (float*)malloc((size_t)Tq*dh*sizeof(float));
+	for (int h=0; h<n_head; ++h) {
+		/* S[Tq][Tk] = q_h[Tq][dh] . k_h[Tk][dh]^T */
+		orc_sgemm_nt(Tq, Tk, dh, q->d + h*dh, D, k->d + h*dh, D, S, Tk);
+		#pragma omp parallel for schedule(static)
+		for (int64_t i=0;i<Tq;++i) {
+			float *s = S + i*Tk;
+			float mx = -INFINITY;
+			for (int64_t j=0;j<Tk;++j) {
+				s[j] *= scale;
+				if (causal && j > i) s[j] = -INFINITY;
+				if (s[j] > mx) mx = s[j];
+			}
+			double sum = 0;
+			for (int64_t j=0;j<Tk;++j) { float e = expf(s[j]-mx); s[j] = e; sum += e; }
+			float inv = (float)(1.0/sum);
+			for (int64_t j=0;j<Tk;++j) s[j] *= inv;
+		}
+		/* v pre-transposed to [Tk, dh] -> vt[dh][Tk] (mlblock_nn.c:221-222) */
+		for (int64_t j=0;j<Tk;++j) for (int64_t c=0;c<dh;++c) vt[c*Tk+j] = v->d[j*D + h*dh + c];
+		orc_sgemm_nt(Tq, dh, Tk, S, Tk, vt, Tk, oh, dh);
+		for (int64_t i=0;i<Tq;++i) memcpy(o->d + i*D + h*dh, oh + i*dh, (size_t)dh*sizeof(float));
+	}
+	free(S); free(vt); free(oh);
+	return o;
+}
+
+void orc_silu(OT* x)
+{	/* ggml_silu: x/(1+exp(-x)) */
+	int64_t n = ot_nel(x);
+	#pragma omp parallel for schedule(static) if (n > 65536)
+	for (int64_t i=0;i<n;++i) x->d[i] = x->d[i] / (1.0f + expf(-x->d[i]));
+}
+
+void orc_gelu(OT* x)
+{	/* ggml_gelu: tanh approximation (ggml's F16 lookup table is not emulated) */
+	int64_t n = ot_nel(x);
+	const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
+	#pragma omp parallel for schedule(static) if (n > 65536)
+	for (int64_t i=0;i<n;++i) { float v=x->d[i]; x->d[i] = 0.5f*v*(1.0f + tanhf(c*v*(1.0f + a*v*v))); }
+}
+
+void orc_gelu_quick(OT* x)
+{	/* ggml_gelu_quick: x*sigmoid(1.702x) */
+	int64_t n = ot_nel(x);
+	#pragma omp parallel for schedule(static) if (n > 65536)
+	for (int64_t i=0;i<n;++i) { float v=x->d[i]; x->d[i] = v / (1.0f + expf(-1.702f*v)); }
+}
+
+void orc_relu(OT* x)
+{
+	int64_t n = ot_nel(x);
+	for (int64_t i=0;i<n;++i) if (!(x->d[i] > 0)) x->d[i] = 0;
+}
+
+/* ggml_upscale(x, 2, NEAREST), src/mlblock_nn.c:122, src/tae.c:82 */
+OT* orc_upscale2(const OT* x)
+{
+	const int64_t W=x->ne[0], H=x->ne[1], CN=x->ne[2]*x->ne[3];
+	OT *y = ot_new(W*2, H*2, x->ne[2], x->ne[3]);
+	#pragma omp parallel for schedule(static)
+	for (int64_t c=0;c<CN;++c)
+		for (int64_t i=0;i<H*2;++i) for (int64_t j=0;j<W*2;++j)
+			y->d[(c*H*2 + i)*W*2 + j] = x->d[(c*H + i/2)*W + j/2];
+	return y;
+}
+
+/* ggml_pad(x, p0, p1, 0, 0): zeros appended at the END of dims 0,1 (src/mlblock_nn.c:110) */
+OT* orc_pad_end(const OT* x, int p0, int p1)
+{
+	const int64_t W=x->ne[0], H=x->ne[1], CN=x->ne[2]*x->ne[3];
+	OT *y = ot_new(W+p0, H+p1, x->ne[2], x->ne[3]);
+	memset(y->d, 0, (size_t)ot_nel(y)*sizeof(float));
+	for (int64_t c=0;c<CN;++c) for (int64_t i=0;i<H;++i)
+		memcpy(y->d + (c*(H+p1) + i)*(W+p0), x->d + (c*H + i)*W, (size_t)W*sizeof(float));
+	return y;
+}
+
+/* ggml_concat(a, b, 2): channels of a then b (src/unet.c:233), batch 1 */
+OT* orc_concat_ch(const OT* a, const OT* b)
+{
+	OT *y = ot_new(a->ne[0], a->ne[1], a->ne[2]+b->ne[2], 1);
+	memcpy(y->d, a->d, (size_t)ot_nel(a)*sizeof(float));
+	memcpy(y->d + ot_nel(a), b->d, (size_t)ot_nel(b)*sizeof(float));
+	return y;
+}
+
+/* permute(1,2,0,3)+cont+reshape: [W,H,C,1] -> [C, W*H, 1] (src/unet.c:126-127); token order W-fastest */
+OT* orc_nchw_to_tokens(const OT* x)
+{
+	const int64_t HW=x->ne[0]*x->ne[1], C=x->ne[2];
+	OT *y = ot_new(C, HW, 1, 1);
+	#pragma omp parallel for schedule(static)
+	for (int64_t t=0;t<HW;++t) for (int64_t c=0;c<C;++c) y->d[t*C+c] = x->d[c*HW+t];
+	return y;
+}
+
+/* permute(1,0,2,3)+cont+reshape: [C,T,1] -> [W,H,C,1] (src/unet.c:134-137) */
+OT* orc_tokens_to_nchw(const OT* x, int w, int h)
+{
+	const int64_t C=x->ne[0], HW=x->ne[1];
+	OT *y = ot_new(w, h, C, 1);
+	#pragma omp parallel for schedule(static)
+	for (int64_t c=0;c<C;++c) for (int64_t t=0;t<HW;++t) y->d[c*HW+t] = x->d[t*C+c];
+	return y;
+}
+
+/* ggml_timestep_embedding(t, dim, max_period) == sd_timestep_embedding (src/mlimgsynth.c:1485-1499):
+ * out[s*dim + i] = cos(t_s*f_i), out[s*dim + i + half] = sin(t_s*f_i), f_i = exp(-ln(max_period)*i/half) */
+void orc_timestep_embedding(const float* t, int n_t, int dim, float max_period, float* out)
+{
+	int half = dim/2;
+	for (int i=0;i<half;++i) {
+		float freq = (float)exp(-log(max_period)*i/half);
+		for (int s=0;s<n_t;++s) {
+			out[s*dim+i]      = (float)cos(t[s]*freq);
+			out[s*dim+i+half] = (float)sin(t[s]*freq);
+		}
+	}
+}
