@@ -1,0 +1,182 @@
+/* mlsd_kernels.h — the thin C-ABI shim into the hand-written HIP kernels (gfx950).
+ *
+ * This is the layer that replaces the ggml op call sites of the reference's hot path
+ * (SURVEY.md §2.3).  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * unless stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default).
+ * Return convention: 0 = success (like ggml_status / ggml_backend_graph_compute,
+ * reference src/mlblock.c:301-307), <0 = error with text in mlsd_last_error().
+ *
+ * Data layout (MI355X-first, differs from the reference on purpose):
+ *   activations  : channels-last.  An image tensor [N,H,W,C] and a token tensor [N,T,C]
+ *                  are the same memory, so the reference's permute/cont/reshape nodes
+ *                  (src/unet.c:126-137, src/mlblock_nn.c:204-227) disappear.
+ *                  Residual streams are fp32; GEMM/conv/attention operands are fp16
+ *                  (ggml rounds activations to F16 before every F16-weight mul_mat/im2col,
+ *                  SURVEY App. A), accumulation fp32 on MFMA.
+ *   weights      : fp16 [n_out][K] row-major, K = n_in (linear) or (kh,kw,cin) with cin
+ *                  fastest (conv; repacked from the reference's [cout][cin][kh][kw]).
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- runtime (replaces ggml_backend_*:
+ * src/mlimgsynth.c:1131-1161, src/localtensor.h:96-106, src/mlblock.c:257) */
+const char* mlsd_last_error(void);
+int mlsd_device_count(void);
+int mlsd_device_set(int dev);
+int mlsd_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu,
+                     size_t* mem_total, size_t* mem_free);
+int mlsd_malloc(void** out, size_t nbytes);
+int mlsd_free(void* p);
+int mlsd_host_alloc(void** out, size_t nbytes);      /* pinned host memory */
+int mlsd_host_free(void* p);
+int mlsd_memset(void* dst, int value, size_t nbytes, void* stream);
+int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind /*0 h2d,1 d2h,2 d2d*/, void* stream);
+int mlsd_stream_create(void** out);
+int mlsd_stream_destroy(void* s);
+int mlsd_stream_sync(void* s);
+int mlsd_device_sync(void);
+int mlsd_event_create(void** out);
+int mlsd_event_destroy(void* e);
+int mlsd_event_record(void* e, void* stream);
+int mlsd_event_sync(void* e);
+int mlsd_event_elapsed_ms(void* e0, void* e1, float* ms);
+int mlsd_stream_wait_event(void* stream, void* e);
+int mlsd_capture_begin(void* stream);
+int mlsd_capture_end(void* stream, void** graph_exec);
+int mlsd_graph_launch(void* graph_exec, void* stream);
+int mlsd_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------- GEMM / implicit-GEMM conv
+ * Replaces ggml_mul_mat (+ggml_add bias) at src/mlblock_nn.c:22-25 and ggml_conv_2d (+bias) at
+ * src/mlblock_nn.c:44-50, with the adjacent elementwise nodes fused as epilogues:
+ *   time-embedding add  src/mlblock_nn.c:141-143     residual add  :154, :242,:247,:251, src/unet.c:143
+ *   SiLU src/unet.c:153,159   GELU/quick-GELU src/clip.c:354-356   ReLU src/tae.c:30-37
+ *   GEGLU (chunk+gelu+mul) src/mlblock_nn.c:164-169   nearest-2x upsample folded into the gather (:122)
+ * C[M,N] = A[M,K] . W[N,K]^T, fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16).
+ */
+enum { MLSD_ACT_NONE = 0, MLSD_ACT_SILU = 1, MLSD_ACT_GELU = 2, MLSD_ACT_GELU_QUICK = 3, MLSD_ACT_RELU = 4,
+       MLSD_ACT_GEGLU = 5 };
+
+typedef struct mlsd_gemm_args {
+	/* A operand: fp16 activations */
+	const void* A;
+	int64_t lda;            /* elements between consecutive rows (linear) / pixels (conv) */
+	int conv;               /* 0: A is a plain [M][K] matrix; 1: implicit im2col over an NHWC image */
+	int n_img, H, W, Cin;   /* conv: source image dims (before the optional 2x upsample) */
+	int OH, OW;             /* conv: output dims; M must equal n_img*OH*OW */
+	int KH, KW, stride, pad;
+	int upsample;           /* conv: 1 = the conv reads nearest-2x-upsampled input (ggml_upscale + conv) */
+	/* B operand: fp16 weights [N][ldb], K-contiguous */
+	const void* W_;
+	int64_t ldb;
+	int M, N, K;            /* K % 8 == 0; conv: K = KH*KW*Cin */
+	/* epilogue */
+	const float* bias;      /* [N] or NULL */
+	const float* rowbias;   /* [M/rows_per_batch][ldrb] added per batch element (time embedding) or NULL */
+	int rows_per_batch;
+	int64_t ldrb;
+	const float* resid;     /* fp32 [M][ldr] residual added after activation, or NULL */
+	int64_t ldr;
+	int act;                /* MLSD_ACT_*; GEGLU: W rows interleaved in blocks of 32 (value,gate), output has N/2 columns */
+	float* C32;             /* fp32 output [M][ldc32] or NULL */
+	int64_t ldc32;
+	void* C16;              /* fp16 output [M][ldc16] or NULL */
+	int64_t ldc16;
+} mlsd_gemm_args;
+
+int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
+/* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
+const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
+
+/* ---------------------------------------------------------------- fused attention
+ * Replaces ggml_nn_attention (src/ggml_extend.c:200-222: mul_mat, scale, [diag_mask_inf], soft_max,
+ * mul_mat with materialised scores) and the head split/merge permutes around it
+ * (src/mlblock_nn.c:204-227).  Flash-style: online softmax, scores never leave the CU.
+ * q [n_batch][Tq][ldq], k/v [n_batch][Tk][ldk/ldv] fp16 with head h at column h*d_head; out fp16
+ * [n_batch][Tq][ldo], heads merged.  d_head in {40,64,80,160} (any multiple of 8 up to 160). */
+typedef struct mlsd_attn_args {
+	const void *q, *k, *v;
+	void* out;
+	int64_t ldq, ldk, ldv, ldo;          /* row strides in elements */
+	int64_t bsq, bsk, bsv, bso;          /* batch strides in elements */
+	int n_batch, n_head, d_head, Tq, Tk;
+	int causal;                           /* 1: key index > query index masked (CLIP, src/clip.c:407-408) */
+} mlsd_attn_args;
+
+int mlsd_attention(const mlsd_attn_args* a, void* stream);
+
+/* row softmax over fp32 scores -> fp16 probabilities (VAE mid attention, d=512 single head,
+ * src/vae.c:46-74, computed as GEMM + softmax + GEMM).  in [rows][ld_in] f32, out [rows][ld_out] f16 */
+int mlsd_softmax_rows(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
+                      float scale, void* stream);
+
+/* ---------------------------------------------------------------- normalisation
+ * GroupNorm: ggml_group_norm + mul + add (+ silu) at src/mlblock_nn.c:86-99,135-136,146-147.
+ * Two fp32 sources (x1 with C1 channels, x2 with C2 channels, either row-strided) give the
+ * channel concat of src/unet.c:233 for free.  Output fp16 [n_img][HW][C1+C2]; optional raw fp16 copy
+ * of the (concatenated) input for the 1x1 skip conv. `ws` = workspace of mlsd_groupnorm_ws_bytes(). */
+typedef struct mlsd_gn_args {
+	const float *x1, *x2;
+	int64_t ld1, ld2;                     /* pixel strides in elements */
+	int C1, C2;                           /* C2 = 0 if no second source */
+	int n_img, HW, n_grp;
+	float eps;
+	const float *gamma, *beta;            /* [C1+C2] */
+	int silu;
+	void* y16;                            /* fp16 [n_img][HW][C1+C2] */
+	void* raw16;                          /* optional fp16 copy of the un-normalised input, or NULL */
+	void* ws;
+} mlsd_gn_args;
+
+size_t mlsd_groupnorm_ws_bytes(int n_img, int HW, int n_grp);
+int mlsd_groupnorm(const mlsd_gn_args* a, void* stream);
+
+/* LayerNorm over the last dim: ggml_norm + mul + add at src/mlblock_nn.c:65-71.  x fp32 [rows][ldx] ->
+ * y fp16 [rows][d] (and/or y32 fp32 [rows][d]) */
+int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float eps, const float* gamma,
+                   const float* beta, void* y16, float* y32, void* stream);
+
+/* ---------------------------------------------------------------- small ops */
+/* NCHW fp32 [n_src][C][HW] -> NHWC fp16 [n_dst][HW][Cpad] (channels >= C zero-filled);
+ * dst image n reads src image n % n_src (cond/uncond duplication of src/mlimgsynth.c:1578-1582);
+ * value = f(src * scale[n % n_src]) with scale NULL -> scalar `scale0`
+ * (c_in of src/unet.c:470-472; 1/scale_factor of src/vae.c:174);
+ * mode 1: 3*tanh(x/3) clamp of src/tae.c:71-73 applied first. */
+int mlsd_nchw_to_nhwc_f16(const float* src, int n_src, int C, int HW, void* dst, int n_dst, int Cpad,
+                          const float* scale, float scale0, int mode, void* stream);
+/* NHWC fp32 [n][HW][ld] (first C channels) -> NCHW fp32 [n][C][HW]; out = in*mul + add
+ * ((x+1)/2 of src/vae.h:43-47) */
+int mlsd_nhwc_to_nchw_f32(const float* src, int64_t ld, int n, int C, int HW, float* dst, float mul, float add,
+                          void* stream);
+/* ggml_timestep_embedding(t, dim, 10000) (src/unet.c:150): t fp32 [n] -> fp16 [n][dim] (cos | sin) */
+int mlsd_timestep_embedding(const float* t, int n, int dim, float max_period, void* out16, void* stream);
+/* y16 = act(x32) elementwise (silu of the embedding, src/mlblock_nn.c:140) */
+int mlsd_act_f32_to_f16(const float* x, void* y16, size_t n, int act, void* stream);
+/* ggml_get_rows + position add (src/clip.c:337-342): tokens int32 [n][T] -> x fp32 [n][T][d] */
+int mlsd_clip_embed(const int32_t* tokens, int n, int T, int d, const void* tok_w16, const float* pos_w,
+                    float* out, void* stream);
+/* Euler(-ancestral) update with CFG mix on device (src/mlimgsynth.c:1583, src/solvers.c:86,
+ * src/sampling.c:170-174):  x[b] += (eps_c*f + eps_u*(1-f)) * dt[b] + noise[b]*s_up[b]
+ * x, noise: NCHW fp32 [B][C][HW]; eps: NHWC fp32 [2B][HW][ld] (cond rows 0..B-1, uncond B..2B-1;
+ * f<=1: only cond is read).  dt, s_up: fp32 [B] on device. noise may be NULL. */
+int mlsd_sampler_update(float* x, const float* eps, int64_t ld, int B, int C, int HW, float cfg,
+                        const float* dt, const float* noise, const float* s_up, void* stream);
+/* finite check (ltensor_finite_check, src/unet.c:487): counts non-finite values into *count (device int32) */
+int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream);
+/* deterministic synthetic parameter fill, bit-identical to oracle/o_core.c orc_synth_fill.
+ * Writes element i (reference-layout index, ne[0] fastest) at position perm(i):
+ *   layout 0: identity;  layout 1: conv weight [k0,k1,cin,cout] (reference) -> [cout][k1][k0][cin_pad];
+ *   layout 2: GEGLU row interleave of a [n_in, 2*d] linear weight; layout 3: same for its bias.
+ * dtype: 0 fp32, 1 fp16.  The destination must be zero-initialised when padding is present. */
+int mlsd_synth_fill(void* dst, int dtype, int64_t n, uint64_t key, float offset, float kf, int layout,
+                    int64_t p0, int64_t p1, int64_t p2, int64_t p3, int64_t p4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,282 @@
+// GroupNorm(+affine+SiLU) and LayerNorm(+affine) for gfx950: HBM-bound wavefront reductions.
+//
+// GroupNorm (reference: ggml_group_norm + mul + add [+ silu], src/mlblock_nn.c:78-103,135-136):
+//   input  fp32 channels-last, optionally TWO sources concatenated along channels (the
+//          ggml_concat of src/unet.c:233 never materialises),
+//   pass 1 (gn_stats):  per (image, pixel-chunk) partial sums of (x-K) and (x-K)^2 per group,
+//          K = the group's first element (shifted sums: no catastrophic cancellation),
+//          combined deterministically (no atomics),
+//   pass 2 (gn_apply):  every block re-derives mean/rstd of its image from the partials in
+//          double, builds per-channel scale/shift in LDS, then streams x -> fp16 y
+//          (normalise, affine, SiLU) and optionally a raw fp16 copy for the 1x1 skip conv.
+//   Traffic: 2 fp32 reads + 1 fp16 write per element (the statistic is a global reduction, so
+//   one re-read is the minimum without fusing the statistics into the producer's epilogue).
+//
+// LayerNorm (reference: ggml_norm + mul + add, src/mlblock_nn.c:58-75): one wavefront per row,
+//   row held in registers, two-pass mean/variance, fp16 (and/or fp32) output.
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+#include "mlsd_kernels.h"
+
+namespace {
+
+constexpr int GN_MAXG = 32;
+constexpr int GN_MAXPP = 6;   // channel pairs per thread: supports C up to 2*256*6 = 3072
+
+struct GnP {
+    const float *x1, *x2;
+    long ld1, ld2;
+    int C1, C2, C, HW, G, cg;
+    int nchunk, pix_per_chunk;
+    float eps;
+    const float *gamma, *beta;
+    int silu;
+    _Float16* y16;
+    _Float16* raw16;
+    float* ws;  // [n_img][nchunk][G][2]
+};
+
+__device__ __forceinline__ const float* gn_src(const GnP& p, int img, int pix, int c)
+{
+    return c < p.C1 ? p.x1 + ((long)img * p.HW + pix) * p.ld1 + c : p.x2 + ((long)img * p.HW + pix) * p.ld2 + (c - p.C1);
+}
+
+__global__ __launch_bounds__(256) void gn_stats(const GnP p)
+{
+    __shared__ float s1[256 * GN_MAXPP], s2[256 * GN_MAXPP];
+    const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C2p = p.C >> 1;  // channel pairs
+    int PL, PP;
+    if (C2p >= 256) { PL = 1; PP = (C2p + 255) / 256; } else { PL = 256 / C2p; PP = 1; }
+    const int pl = C2p >= 256 ? 0 : tid / C2p;
+    const int pbase = C2p >= 256 ? tid : tid % C2p;
+    const bool active = pl < PL;
+    const int pix0 = chunk * p.pix_per_chunk;
+    const int pix1 = min(pix0 + p.pix_per_chunk, p.HW);
+
+    float a1[GN_MAXPP][2], a2[GN_MAXPP][2], K[GN_MAXPP];
+#pragma unroll
+    for (int i = 0; i < GN_MAXPP; ++i) {
+        a1[i][0] = a1[i][1] = a2[i][0] = a2[i][1] = 0.f;
+        K[i] = 0.f;
+        const int pr = pbase + i * 256;
+        if (i < PP && pr < C2p) { const int g = (2 * pr) / p.cg; K[i] = *gn_src(p, img, 0, g * p.cg); }
+    }
+    if (active) {
+        for (int pix = pix0 + pl; pix < pix1; pix += PL) {
+#pragma unroll
+            for (int i = 0; i < GN_MAXPP; ++i) {
+                const int pr = pbase + i * 256;
+                if (i < PP && pr < C2p) {
+                    const float2 v = *reinterpret_cast<const float2*>(gn_src(p, img, pix, 2 * pr));
+                    const float d0 = v.x - K[i], d1 = v.y - K[i];
+                    a1[i][0] += d0; a1[i][1] += d1;
+                    a2[i][0] += d0 * d0; a2[i][1] += d1 * d1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GN_MAXPP; ++i) {
+        s1[i * 256 + tid] = a1[i][0] + a1[i][1];
+        s2[i * 256 + tid] = a2[i][0] + a2[i][1];
+    }
+    __syncthreads();
+    if (tid < p.G) {
+        // deterministic combine: pairs of group g are [g*cg/2, (g+1)*cg/2), over all pixel lanes
+        const int g = tid, pr0 = g * (p.cg >> 1), pr1 = pr0 + (p.cg >> 1);
+        float t1 = 0.f, t2 = 0.f;
+        for (int pr = pr0; pr < pr1; ++pr) {
+            if (C2p >= 256) {
+                const int i = pr >> 8, t = pr & 255;
+                t1 += s1[i * 256 + t]; t2 += s2[i * 256 + t];
+            } else {
+                for (int l = 0; l < PL; ++l) { t1 += s1[l * C2p + pr]; t2 += s2[l * C2p + pr]; }
+            }
+        }
+        float* w = p.ws + (((long)img * p.nchunk + chunk) * p.G + g) * 2;
+        w[0] = t1; w[1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply(const GnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C]
+    __shared__ float g_mean[GN_MAXG], g_rstd[GN_MAXG];
+    float* sc = sm;
+    float* sh = sm + p.C;
+    const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    if (tid < p.G) {
+        double t1 = 0, t2 = 0;
+        const float* w = p.ws + ((long)img * p.nchunk * p.G + tid) * 2;
+        for (int c = 0; c < p.nchunk; ++c) { t1 += w[(long)c * p.G * 2]; t2 += w[(long)c * p.G * 2 + 1]; }
+        const double cnt = (double)p.cg * p.HW;
+        const double K = *gn_src(p, img, 0, tid * p.cg);
+        const double m = t1 / cnt;
+        double var = t2 / cnt - m * m;
+        if (var < 0) var = 0;
+        g_mean[tid] = (float)(K + m);
+        g_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / p.cg;
+        const float s = g_rstd[g] * p.gamma[c];
+        sc[c] = s;
+        sh[c] = p.beta[c] - g_mean[g] * s;
+    }
+    __syncthreads();
+    const int pix0 = chunk * p.pix_per_chunk;
+    const int pix1 = min(pix0 + p.pix_per_chunk, p.HW);
+    const int Q = p.C >> 2;  // channel quads
+    const long total = (long)(pix1 - pix0) * Q;
+    for (long idx = tid; idx < total; idx += 256) {
+        const int pix = pix0 + (int)(idx / Q), c = (int)(idx % Q) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(gn_src(p, img, pix, c));
+        const float4 s = *reinterpret_cast<const float4*>(sc + c);
+        const float4 b = *reinterpret_cast<const float4*>(sh + c);
+        float y0 = v.x * s.x + b.x, y1 = v.y * s.y + b.y, y2 = v.z * s.z + b.z, y3 = v.w * s.w + b.w;
+        if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+        const long o = ((long)img * p.HW + pix) * p.C + c;
+        f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+        *reinterpret_cast<f16x4*>(p.y16 + o) = h;
+        if (p.raw16) {
+            f16x4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<f16x4*>(p.raw16 + o) = r;
+        }
+    }
+}
+
+int gn_chunks(int HW)
+{
+    int c = HW / 16;
+    if (c > 64) c = 64;
+    if (c < 1) c = 1;
+    return c;
+}
+
+// ---------------------------------------------------------------- LayerNorm
+constexpr int LN_MAXQ = 8;  // float4 per lane: d up to 64*4*8 = 2048
+
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, long ldx, int rows, int d, float eps,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 _Float16* __restrict__ y16, float* __restrict__ y32)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int Q = d >> 2;
+    const float* xr = x + (long)row * ldx;
+    float4 v[LN_MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+        const int q = lane + i * 64;
+        if (q < Q) { v[i] = *reinterpret_cast<const float4*>(xr + q * 4); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        else v[i] = make_float4(0, 0, 0, 0);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+        const int q = lane + i * 64;
+        if (q < Q) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+        const int q = lane + i * 64;
+        if (q < Q) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + q * 4);
+            const float4 b = beta ? *reinterpret_cast<const float4*>(beta + q * 4) : make_float4(0, 0, 0, 0);
+            const float y0 = v[i].x * rstd * g.x + b.x, y1 = v[i].y * rstd * g.y + b.y;
+            const float y2 = v[i].z * rstd * g.z + b.z, y3 = v[i].w * rstd * g.w + b.w;
+            if (y16) {
+                f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+                *reinterpret_cast<f16x4*>(y16 + (long)row * d + q * 4) = h;
+            }
+            if (y32) *reinterpret_cast<float4*>(y32 + (long)row * d + q * 4) = make_float4(y0, y1, y2, y3);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- row softmax (VAE mid attention)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, long ld_in, _Float16* __restrict__ out,
+                                                           long ld_out, int rows, int cols, float scale)
+{
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = in + (long)row * ld_in;
+    float mx = -3.0e38f;
+    for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < cols; c += 256) s += __expf((xr[c] - mx) * scale);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    _Float16* yr = out + (long)row * ld_out;
+    for (int c = tid; c < cols; c += 256) yr[c] = (_Float16)(__expf((xr[c] - mx) * scale) * inv);
+}
+
+}  // namespace
+
+extern "C" {
+
+MLSD_API size_t mlsd_groupnorm_ws_bytes(int n_img, int HW, int n_grp)
+{
+    return (size_t)n_img * gn_chunks(HW) * n_grp * 2 * sizeof(float);
+}
+
+MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
+{
+    const int C = a->C1 + a->C2;
+    if (a->n_grp <= 0 || a->n_grp > GN_MAXG || C % a->n_grp) return mlsd_set_error(-1, "mlsd_groupnorm: bad group count %d for C=%d", a->n_grp, C);
+    const int cg = C / a->n_grp;
+    if ((cg & 1) || (a->C1 & 3) || (a->C2 & 3)) return mlsd_set_error(-1, "mlsd_groupnorm: need even channels/group and C1,C2 %% 4 == 0 (C1=%d C2=%d cg=%d)", a->C1, a->C2, cg);
+    if (C > 2 * 256 * GN_MAXPP) return mlsd_set_error(-1, "mlsd_groupnorm: C=%d too large", C);
+    if ((a->ld1 & 3) || (a->C2 && (a->ld2 & 3))) return mlsd_set_error(-1, "mlsd_groupnorm: strides must be multiples of 4");
+    if (!a->ws || !a->y16) return mlsd_set_error(-1, "mlsd_groupnorm: null workspace/output");
+    GnP p;
+    p.x1 = a->x1; p.x2 = a->x2; p.ld1 = a->ld1; p.ld2 = a->ld2; p.C1 = a->C1; p.C2 = a->C2; p.C = C;
+    p.HW = a->HW; p.G = a->n_grp; p.cg = cg; p.eps = a->eps; p.gamma = a->gamma; p.beta = a->beta; p.silu = a->silu;
+    p.y16 = (_Float16*)a->y16; p.raw16 = (_Float16*)a->raw16; p.ws = (float*)a->ws;
+    p.nchunk = gn_chunks(a->HW);
+    p.pix_per_chunk = (a->HW + p.nchunk - 1) / p.nchunk;
+    p.nchunk = (a->HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
+    const dim3 grid(p.nchunk, a->n_img);
+    hipLaunchKernelGGL(gn_stats, grid, dim3(256), 0, (hipStream_t)stream, p);
+    int rc = mlsd_check_launch("gn_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_apply, grid, dim3(256), (size_t)C * 2 * sizeof(float), (hipStream_t)stream, p);
+    return mlsd_check_launch("gn_apply");
+}
+
+MLSD_API int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float eps, const float* gamma,
+                            const float* beta, void* y16, float* y32, void* stream)
+{
+    if ((d & 3) || d > 64 * 4 * LN_MAXQ || (ldx & 3)) return mlsd_set_error(-1, "mlsd_layernorm: unsupported d=%d ldx=%ld", d, (long)ldx);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, d, eps, gamma,
+                       beta, (_Float16*)y16, y32);
+    return mlsd_check_launch("ln_kernel");
+}
+
+MLSD_API int mlsd_softmax_rows(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
+                               float scale, void* stream)
+{
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, (_Float16*)out,
+                       (long)ld_out, rows, cols, scale);
+    return mlsd_check_launch("softmax_rows_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+"""Op-level parity of the HIP kernels (through the C-ABI of include/mlsd_kernels.h) against
+the oracle (oracle/, CPU restatement of the reference ops) on seeded inputs.
+
+Tolerances (stated, fp32 accumulate on MFMA vs fp32 CPU with different summation order):
+  fp32 outputs: rel-L2 <= 2e-5;  fp16 outputs: rel-L2 <= 1e-3 (one fp16 rounding of the result);
+  attention: fp16 Q/K/V/P operands vs the oracle's all-fp32 attention: rel-L2 <= 2e-3.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def f16r(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def K():
+    from mlimgsynth_amd import kernels, _lib
+    return kernels, _lib
+
+
+def dev(_lib, a):
+    return _lib.from_numpy(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------ linear
+@pytest.mark.parametrize("M,N,Kd,act,use_bias,use_res", [
+    (128, 128, 64, 0, False, False), (300, 200, 136, 0, True, False), (8, 1280, 320, 1, True, False),
+    (77, 768, 768, 3, True, False), (1000, 320, 1280, 0, True, True), (513, 130, 2048, 2, True, True),
+    (1, 8, 8, 4, False, False)])
+def test_gemm_linear(K, M, N, Kd, act, use_bias, use_res):
+    kernels, _lib = K
+    rng = np.random.default_rng(M * 7 + N)
+    A = f16r(rng.standard_normal((M, Kd)))
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    # oracle: orc_linear (+ activation + residual as the graph would apply them)
+    P = O.Params()
+    y = O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias) if use_bias else None)
+    if act:
+        getattr(O.L(), {1: "orc_silu", 2: "orc_gelu", 3: "orc_gelu_quick", 4: "orc_relu"}[act])(y)
+    ref = O.from_ot(y).reshape(M, N)
+    if use_res:
+        ref = ref + res
+    dA, dW, dB, dR = dev(_lib, A.astype(np.float16)), dev(_lib, W.astype(np.float16)), dev(_lib, bias), dev(_lib, res)
+    dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd,
+                         bias=dB.ptr if use_bias else None, resid=dR.ptr if use_res else None, ldr=N, act=act,
+                         C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N)
+    kernels.gemm(a)
+    c32 = dC32.download((M, N), np.float32)
+    c16 = dC16.download((M, N), np.float16).astype(np.float32)
+    assert rel(c32, ref) < 2e-5
+    assert rel(c16, ref) < 1e-3
+
+
+def geglu_interleave(Wt, d):
+    """rows [value 0..d) | gate 0..d) -> blocks of 64: 32 value rows then 32 gate rows."""
+    out = np.zeros_like(Wt)
+    for j in range(d):
+        out[(j >> 5) * 64 + (j & 31)] = Wt[j]
+        out[(j >> 5) * 64 + 32 + (j & 31)] = Wt[d + j]
+    return out
+
+
+@pytest.mark.parametrize("M,d,Kd", [(200, 128, 64), (64, 64, 32), (1024, 320 * 4, 320)])
+def test_gemm_geglu(K, M, d, Kd):
+    kernels, _lib = K
+    rng = np.random.default_rng(5)
+    A = f16r(rng.standard_normal((M, Kd)))
+    W = f16r(rng.standard_normal((2 * d, Kd)) / np.sqrt(Kd))
+    bias = rng.standard_normal(2 * d).astype(np.float32)
+    P = O.Params()
+    proj = O.from_ot(O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias))).reshape(M, 2 * d)
+    g = O.to_ot(proj[:, d:].copy().reshape(1, 1, M, d))
+    O.L().orc_gelu(g)
+    ref = proj[:, :d] * O.from_ot(g).reshape(M, d)       # mlb_GEGLU, src/mlblock_nn.c:159-172
+    Wi, bi = geglu_interleave(W, d), geglu_interleave(bias[:, None], d)[:, 0]
+    dA, dW, dB = dev(_lib, A.astype(np.float16)), dev(_lib, Wi.astype(np.float16)), dev(_lib, bi)
+    dC = _lib.DeviceBuffer(M * d * 4)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=2 * d, K=Kd, bias=dB.ptr,
+                         act=kernels.ACT_GEGLU, C32=dC.ptr, ldc32=d)
+    kernels.gemm(a)
+    assert rel(dC.download((M, d), np.float32), ref) < 2e-5
+
+
+# ------------------------------------------------------------------ conv
+def repack_conv_w(w, cin_pad):
+    """reference [cout][cin][kh][kw] -> [cout][kh][kw][cin_pad]"""
+    co, ci, kh, kw = w.shape
+    out = np.zeros((co, kh, kw, cin_pad), np.float32)
+    out[..., :ci] = w.transpose(0, 2, 3, 1)
+    return out.reshape(co, kh * kw * cin_pad)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s,p,ups,emb", [
+    (2, 16, 16, 32, 48, 3, 1, 1, 0, True), (1, 16, 16, 64, 64, 3, 2, 1, 0, False), (2, 8, 8, 128, 320, 1, 1, 0, 0, False),
+    (1, 8, 8, 64, 32, 3, 1, 1, 1, False), (3, 8, 8, 4, 64, 3, 1, 1, 0, False), (1, 16, 16, 320, 4, 3, 1, 1, 0, False),
+    (2, 32, 32, 320, 320, 3, 1, 1, 0, True)])
+def test_conv2d(K, n, h, w, cin, cout, k, s, p, ups, emb):
+    kernels, _lib = K
+    rng = np.random.default_rng(cin + cout)
+    cpad = (cin + 7) // 8 * 8
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    rowb = rng.standard_normal((n, cout)).astype(np.float32)
+    P = O.Params()
+    pw, pb = P.set("w", wt, f16=True), P.set("b", bias)
+    refs = []
+    for i in range(n):  # the oracle (like the reference) is batch-1
+        xi = O.to_ot(x[i:i + 1])
+        if ups:
+            xi = O.L().orc_upscale2(xi)
+        yi = O.from_ot(O.L().orc_conv2d(xi, pw, pb, s, p))[0]
+        if emb:
+            yi = yi + rowb[i][:, None, None]
+        refs.append(yi)
+    ref = np.stack(refs)                                   # [n][cout][oh][ow]
+    oh, ow = ref.shape[2], ref.shape[3]
+    x_nhwc = np.zeros((n, h, w, cpad), np.float16)
+    x_nhwc[..., :cin] = x.transpose(0, 2, 3, 1)
+    dX, dW, dB, dRB = dev(_lib, x_nhwc), dev(_lib, repack_conv_w(wt, cpad).astype(np.float16)), dev(_lib, bias), dev(_lib, rowb)
+    M = n * oh * ow
+    dC = _lib.DeviceBuffer(M * cout * 4)
+    a = kernels.GemmArgs(A=dX.ptr, lda=cpad, conv=1, n_img=n, H=h, W=w, Cin=cpad, OH=oh, OW=ow, KH=k, KW=k, stride=s,
+                         pad=p, upsample=ups, W_=dW.ptr, ldb=k * k * cpad, M=M, N=cout, K=k * k * cpad, bias=dB.ptr,
+                         rowbias=dRB.ptr if emb else None, rows_per_batch=oh * ow, ldrb=cout, C32=dC.ptr, ldc32=cout)
+    kernels.gemm(a)
+    got = dC.download((n, oh, ow, cout), np.float32).transpose(0, 3, 1, 2)
+    assert rel(got, ref) < 2e-5
+
+
+def test_gemm_rejects_bad_args(K):
+    kernels, _lib = K
+    a = kernels.GemmArgs(A=16, lda=12, W_=16, ldb=8, M=4, N=4, K=12, C32=16, ldc32=4)
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a)
+    a = kernels.GemmArgs(A=16, lda=8, W_=16, ldb=8, M=0, N=4, K=8, C32=16, ldc32=4)   # empty problem is an error, not a no-op
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a)
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("nb,heads,dh,tq,tk,causal", [
+    (1, 2, 64, 256, 256, 0), (2, 3, 64, 100, 77, 0), (1, 4, 64, 77, 77, 1), (1, 2, 40, 200, 200, 0),
+    (1, 2, 80, 130, 77, 0), (1, 2, 160, 64, 64, 0), (1, 2, 32, 64, 77, 0), (2, 10, 64, 1024, 1024, 0),
+    (1, 1, 64, 1, 1, 0), (1, 2, 64, 300, 300, 1)])
+def test_attention(K, nb, heads, dh, tq, tk, causal):
+    kernels, _lib = K
+    rng = np.random.default_rng(dh + tq)
+    D = heads * dh
+    q = f16r(rng.standard_normal((nb, tq, D)))
+    k = f16r(rng.standard_normal((nb, tk, D)))
+    v = f16r(rng.standard_normal((nb, tk, D)))
+    ref = np.stack([O.from_ot(O.L().orc_attention(O.to_ot(q[i][None, None]), O.to_ot(k[i][None, None]),
+                                                   O.to_ot(v[i][None, None]), heads, causal)).reshape(tq, D)
+                    for i in range(nb)])
+    dq, dk, dv = (dev(_lib, a.astype(np.float16)) for a in (q, k, v))
+    do = _lib.DeviceBuffer(nb * tq * D * 2)
+    a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
+                         bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=causal)
+    kernels.attention(a)
+    got = do.download((nb, tq, D), np.float16).astype(np.float32)
+    assert np.isfinite(got).all()
+    assert rel(got, ref) < 2e-3
+
+
+def test_attention_fused_qkv_strides(K):
+    """q/k/v as column slices of one [T][3*D] projection output (how the UNet self-attention feeds it)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(3)
+    heads, dh, T = 5, 64, 192
+    D = heads * dh
+    qkv = f16r(rng.standard_normal((1, T, 3 * D)))
+    ref = O.from_ot(O.L().orc_attention(O.to_ot(qkv[:, :, :D][None]), O.to_ot(qkv[:, :, D:2 * D][None]),
+                                        O.to_ot(qkv[:, :, 2 * D:][None]), heads, 0)).reshape(T, D)
+    d = dev(_lib, qkv.astype(np.float16))
+    do = _lib.DeviceBuffer(T * D * 2)
+    a = kernels.AttnArgs(q=d.ptr, k=d.ptr + D * 2, v=d.ptr + 4 * D, out=do.ptr, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D,
+                         n_batch=1, n_head=heads, d_head=dh, Tq=T, Tk=T, causal=0)
+    kernels.attention(a)
+    assert rel(do.download((T, D), np.float16).astype(np.float32), ref) < 2e-3
+
+
+def test_attention_online_softmax_rescale_branch(K):
+    """Force the running-max jump: one key in the LAST tile dominates one query row (guide rule 26)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(11)
+    heads, dh, T = 1, 64, 256
+    q = f16r(rng.standard_normal((1, T, dh)))
+    k = f16r(rng.standard_normal((1, T, dh)))
+    v = f16r(rng.standard_normal((1, T, dh)))
+    k[0, 250] = f16r(q[0, 7] * 4.0)      # score jumps by ~ +4*|q|^2/8 at tile 3
+    ref = O.from_ot(O.L().orc_attention(O.to_ot(q[None]), O.to_ot(k[None]), O.to_ot(v[None]), heads, 0)).reshape(T, dh)
+    dq, dk, dv = (dev(_lib, a.astype(np.float16)) for a in (q, k, v))
+    do = _lib.DeviceBuffer(T * dh * 2)
+    a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=dh, ldk=dh, ldv=dh, ldo=dh, n_batch=1, n_head=1,
+                         d_head=dh, Tq=T, Tk=T, causal=0)
+    kernels.attention(a)
+    got = do.download((T, dh), np.float16).astype(np.float32)
+    assert np.abs(got[7] - ref[7]).max() < 5e-3 and rel(got, ref) < 2e-3
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("n,hw,c1,c2,silu,raw", [(2, 64, 64, 0, 1, 0), (1, 256, 320, 0, 1, 0), (2, 100, 640, 320, 1, 1),
+                                                  (1, 64, 1280, 1280, 0, 0), (1, 1024, 128, 0, 1, 1), (3, 16, 32, 32, 1, 0)])
+def test_groupnorm(K, n, hw, c1, c2, silu, raw):
+    kernels, _lib = K
+    rng = np.random.default_rng(c1 + c2)
+    C = c1 + c2
+    x1 = (rng.standard_normal((n, hw, c1)) * 2 + 3).astype(np.float32)       # non-zero mean: exercises the shifted sums
+    x2 = (rng.standard_normal((n, hw, max(c2, 1))) * 0.5 - 1).astype(np.float32)
+    gamma, beta = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    xc = np.concatenate([x1, x2[..., :c2]], -1)                               # [n][hw][C]
+    P = O.Params()
+    pg, pb = P.set("g", gamma), P.set("b", beta)
+    refs = []
+    for i in range(n):
+        t = O.L().orc_group_norm(O.to_ot(xc[i].T.reshape(1, C, hw, 1)), 32, 1e-6, pg, pb)
+        if silu:
+            O.L().orc_silu(t)
+        refs.append(O.from_ot(t).reshape(C, hw).T)
+    ref = np.stack(refs)
+    d1, d2, dg, db = dev(_lib, x1), dev(_lib, x2), dev(_lib, gamma), dev(_lib, beta)
+    dy, dr = _lib.DeviceBuffer(n * hw * C * 2), _lib.DeviceBuffer(n * hw * C * 2)
+    ws = _lib.DeviceBuffer(kernels.groupnorm_ws_bytes(n, hw, 32))
+    a = kernels.GnArgs(x1=d1.ptr, x2=d2.ptr if c2 else None, ld1=c1, ld2=c2, C1=c1, C2=c2, n_img=n, HW=hw, n_grp=32,
+                       eps=1e-6, gamma=dg.ptr, beta=db.ptr, silu=silu, y16=dy.ptr, raw16=dr.ptr if raw else None, ws=ws.ptr)
+    kernels.groupnorm(a)
+    got = dy.download((n, hw, C), np.float16).astype(np.float32)
+    assert rel(got, ref) < 1e-3
+    if raw:
+        assert np.array_equal(dr.download((n, hw, C), np.float16), xc.astype(np.float16))
+
+
+@pytest.mark.parametrize("rows,d", [(7, 64), (77, 768), (1000, 320), (130, 1280), (5, 1024), (2, 2048)])
+def test_layernorm(K, rows, d):
+    kernels, _lib = K
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((rows, d)) * 3 - 2).astype(np.float32)
+    gamma, beta = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+    P = O.Params()
+    ref = O.from_ot(O.L().orc_layer_norm(O.to_ot(x[None, None]), 1e-5, P.set("g", gamma), P.set("b", beta))).reshape(rows, d)
+    dx, dg, db = dev(_lib, x), dev(_lib, gamma), dev(_lib, beta)
+    dy16, dy32 = _lib.DeviceBuffer(rows * d * 2), _lib.DeviceBuffer(rows * d * 4)
+    kernels.layernorm(dx.ptr, d, rows, d, 1e-5, dg.ptr, db.ptr, dy16.ptr, dy32.ptr)
+    assert rel(dy32.download((rows, d), np.float32), ref) < 2e-6
+    assert rel(dy16.download((rows, d), np.float16).astype(np.float32), ref) < 1e-3
+
+
+# ------------------------------------------------------------------ small ops
+def test_layout_and_small_ops(K):
+    kernels, _lib = K
+    L = _lib.lib()
+    vp = _lib.vp
+    rng = np.random.default_rng(0)
+    # NCHW -> NHWC fp16 with per-image scale, cond/uncond duplication and channel padding
+    x = rng.standard_normal((2, 4, 6, 5)).astype(np.float32)
+    scale = np.array([0.5, 2.0], np.float32)
+    dx, ds = dev(_lib, x), dev(_lib, scale)
+    dy = _lib.DeviceBuffer(4 * 30 * 8 * 2)
+    _lib.check(L.mlsd_nchw_to_nhwc_f16(vp(dx.ptr), 2, 4, 30, vp(dy.ptr), 4, 8, vp(ds.ptr), ctypes.c_float(1.0), 0, None))
+    got = dy.download((4, 30, 8), np.float16).astype(np.float32)
+    exp = np.zeros((4, 30, 8), np.float32)
+    for n in range(4):
+        exp[n, :, :4] = f16r((x[n % 2] * scale[n % 2]).reshape(4, 30).T)
+    assert np.array_equal(got, exp)
+    # TAE clamp mode: 3*tanh(x/3)
+    _lib.check(L.mlsd_nchw_to_nhwc_f16(vp(dx.ptr), 2, 4, 30, vp(dy.ptr), 2, 8, None, ctypes.c_float(1.0), 1, None))
+    got = dy.download((2, 30, 8), np.float16).astype(np.float32)[..., :4]
+    assert np.abs(got - (np.tanh(x / 3) * 3).reshape(2, 4, 30).transpose(0, 2, 1)).max() < 2e-3
+    # NHWC fp32 -> NCHW with (x+1)/2
+    y = rng.standard_normal((2, 30, 4)).astype(np.float32)
+    dyy, dz = dev(_lib, y), _lib.DeviceBuffer(2 * 3 * 30 * 4)
+    _lib.check(L.mlsd_nhwc_to_nchw_f32(vp(dyy.ptr), ctypes.c_int64(4), 2, 3, 30, vp(dz.ptr), ctypes.c_float(0.5), ctypes.c_float(0.5), None))
+    assert np.allclose(dz.download((2, 3, 30), np.float32), (y[..., :3].transpose(0, 2, 1) + 1) / 2, atol=1e-6)
+    # timestep embedding vs the oracle (cos first, then sin)
+    t = np.array([999.0, 353.89, 0.0], np.float32)
+    dt_, de = dev(_lib, t), _lib.DeviceBuffer(3 * 320 * 2)
+    _lib.check(L.mlsd_timestep_embedding(vp(dt_.ptr), 3, 320, ctypes.c_float(10000.0), vp(de.ptr), None))
+    ref = np.empty((3, 320), np.float32)
+    O.L().orc_timestep_embedding(O.fptr(t), 3, 320, 10000.0, O.fptr(ref))
+    assert np.abs(de.download((3, 320), np.float16).astype(np.float32) - ref).max() < 2e-3
+    # softmax rows
+    s = rng.standard_normal((5, 300)).astype(np.float32) * 4
+    dsx, dso = dev(_lib, s), _lib.DeviceBuffer(5 * 304 * 2)
+    _lib.check(L.mlsd_softmax_rows(vp(dsx.ptr), ctypes.c_int64(300), vp(dso.ptr), ctypes.c_int64(304), 5, 300, ctypes.c_float(0.25), None))
+    e = np.exp((s - s.max(1, keepdims=True)) * 0.25)
+    assert np.abs(dso.download((5, 304), np.float16)[:, :300].astype(np.float32) - e / e.sum(1, keepdims=True)).max() < 1e-3
+    # CLIP embedding gather + position add
+    tok = rng.integers(0, 50, (2, 7)).astype(np.int32)
+    tw, pw = f16r(rng.standard_normal((50, 16))), rng.standard_normal((7, 16)).astype(np.float32)
+    dtok, dtw, dpw, dout = dev(_lib, tok), dev(_lib, tw.astype(np.float16)), dev(_lib, pw), _lib.DeviceBuffer(2 * 7 * 16 * 4)
+    _lib.check(L.mlsd_clip_embed(vp(dtok.ptr), 2, 7, 16, vp(dtw.ptr), vp(dpw.ptr), vp(dout.ptr), None))
+    assert np.array_equal(dout.download((2, 7, 16), np.float32), tw[tok] + pw[None])
+
+
+def test_sampler_update_matches_host_formula(K):
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    rng = np.random.default_rng(1)
+    B, C, HW = 3, 4, 50
+    x = rng.standard_normal((B, C, HW)).astype(np.float32)
+    eps = rng.standard_normal((2 * B, HW, C)).astype(np.float32)
+    noise = rng.standard_normal((B, C, HW)).astype(np.float32)
+    dt, sup, f = np.array([-3.5, -1.25, -0.01], np.float32), np.array([0.7, 0.0, 2.0], np.float32), np.float32(7.0)
+    # host restatement: dx = c*f + u*(1-f) (mlimgsynth.c:1583); x += dx*dt (solvers.c:86); x += noise*s_up (sampling.c:115)
+    dxm = eps[:B] * f + eps[B:] * (np.float32(1) - f)
+    ref = x + dxm.transpose(0, 2, 1) * dt[:, None, None]
+    ref = ref + noise * sup[:, None, None]
+    d = [dev(_lib, a) for a in (x, eps, dt, noise, sup)]
+    _lib.check(L.mlsd_sampler_update(vp(d[0].ptr), vp(d[1].ptr), ctypes.c_int64(C), B, C, HW, ctypes.c_float(7.0),
+                                     vp(d[2].ptr), vp(d[3].ptr), vp(d[4].ptr), None))
+    got = d[0].download((B, C, HW), np.float32)
+    assert np.array_equal(got, ref.astype(np.float32))     # same fp32 operation order -> bit exact
+
+
+def test_synth_fill_bit_exact_vs_oracle(K):
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    import zlib
+    for name, shape, f16 in [("unet.in.conv.weight", (3, 3, 4, 64), True), ("unet.out.norm.weight", (64, 1, 1, 1), False),
+                             ("unet.mid.0.emb_proj.bias", (128, 1, 1, 1), False), ("unet.time_embed.0.weight", (64, 256, 1, 1), True)]:
+        n = int(np.prod(shape))
+        ne = (ctypes.c_int64 * 4)(*shape)
+        off, sc = ctypes.c_float(), ctypes.c_float()
+        O.L().orc_synth_rule(name.encode(), int(f16), ctypes.byref(ne), ctypes.byref(off), ctypes.byref(sc))
+        ref = np.empty(n, np.float32)
+        O.L().orc_synth_fill(O.fptr(ref), n, 1234, name.encode(), off, sc, int(f16))
+        # product-side key derivation is restated in the host library; here the raw kernel is checked with the oracle's key
+        key = oracle_key(name, 1234)
+        kf = np.float32(np.float64(sc.value) * 1.7320508075688772 / 65536.0)
+        buf = _lib.DeviceBuffer(n * 4)
+        _lib.check(L.mlsd_synth_fill(vp(buf.ptr), int(f16), ctypes.c_int64(n), ctypes.c_uint64(key), off, ctypes.c_float(kf), 0,
+                                     *[ctypes.c_int64(0)] * 5, None))
+        got = buf.download((n,), np.float16 if f16 else np.float32).astype(np.float32)
+        assert np.array_equal(got, ref), name
+
+
+def oracle_key(name, seed):
+    M = (1 << 64) - 1
+    h = 0xCBF29CE484222325
+    for ch in name.encode():
+        h = ((h ^ ch) * 0x100000001B3) & M
+    z = h ^ ((seed * 0x9E3779B97F4A7C15) & M)
+    z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & M
+    z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return z
