@@ -1,0 +1,120 @@
+/* mlblock_amd.h — the host side (C) of the MI355X engine: a re-creation of the reference's
+ * mlblock graph-builder API (src/mlblock.h:82-160, src/mlblock_nn.h:9-41) whose "tensors"
+ * are device buffers in channels-last layout and whose "graph" is a recorded launch plan
+ * of the HIP kernels in mlsd_kernels.h (replayed per evaluation, optionally as a hipGraph).
+ *
+ * Same names, argument meaning and error behaviour as the reference where a counterpart
+ * exists:  int results, >=1 ok, <0 error (ccommon.h TRY convention), message via
+ * mlsd_last_error().  Builder functions return NULL on error and latch the context into an
+ * error state that mlctx_prep() reports.
+ *
+ * Logical shapes follow the reference (ne[0] fastest: activations [W,H,C,N], sequences
+ * [d,T,N]); physical storage is [N][H*W][C] (= [N][T][d]) so image<->token reshapes and the
+ * head split/merge permutes cost nothing.
+ */
+#pragma once
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MLCtx MLCtx;
+typedef struct MLTensor MLTensor;
+
+enum { MLT_F32 = 0, MLT_F16 = 1, MLT_I32 = 26 };  /* ggml_type numbering (mlimgsynth.h:336-339) */
+
+enum MLCtxFlags {           /* src/mlblock.h:29-36 */
+	MLB_F_MULTI_COMPUTE = 1,
+	MLB_F_QUIET = 2,
+	MLB_F_DUMP = 4,
+	MLB_F_HIPGRAPH = 8,     /* new: capture the plan into a hipGraph at prep and replay it */
+};
+
+/* ---- context lifecycle (mlctx_begin/end/prep/compute: src/mlblock.c:54-345) */
+MLCtx* mlctx_new(void* stream);           /* stream: hipStream_t or NULL (default stream) */
+void   mlctx_destroy(MLCtx* C);
+void   mlctx_begin(MLCtx* C, const char* name);
+void   mlctx_end(MLCtx* C);
+void   mlctx_set_tprefix(MLCtx* C, const char* prefix);   /* C->c.tprefix */
+void   mlctx_set_flags(MLCtx* C, int flags);
+void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type; only MLT_F16 is implemented */
+int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
+int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
+int    mlctx_sync(MLCtx* C);
+
+/* ---- graph definition (src/mlblock.h:115-160) */
+void      mlctx_block_begin(MLCtx* C);
+MLTensor* mlctx_tensor_add(MLCtx* C, const char* name, MLTensor* t);
+MLTensor* mlctx_input_new(MLCtx* C, const char* name, int dtype, int n0, int n1, int n2, int n3);
+MLTensor* mlctx_result(MLCtx* C);
+
+/* ---- inputs / outputs at the host boundary (ltensor_to/from_backend, src/localtensor.h:96-106).
+ * Host data is in the reference layout (ne[0] fastest: NCHW fp32 for images). */
+int mlctx_input_set(MLCtx* C, MLTensor* t, const void* host_data, size_t nbytes);
+int mlctx_output_get(MLCtx* C, MLTensor* t, float* host_out, size_t nbytes);
+/* device-side access for callers that keep data resident (the sampler): pointer to the input's staging
+ * buffer in the reference layout (fp32 NCHW / int32) */
+void* mlctx_input_device_ptr(MLTensor* t);
+/* image inputs: read the NCHW fp32 source from `dev_src` ([n_src][C][HW]; graph image n uses n % n_src) scaled by
+ * dev_scale[n % n_src] (or scale0), instead of the staging buffer.  Must precede the first consumer.
+ * (c_in scaling + cond/uncond duplication of src/unet.c:470-472, src/mlimgsynth.c:1578-1582; mode 1 = TAE clamp) */
+int mlctx_input_bind(MLTensor* t, const float* dev_src, int n_src, const float* dev_scale, float scale0, int mode);
+/* portable fp16 conversion used by the parameter loader (RNE, as ggml_fp32_to_fp16_row) */
+uint16_t mlb_f32_to_f16_bits(float f);
+float mlb_f16_bits_to_f32(uint16_t h);
+const float* mlctx_tensor_device_f32(MLCtx* C, MLTensor* t, int64_t* ld);   /* channels-last fp32 view */
+void mlctx_tensor_shape(const MLTensor* t, int64_t ne[4]);
+
+/* ---- parameters (tstore_tensor_read / mlctx_tstore_load: src/mlblock.c:232-292) */
+int mlctx_param_count(const MLCtx* C);
+/* key = full dotted name as the reference derives it (src/mlblock.c:67-105) */
+int mlctx_param_info(const MLCtx* C, int i, const char** key, int* type, int64_t ne[4]);
+/* load one parameter from host memory in the REFERENCE layout/shape (element count is what is checked,
+ * src/mlblock.c:243); src_type MLT_F32 or MLT_F16; converted/repacked to the engine's device layout */
+int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void* host_data, int64_t n_elem);
+/* deterministic synthetic weights (bench/tests: no checkpoints exist): same generator as oracle/o_core.c */
+int mlctx_params_synth(MLCtx* C, uint64_t seed);
+
+/* ---- statistics (MLCtxInfo, src/mlblock.h:74-79) */
+typedef struct MLCtxInfo {
+	size_t mem_params, mem_compute, mem_total;
+	double t_load, t_compute;
+	unsigned n_compute, n_conv;
+	unsigned n_ops;          /* kernels launched per compute */
+	double flops;            /* algorithmic FLOPs per compute (2*MAC of conv, linear, QK^T, PV) */
+} MLCtxInfo;
+void mlctx_info(const MLCtx* C, MLCtxInfo* out);
+/* per-op listing for profiling: returns kernel label, flops of op i */
+int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flops);
+/* time every op individually with HIP events (diagnostics; synchronises) */
+int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out);
+
+/* ---- NN blocks (src/mlblock_nn.h:9-41) */
+MLTensor* mlb_nn_linear(MLCtx* C, MLTensor* x, int n_out, bool bias);
+MLTensor* mlb_nn_conv2d(MLCtx* C, MLTensor* x, int ch_out,
+	int k0, int k1, int s0, int s1, int p0, int p1, int d0, int d1, bool bias);
+MLTensor* mlb_nn_layer_norm(MLCtx* C, MLTensor* x, bool affine, bool bias, float eps);
+MLTensor* mlb_nn_groupnorm(MLCtx* C, MLTensor* x, int n_grp, bool affine, float eps);
+static inline MLTensor* mlb_nn_groupnorm32(MLCtx* C, MLTensor* x) { return mlb_nn_groupnorm(C, x, 32, true, 1e-6f); }
+MLTensor* mlb_downsample(MLCtx* C, MLTensor* x, int ch_out, bool vae);
+MLTensor* mlb_upsample(MLCtx* C, MLTensor* x, int ch_out);
+MLTensor* mlb_resnet(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out);
+MLTensor* mlb_GEGLU(MLCtx* C, MLTensor* x, int d_out);
+MLTensor* mlb_feed_forward(MLCtx* C, MLTensor* x, int d_out, int mult);
+MLTensor* mlb_attn_mhead(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v,
+	int d_out, int d_embed, int n_head, bool mask, bool bias, bool bias_out);
+MLTensor* mlb_basic_transf(MLCtx* C, MLTensor* x, MLTensor* c, int d_out, int d_embed, int n_head);
+
+/* elementwise graph ops the reference builders call on ggml directly */
+MLTensor* mlb_silu(MLCtx* C, MLTensor* x);                       /* ggml_silu(_inplace) */
+MLTensor* mlb_add(MLCtx* C, MLTensor* a, MLTensor* b);           /* ggml_add, same shape; `a` is consumed */
+MLTensor* mlb_concat_ch(MLCtx* C, MLTensor* a, MLTensor* b);     /* ggml_concat(a,b,2), zero-copy */
+MLTensor* mlb_timestep_embedding(MLCtx* C, MLTensor* t, int dim, int max_period);
+void      mlb_release(MLCtx* C, MLTensor* t);                    /* the caller will not use t again */
+
+#ifdef __cplusplus
+}
+#endif

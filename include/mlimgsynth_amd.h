@@ -1,0 +1,145 @@
+/* mlimgsynth_amd.h — model graphs, sampler and the generation driver of the MI355X engine.
+ *
+ * Mirrors, for the hot path only, the reference's model/sampler interfaces:
+ *   UnetParams / unet_*      src/unet.h:10-62        VaeParams / sdvae_decode   src/vae.h:10-53
+ *   SdTaeParams / sdtae_*    src/tae.h               ClipParams / clip_text_*   src/clip.h
+ *   DenoiseSampler           src/sampling.h:17-46    Solver (Euler)             src/solvers.h:65-77
+ *   RngPhilox                src/ccommon/rng_philox.h:10-22
+ *   mlis_generate slice      include/mlimgsynth.h:414-558, src/mlimgsynth.c:1634-1773
+ * Differences that are the point of the exercise: every graph takes a batch dimension N
+ * (the reference rejects n_batch > 1, src/mlimgsynth.c:1640), cond and uncond evaluations
+ * of classifier-free guidance run as ONE batch-2B UNet evaluation, and the latent, the
+ * Euler(-ancestral) update and the CFG mix stay on the device between steps.
+ * Return convention: >=1 ok, <0 error (reference TRY convention), text in mlsd_last_error().
+ */
+#pragma once
+#include "mlblock_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- UNet (src/unet.h) */
+typedef struct {
+	int n_ch_in, n_ch_out, n_res_blk;
+	int attn_res[4];
+	int ch_mult[5];
+	int transf_depth[5];
+	int n_te, n_head, d_head, n_ctx, n_ch, ch_adm_in;
+	int clip_norm, cond_label, uncond_empty_zero, vparam;
+	int n_step_train;
+	float sigma_min, sigma_max;
+} UnetParams;
+
+/* "sd1" | "sd2" | "sdxl" (g_unet_sd1/sd2/sdxl, src/unet.c:21-83) | "tiny" | "tinyxl" (test configs) */
+int unet_params_get(const char* model, UnetParams* out);
+
+MLTensor* mlb_unet_denoise(MLCtx* C, MLTensor* x, MLTensor* time, MLTensor* c, MLTensor* label, const UnetParams* P);
+
+void  unet_params_init(void);
+float unet_sigma_to_t(const UnetParams* P, float sigma);
+float unet_t_to_sigma(const UnetParams* P, float t);
+
+typedef struct {
+	MLCtx* ctx;
+	const UnetParams* par;
+	unsigned nfe;
+	int lw, lh, n_batch;           /* graph batch N (= 2*images with CFG) */
+	MLTensor *t_x, *t_t, *t_c, *t_l, *t_out;
+} UnetState;
+
+/* builds the batch-N graph on C (prefix "unet"); weights are loaded afterwards with
+ * mlctx_params_synth / mlctx_param_set */
+int unet_denoise_init(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, unsigned n_batch);
+/* second half of the init: records the graph and calls mlctx_prep (split so that the x input can first be
+ * bound to a device-resident latent with mlctx_input_bind) */
+int unet_denoise_build(UnetState* S);
+/* host-boundary evaluation (tests, drop-in for src/unet.c:460-498 with a batch): x [N][4][lh][lw] NCHW,
+ * cond [N][77][n_ctx], label [N][adm] or NULL, sigma[N] -> dx like x.  Applies c_in, sigma->t, v-param. */
+int unet_denoise_run(UnetState* S, const float* x, const float* cond, const float* label,
+	const float* sigma, float* dx);
+
+/* ---------------------------------------------------------------- VAE / TAE decoders */
+typedef struct {
+	int ch_x, ch_z, ch, n_res, n_res_blk;
+	int ch_mult[5];
+	int d_embed, f_down;
+	float scale_factor;
+} VaeParams;
+int vae_params_get(const char* model, VaeParams* out);   /* "sd1" | "sdxl" | "tiny" */
+MLTensor* mlb_sdvae_decoder(MLCtx* C, MLTensor* x, const VaeParams* P);
+/* builds the decode graph for n images of lw x lh latents on C (prefix "vae"); result [8lw,8lh,3,n] */
+int sdvae_decode_init(MLCtx* C, const VaeParams* P, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent);
+/* host-boundary decode incl. the (x+1)/2 post (src/vae.h:43-47): latent NCHW [n][4][lh][lw] -> img [n][3][8lh][8lw] */
+int sdvae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img);
+
+typedef struct { int ch_x, ch_inner, ch_z, n_blk; } SdTaeParams;
+MLTensor* mlb_sdtae_decoder(MLCtx* C, MLTensor* x, const SdTaeParams* P);
+int sdtae_decode_init(MLCtx* C, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent);
+int sdtae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img);
+
+/* ---------------------------------------------------------------- CLIP text encoder (src/clip.h) */
+typedef struct {
+	int n_vocab, n_token, d_embed, n_interm, n_head, n_layer;
+	int tok_start, tok_end, tok_pad;
+} ClipParams;
+int clip_params_get(const char* model, ClipParams* out);   /* "vit_l" | "vit_h" | "vit_bigg" | "tiny" */
+/* clip_text_encode (src/clip.c:439-488) for a batch of n prompts: toks [n][n_tok] (without BOS/EOS/PAD,
+ * all prompts padded by the caller to the same n_tok), embed out [n][77][d] or NULL, feat out [n][d] or NULL */
+int clip_text_encode(MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt, unsigned n_tok,
+	const int32_t* toks, float* embed, float* feat, int clip_skip, bool norm, uint64_t synth_seed);
+
+/* ---------------------------------------------------------------- RNG / schedule / sampler */
+typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
+void rng_philox_randn(RngPhilox* S, unsigned n, float* out);
+
+enum { DNSAMP_SCHED_UNIFORM = 1, DNSAMP_SCHED_KARRAS = 2 };      /* src/sampling.h:11-14 */
+enum { SOLVER_METHOD_EULER = 1 };                                /* src/solvers.h:56-62 (others: next) */
+
+/* dnsamp_init schedule (src/sampling.c:28-96): fills sigmas[0..n_step], returns n_step */
+int  dnsamp_schedule(const UnetParams* P, int n_step, int sched, float f_t_ini, float f_t_end, float* sigmas);
+void dnsamp_ancestral(float s1, float s2, float eta, float* s_down, float* s_up);
+
+/* ---------------------------------------------------------------- generation driver (mlis_generate slice) */
+typedef struct MLIS_AmdCtx MLIS_AmdCtx;
+
+typedef struct {
+	const char* model;       /* "sd1" | "sdxl" | "tiny" | "tinyxl" */
+	int width, height;       /* pixels (multiple of 8) */
+	int n_batch;             /* images generated together on this GPU */
+	int n_step;              /* 20 */
+	float cfg_scale;         /* 7 */
+	float s_ancestral;       /* 1 = euler_a */
+	int sched;               /* DNSAMP_SCHED_UNIFORM */
+	int use_tae;             /* decode with TAESD instead of the KL-VAE */
+	int use_hipgraph;        /* replay each UNet evaluation as one hipGraph launch */
+	uint64_t weight_seed;    /* synthetic weights seed (1234) */
+} MLIS_AmdConfig;
+
+MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream);
+void mlis_amd_destroy(MLIS_AmdCtx* S);
+/* conditioning for the whole batch (shared prompt, as generate.sh): cond/uncond [77][n_ctx] fp32 host,
+ * label/unlabel [adm] or NULL */
+int mlis_amd_set_cond(MLIS_AmdCtx* S, const float* cond, const float* label, const float* uncond, const float* unlabel);
+/* device-resident variant used after an RCCL broadcast: pointers are DEVICE pointers of the same shapes */
+int mlis_amd_set_cond_device(MLIS_AmdCtx* S, const void* cond, const void* label, const void* uncond, const void* unlabel);
+/* runs the denoising loop for n_batch images with seeds[i] (offset 0 per image, src/generate.sh:56-59
+ * semantics) and decodes; everything is enqueued on the stream, the call returns after the final sync.
+ * latents_out [n][4][lh][lw] and/or images_out [n][3][h][w] (host, may be NULL) */
+int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* latents_out, float* images_out);
+/* pieces, for tests and for the multi-GPU driver */
+int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */
+int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device */
+void* mlis_amd_latent_device(MLIS_AmdCtx* S);                               /* fp32 NCHW [n][4][lh][lw] */
+void* mlis_amd_image_device(MLIS_AmdCtx* S);                                /* fp32 NCHW [n][3][h][w] */
+int mlis_amd_info(MLIS_AmdCtx* S, double* unet_flops_per_eval, double* decode_flops, int* unet_ops, size_t* mem_params,
+	size_t* mem_compute);
+MLCtx* mlis_amd_unet_ctx(MLIS_AmdCtx* S);
+MLCtx* mlis_amd_decoder_ctx(MLIS_AmdCtx* S);
+/* time of the last mlis_amd_denoise spent in UNet evaluations, measured with HIP events on the stream (ms) */
+float mlis_amd_last_unet_ms(MLIS_AmdCtx* S);
+int mlis_amd_last_nfe(MLIS_AmdCtx* S);
+
+#ifdef __cplusplus
+}
+#endif

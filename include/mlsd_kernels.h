@@ -27,6 +27,10 @@ extern "C" {
 /* ---------------------------------------------------------------- runtime (replaces ggml_backend_*:
  * src/mlimgsynth.c:1131-1161, src/localtensor.h:96-106, src/mlblock.c:257) */
 const char* mlsd_last_error(void);
+/* dry mode: memory calls are served from host memory so the plan builder can run without a GPU; no kernel
+ * can be launched (every launcher fails).  Used by the CPU-only tests of the host logic. */
+void mlsd_runtime_dry(int on);
+int mlsd_runtime_is_dry(void);
 int mlsd_device_count(void);
 int mlsd_device_set(int dev);
 int mlsd_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cu,

@@ -6,9 +6,14 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 static thread_local char g_err[512] = "";
+// "dry" mode: device memory calls are served from host memory so that the host-side plan builder
+// (shapes, parameter names, FLOP accounting) can be exercised on a machine without a GPU.  No kernel
+// can be launched in this mode: every launcher fails loudly.
+static int g_dry = 0;
 
 extern "C" {
 
@@ -23,12 +28,15 @@ int mlsd_set_error(int code, const char* fmt, ...)
 
 int mlsd_check_launch(const char* what)
 {
+    if (g_dry) return mlsd_set_error(-2, "%s: no GPU (dry mode builds plans only)", what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlsd_set_error(-(int)e - 1000, "launch %s failed: %s", what, hipGetErrorString(e));
     return 0;
 }
 
 MLSD_API const char* mlsd_last_error(void) { return g_err; }
+MLSD_API void mlsd_runtime_dry(int on) { g_dry = on; }
+MLSD_API int mlsd_runtime_is_dry(void) { return g_dry; }
 
 MLSD_API int mlsd_device_count(void)
 {
@@ -66,12 +74,14 @@ MLSD_API int mlsd_device_info(int dev, char* name, int name_len, char* arch, int
 MLSD_API int mlsd_malloc(void** out, size_t nbytes)
 {
     *out = NULL;
+    if (g_dry) { *out = calloc(1, nbytes ? nbytes : 16); return *out ? 0 : mlsd_set_error(-1, "out of host memory"); }
     MLSD_HIP_TRY(hipMalloc(out, nbytes ? nbytes : 16));
     return 0;
 }
 
 MLSD_API int mlsd_free(void* p)
 {
+    if (g_dry) { free(p); return 0; }
     if (p) MLSD_HIP_TRY(hipFree(p));
     return 0;
 }
@@ -91,6 +101,7 @@ MLSD_API int mlsd_host_free(void* p)
 
 MLSD_API int mlsd_memset(void* dst, int value, size_t nbytes, void* stream)
 {
+    if (g_dry) { memset(dst, value, nbytes); return 0; }
     MLSD_HIP_TRY(hipMemsetAsync(dst, value, nbytes, (hipStream_t)stream));
     return 0;
 }
@@ -98,6 +109,7 @@ MLSD_API int mlsd_memset(void* dst, int value, size_t nbytes, void* stream)
 // kind: 0 = host->device, 1 = device->host, 2 = device->device
 MLSD_API int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind, void* stream)
 {
+    if (g_dry) { memcpy(dst, src, nbytes); return 0; }
     hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     MLSD_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, k, (hipStream_t)stream));
     return 0;
@@ -119,6 +131,7 @@ MLSD_API int mlsd_stream_destroy(void* s)
 
 MLSD_API int mlsd_stream_sync(void* s)
 {
+    if (g_dry) return 0;
     MLSD_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
     return 0;
 }

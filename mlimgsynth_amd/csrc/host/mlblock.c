@@ -1,0 +1,617 @@
+/* Host-side graph builder + plan executor (C), the MI355X re-creation of the reference's
+ * MLCtx runtime (src/mlblock.h:44-160, src/mlblock.c:54-345).
+ *
+ *   reference                         here
+ *   ---------                         ----
+ *   two ggml contexts (cp, cc)        MLParam table (device-resident weights) + MLTensor list
+ *   ggml_cgraph + gallocr             recorded launch plan (MLOp[]) + arena with exact-size reuse
+ *   mlctx_load_prep name resolution   same backward walk over (name, BLOCK_BEGIN) records
+ *   mlctx_tstore_load + tensor_set    mlctx_param_set (repack to device layout) / mlctx_params_synth
+ *   ggml_backend_graph_compute        mlctx_compute: replay the plan on a HIP stream, or one
+ *                                     hipGraphLaunch when MLB_F_HIPGRAPH is set
+ */
+#include "mlblock_int.h"
+#include <math.h>
+#include <stdarg.h>
+#include <time.h>
+
+#define CHUNK_BYTES   ((size_t)64 << 20)
+#define BIG_BYTES     ((size_t)8 << 20)
+#define ALIGN_UP(x,a) (((x) + (a) - 1) / (a) * (a))
+
+#define VEC_PUSH(C, arr, n, cap, T) \
+	(((n) == (cap) ? ((cap) = (cap) ? (cap)*2 : 64, (arr) = (T*)realloc((arr), sizeof(T)*(cap))) : 0), &(arr)[(n)++])
+
+static double now_s(void)
+{
+	struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec*1e-9;
+}
+
+int mlctx_fail(MLCtx* C, const char* fmt, ...)
+{
+	char buf[400];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+	if (C && !C->err) C->err = -1;
+	return mlsd_set_error(-1, "%s%s%s", C ? C->name : "", C ? ": " : "", buf);
+}
+
+/* ------------------------------------------------------------------ lifecycle */
+MLB_API MLCtx* mlctx_new(void* stream)
+{
+	MLCtx *C = (MLCtx*)calloc(1, sizeof(MLCtx));
+	C->stream = stream;
+	C->wtype = MLT_F16;
+	return C;
+}
+
+static void ctx_reset(MLCtx* C)
+{
+	if (C->graph_exec) { mlsd_graph_destroy(C->graph_exec); C->graph_exec = NULL; }
+	for (int i=0;i<C->n_tensors;++i) free(C->tensors[i]);
+	C->n_tensors = 0; C->n_inputs = 0; C->result = NULL;
+	for (int i=0;i<C->n_names;++i) free(C->names[i].name);
+	C->n_names = 0;
+	for (int i=0;i<C->n_params;++i) free(C->params[i].key);
+	C->n_params = 0;
+	C->n_ops = 0;
+	for (int i=0;i<C->n_chunks;++i) mlsd_free(C->chunks[i]);
+	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
+	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
+	C->err = 0; C->prepared = 0;
+	memset(&C->info, 0, sizeof(C->info));
+}
+
+MLB_API void mlctx_destroy(MLCtx* C)
+{
+	if (!C) return;
+	mlsd_stream_sync(C->stream);
+	ctx_reset(C);
+	free(C->ops); free(C->tensors); free(C->inputs); free(C->names); free(C->params); free(C->chunks); free(C->freel);
+	free(C);
+}
+
+MLB_API void mlctx_begin(MLCtx* C, const char* name)
+{
+	mlsd_stream_sync(C->stream);
+	ctx_reset(C);
+	snprintf(C->name, sizeof(C->name), "%s", name ? name : "");
+}
+
+MLB_API void mlctx_end(MLCtx* C) { mlsd_stream_sync(C->stream); ctx_reset(C); }
+MLB_API void mlctx_set_tprefix(MLCtx* C, const char* p) { snprintf(C->tprefix, sizeof(C->tprefix), "%s", p ? p : ""); }
+MLB_API void mlctx_set_flags(MLCtx* C, int f) { C->flags = f; }
+MLB_API void mlctx_set_wtype(MLCtx* C, int t) { C->wtype = t; }
+MLB_API MLTensor* mlctx_result(MLCtx* C) { return C->result; }
+MLB_API int mlctx_sync(MLCtx* C) { return mlsd_stream_sync(C->stream) ? -1 : 1; }
+
+/* ------------------------------------------------------------------ device memory */
+/* A released block may be handed out again only to a writer that runs AFTER the block's last reader.
+ * Ops run in recorded order, so a block released when `rel_op` ops had been recorded is safe for any op
+ * with index >= rel_op.  `writer_op` is the index of the op that will write the new allocation: the next
+ * op to be recorded for ordinary allocations (INT32_MAX), or the already-recorded producer when a GEMM
+ * output is bound late (mlt_need16/32). */
+static void* dalloc_ex(MLCtx* C, size_t nbytes, int is_param, int writer_op)
+{
+	nbytes = ALIGN_UP(nbytes ? nbytes : 256, 256);
+	if (!is_param) {
+		for (int i=C->n_free-1; i>=0; --i) if (C->freel[i].size == nbytes && C->freel[i].rel_op <= writer_op) {
+			void *p = C->freel[i].ptr;
+			C->freel[i] = C->freel[--C->n_free];
+			C->mem_live += nbytes; if (C->mem_live > C->mem_peak_live) C->mem_peak_live = C->mem_live;
+			return p;
+		}
+	}
+	void *p = NULL;
+	if (nbytes >= BIG_BYTES) {
+		if (mlsd_malloc(&p, nbytes)) { mlctx_fail(C, "device allocation of %zu bytes failed", nbytes); return NULL; }
+		*VEC_PUSH(C, C->chunks, C->n_chunks, C->cap_chunks, void*) = p;
+	} else {
+		if (C->cur_left < nbytes) {
+			void *c = NULL;
+			if (mlsd_malloc(&c, CHUNK_BYTES)) { mlctx_fail(C, "device chunk allocation failed"); return NULL; }
+			*VEC_PUSH(C, C->chunks, C->n_chunks, C->cap_chunks, void*) = c;
+			C->cur = (char*)c; C->cur_left = CHUNK_BYTES;
+		}
+		p = C->cur; C->cur += nbytes; C->cur_left -= nbytes;
+	}
+	if (is_param) C->mem_params += nbytes;
+	else { C->mem_compute += nbytes; C->mem_live += nbytes; if (C->mem_live > C->mem_peak_live) C->mem_peak_live = C->mem_live; }
+	return p;
+}
+
+void* mlctx_dalloc(MLCtx* C, size_t nbytes, int is_param) { return dalloc_ex(C, nbytes, is_param, 0x7fffffff); }
+
+void mlctx_drelease(MLCtx* C, void* p, size_t nbytes)
+{
+	if (!p || !nbytes) return;
+	nbytes = ALIGN_UP(nbytes, 256);
+	MLFreeBlk *b = VEC_PUSH(C, C->freel, C->n_free, C->cap_free, MLFreeBlk);
+	b->ptr = p; b->size = nbytes; b->rel_op = C->n_ops;
+	C->mem_live -= nbytes;
+}
+
+/* ------------------------------------------------------------------ tensors */
+MLTensor* mlt_new(MLCtx* C, int n, int h, int w, int c)
+{
+	MLTensor *t = (MLTensor*)calloc(1, sizeof(MLTensor));
+	t->n = n; t->h = h; t->w = w; t->c = c; t->prod = -1;
+	if (h > 1 || 0) { t->ne[0]=w; t->ne[1]=h; t->ne[2]=c; t->ne[3]=n; }
+	else { t->ne[0]=c; t->ne[1]=w; t->ne[2]=n; t->ne[3]=1; }
+	*VEC_PUSH(C, C->tensors, C->n_tensors, C->cap_tensors, MLTensor*) = t;
+	return t;
+}
+
+MLB_API void mlctx_tensor_shape(const MLTensor* t, int64_t ne[4]) { memcpy(ne, t->ne, sizeof(t->ne)); }
+
+MLOp* mlctx_op_new(MLCtx* C, MLOpKind kind, const char* label)
+{
+	MLOp *op = VEC_PUSH(C, C->ops, C->n_ops, C->cap_ops, MLOp);
+	memset(op, 0, sizeof(*op));
+	op->kind = kind;
+	snprintf(op->label, sizeof(op->label), "%s", label ? label : "");
+	return op;
+}
+
+float* mlt_need32(MLCtx* C, MLTensor* t)
+{
+	if (!t) return NULL;
+	if (t->d32) return t->d32;
+	if (t->released) { mlctx_fail(C, "use of released tensor %s", t->name); return NULL; }
+	const int64_t rows = (int64_t)t->n * t->h * t->w;
+	if (t->prod >= 0) {
+		MLOp *op = &C->ops[t->prod];
+		t->sz32 = (size_t)rows * t->c * sizeof(float);
+		t->d32 = (float*)dalloc_ex(C, t->sz32, 0, t->prod); t->ld32 = t->c;
+		op->u.gemm.C32 = t->d32; op->u.gemm.ldc32 = t->c;
+		return t->d32;
+	}
+	mlctx_fail(C, "tensor %s has no fp32 form", t->name);
+	return NULL;
+}
+
+void* mlt_need16(MLCtx* C, MLTensor* t)
+{
+	if (!t) return NULL;
+	if (t->d16) return t->d16;
+	if (t->released) { mlctx_fail(C, "use of released tensor %s", t->name); return NULL; }
+	const int64_t rows = (int64_t)t->n * t->h * t->w;
+	if (t->prod >= 0) {
+		MLOp *op = &C->ops[t->prod];
+		t->sz16 = (size_t)rows * t->c * 2;
+		t->d16 = dalloc_ex(C, t->sz16, 0, t->prod); t->ld16 = t->c;
+		op->u.gemm.C16 = t->d16; op->u.gemm.ldc16 = t->c;
+		return t->d16;
+	}
+	if (t->is_input && t->in_type == MLT_F32 && t->h > 1) {
+		/* image input in reference (NCHW fp32) layout -> channels-last fp16, channels padded to 8 */
+		const int cpad = (t->c + 7) / 8 * 8;
+		t->sz16 = (size_t)rows * cpad * 2;
+		t->d16 = mlctx_dalloc(C, t->sz16, 0); t->ld16 = cpad;
+		MLOp *op = mlctx_op_new(C, OP_NCHW2NHWC, "nchw_to_nhwc_f16");
+		op->u.n2h.src = t->in_src ? t->in_src : (const float*)t->in_stage;
+		op->u.n2h.n_src = t->in_src ? t->in_src_n : t->n; op->u.n2h.C = t->c; op->u.n2h.HW = t->h*t->w;
+		op->u.n2h.dst = t->d16; op->u.n2h.n_dst = t->n; op->u.n2h.Cpad = cpad;
+		op->u.n2h.scale = t->in_scale; op->u.n2h.scale0 = t->in_scale0; op->u.n2h.mode = t->in_mode;
+		return t->d16;
+	}
+	if (t->d32 && t->ld32 == t->c) {
+		t->sz16 = (size_t)rows * t->c * 2;
+		t->d16 = mlctx_dalloc(C, t->sz16, 0); t->ld16 = t->c;
+		MLOp *op = mlctx_op_new(C, OP_ACT, "f32_to_f16");
+		op->u.act.x = t->d32; op->u.act.y = t->d16; op->u.act.n = (size_t)rows * t->c; op->u.act.act = MLSD_ACT_NONE;
+		return t->d16;
+	}
+	mlctx_fail(C, "tensor %s has no fp16 form", t->name);
+	return NULL;
+}
+
+MLB_API void mlb_release(MLCtx* C, MLTensor* t)
+{
+	if (!t || t->released || t->is_input) return;
+	t->released = 1;
+	if (t->sz32) mlctx_drelease(C, t->d32, t->sz32);
+	if (t->sz16) mlctx_drelease(C, t->d16, t->sz16);
+	if (t->sz_silu) mlctx_drelease(C, t->silu16, t->sz_silu);
+	t->d32 = NULL; t->d16 = NULL; t->silu16 = NULL; t->sz32 = t->sz16 = t->sz_silu = 0;
+	/* an un-consumed GEMM output keeps its op pointers: the op still writes to memory that may be reused
+	 * only AFTER this point in the recorded order, which stream order makes safe. */
+}
+
+/* ------------------------------------------------------------------ naming records (src/mlblock.h:115-132) */
+MLB_API void mlctx_block_begin(MLCtx* C)
+{
+	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
+	r->kind = 0; r->name = NULL; r->param = -1;
+}
+
+void mlctx_named_op(MLCtx* C, const char* name)
+{
+	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
+	r->kind = 1; r->name = strdup(name); r->param = -1;
+}
+
+MLB_API MLTensor* mlctx_tensor_add(MLCtx* C, const char* name, MLTensor* t)
+{
+	mlctx_named_op(C, name);
+	if (t) { snprintf(t->name, sizeof(t->name), "%s", name); C->result = t; }
+	return t;
+}
+
+MLParam* mlctx_param_new(MLCtx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3,
+	int layout, int64_t lp0, int64_t lp1)
+{
+	(void)lp0; (void)lp1;
+	return mlctx_param_new_at(C, name, type, n0, n1, n2, n3, layout, NULL);
+}
+
+MLParam* mlctx_param_new_at(MLCtx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3,
+	int layout, void* dev)
+{
+	MLParam *p = VEC_PUSH(C, C->params, C->n_params, C->cap_params, MLParam);
+	memset(p, 0, sizeof(*p));
+	p->type = type; p->ne[0]=n0; p->ne[1]=n1; p->ne[2]=n2; p->ne[3]=n3; p->layout = layout;
+	size_t elems = (size_t)(n0*n1*n2*n3);
+	if (layout == 1) {        /* conv [k0,k1,cin,cout] -> [cout][k1][k0][cin_pad] */
+		const int64_t cpad = (n2 + 7) / 8 * 8;
+		p->lp[0]=n0; p->lp[1]=n1; p->lp[2]=n2; p->lp[3]=n3; p->lp[4]=cpad;
+		elems = (size_t)(n0*n1*cpad*n3);
+	} else if (layout == 2) { /* GEGLU weight [n_in, 2d] */
+		p->lp[0]=n0; p->lp[1]=n1/2;
+	} else if (layout == 3) { /* GEGLU bias [2d] */
+		p->lp[0]=1; p->lp[1]=n0/2;
+	}
+	p->dev_elems = elems;
+	const size_t esz = type == MLT_F16 ? 2 : 4;
+	p->dev = dev ? dev : mlctx_dalloc(C, elems * esz, 1);
+	if (p->dev && layout == 1 && p->lp[4] != n2) mlsd_memset(p->dev, 0, elems * esz, C->stream);
+	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
+	r->kind = 2; r->name = strdup(name); r->param = C->n_params - 1;
+	return &C->params[C->n_params - 1];
+}
+
+/* mlctx_load_prep, src/mlblock.c:67-105: walk the records backwards; a named op opens a scope that the
+ * matching BLOCK_BEGIN closes; a parameter's key is the scope path + its own name. */
+static int resolve_names(MLCtx* C)
+{
+	char path[512] = "";
+	int stack[256], sp = 0;
+	if (C->tprefix[0]) mlctx_named_op(C, C->tprefix);   /* mlctx_prep :318 */
+	for (int i=C->n_names-1; i>=0; --i) {
+		MLNameRec *r = &C->names[i];
+		int nlen = (int)strlen(path);
+		if (r->kind == 0) {
+			if (!sp) return mlctx_fail(C, "invalid ML graph (unbalanced block)");
+			path[stack[--sp]] = 0;
+		} else {
+			if (nlen + strlen(r->name) + 2 >= sizeof(path)) return mlctx_fail(C, "tensor name too long");
+			snprintf(path + nlen, sizeof(path) - nlen, "%s%s", nlen ? "." : "", r->name);
+			if (r->kind == 2) {
+				free(C->params[r->param].key);
+				C->params[r->param].key = strdup(path);
+				path[nlen] = 0;
+			} else {
+				if (sp == 256) return mlctx_fail(C, "block nesting too deep");
+				stack[sp++] = nlen;
+			}
+		}
+	}
+	return 1;
+}
+
+/* ------------------------------------------------------------------ inputs */
+static MLTensor* input_finish(MLCtx* C, MLTensor* t, const char* name, int dtype)
+{
+	t->is_input = 1; t->in_type = dtype; t->in_scale0 = 1.0f;
+	snprintf(t->name, sizeof(t->name), "%s", name);
+	t->in_bytes = (size_t)(t->ne[0]*t->ne[1]*t->ne[2]*t->ne[3]) * 4;
+	t->in_stage = mlctx_dalloc(C, t->in_bytes, 0);
+	if (dtype == MLT_F32 && t->h == 1) { t->d32 = (float*)t->in_stage; t->ld32 = t->c; }
+	*VEC_PUSH(C, C->inputs, C->n_inputs, C->cap_inputs, MLTensor*) = t;
+	return t;
+}
+
+MLTensor* mlctx_input_new_seq(MLCtx* C, const char* name, int dtype, int d, int T, int N)
+{	/* [d,T,N,1]: channels-last storage equals the reference order */
+	MLTensor *t = mlt_new(C, N, 1, T, d);
+	t->ne[0]=d; t->ne[1]=T; t->ne[2]=N; t->ne[3]=1;
+	return input_finish(C, t, name, dtype);
+}
+
+MLTensor* mlctx_input_new_img(MLCtx* C, const char* name, int w, int h, int c, int n)
+{	/* [W,H,C,N]: host/staging data is NCHW fp32 (LocalTensor, src/localtensor.h:16-20) */
+	MLTensor *t = mlt_new(C, n, h, w, c);
+	t->ne[0]=w; t->ne[1]=h; t->ne[2]=c; t->ne[3]=n;
+	if (h == 1) { t->h = 1; }
+	return input_finish(C, t, name, MLT_F32);
+}
+
+MLB_API MLTensor* mlctx_input_new(MLCtx* C, const char* name, int dtype, int n0, int n1, int n2, int n3)
+{	/* reference signature (src/mlblock.h:134-143).  [W,H,C,N] images have a small channel dim and H>1;
+	 * everything else is a sequence/vector [d,T,N]. */
+	if (dtype == MLT_F32 && (n3 > 1 || (n2 > 1 && n2 <= 16 && n1 > 1 && n0 > 1))) return mlctx_input_new_img(C, name, n0, n1, n2, n3);
+	if (n3 > 1) { mlctx_fail(C, "mlctx_input_new(%s): unsupported 4-D non-image input", name); return NULL; }
+	return mlctx_input_new_seq(C, name, dtype, n0, n1, n2);
+}
+
+MLB_API int mlctx_input_bind(MLTensor* t, const float* dev_src, int n_src, const float* dev_scale, float scale0, int mode)
+{
+	if (!t || !t->is_input || t->d16) return -1;   /* must be bound before the first consumer is recorded */
+	t->in_src = dev_src; t->in_src_n = n_src; t->in_scale = dev_scale; t->in_scale0 = scale0; t->in_mode = mode;
+	return 1;
+}
+
+MLB_API void* mlctx_input_device_ptr(MLTensor* t) { return t ? t->in_stage : NULL; }
+
+MLB_API int mlctx_input_set(MLCtx* C, MLTensor* t, const void* host, size_t nbytes)
+{
+	if (!t || !t->is_input) return mlctx_fail(C, "mlctx_input_set: not an input tensor");
+	if (nbytes != t->in_bytes) return mlctx_fail(C, "mlctx_input_set(%s): size %zu != %zu", t->name, nbytes, t->in_bytes);
+	if (mlsd_memcpy(t->in_stage, host, nbytes, 0, C->stream)) return -1;
+	if (mlsd_stream_sync(C->stream)) return -1;
+	return 1;
+}
+
+MLB_API const float* mlctx_tensor_device_f32(MLCtx* C, MLTensor* t, int64_t* ld)
+{
+	(void)C;
+	if (!t || !t->d32) return NULL;
+	if (ld) *ld = t->ld32;
+	return t->d32;
+}
+
+MLB_API int mlctx_output_get(MLCtx* C, MLTensor* t, float* out, size_t nbytes)
+{
+	if (!t || !t->d32) return mlctx_fail(C, "mlctx_output_get: tensor has no fp32 data");
+	const int64_t rows = (int64_t)t->n * t->h * t->w, c = t->c;
+	if (nbytes != (size_t)rows * c * 4) return mlctx_fail(C, "mlctx_output_get(%s): size %zu != %zu", t->name, nbytes, (size_t)rows*c*4);
+	if (t->ld32 != c) return mlctx_fail(C, "mlctx_output_get: strided tensor");
+	if (t->h == 1) {   /* sequence: channels-last == reference order */
+		if (mlsd_memcpy(out, t->d32, nbytes, 1, C->stream) || mlsd_stream_sync(C->stream)) return -1;
+		return 1;
+	}
+	float *tmp = (float*)malloc(nbytes);
+	if (mlsd_memcpy(tmp, t->d32, nbytes, 1, C->stream) || mlsd_stream_sync(C->stream)) { free(tmp); return -1; }
+	const int64_t hw = (int64_t)t->h * t->w;   /* [n][hw][c] -> [n][c][hw] (ltensor_from_backend gives NCHW) */
+	for (int64_t n=0;n<t->n;++n) for (int64_t p=0;p<hw;++p) for (int64_t ch=0;ch<c;++ch)
+		out[(n*c + ch)*hw + p] = tmp[(n*hw + p)*c + ch];
+	free(tmp);
+	return 1;
+}
+
+/* ------------------------------------------------------------------ prep / compute */
+static int run_op(MLCtx* C, MLOp* op)
+{
+	void *st = C->stream;
+	switch (op->kind) {
+	case OP_GEMM: return mlsd_gemm(&op->u.gemm, st);
+	case OP_ATTN: return mlsd_attention(&op->u.attn, st);
+	case OP_GN:   return mlsd_groupnorm(&op->u.gn, st);
+	case OP_LN:   return mlsd_layernorm(op->u.ln.x, op->u.ln.ldx, op->u.ln.rows, op->u.ln.d, op->u.ln.eps, op->u.ln.g, op->u.ln.b,
+	                                   op->u.ln.y16, op->u.ln.y32, st);
+	case OP_NCHW2NHWC: return mlsd_nchw_to_nhwc_f16(op->u.n2h.src, op->u.n2h.n_src, op->u.n2h.C, op->u.n2h.HW, op->u.n2h.dst,
+	                                   op->u.n2h.n_dst, op->u.n2h.Cpad, op->u.n2h.scale, op->u.n2h.scale0, op->u.n2h.mode, st);
+	case OP_NHWC2NCHW: return mlsd_nhwc_to_nchw_f32(op->u.h2n.src, op->u.h2n.ld, op->u.h2n.n, op->u.h2n.C, op->u.h2n.HW,
+	                                   op->u.h2n.dst, op->u.h2n.mul, op->u.h2n.add, st);
+	case OP_TEMB: return mlsd_timestep_embedding(op->u.temb.t, op->u.temb.n, op->u.temb.dim, op->u.temb.maxp, op->u.temb.out, st);
+	case OP_ACT:  return mlsd_act_f32_to_f16(op->u.act.x, op->u.act.y, op->u.act.n, op->u.act.act, st);
+	case OP_CLIP_EMBED: return mlsd_clip_embed(op->u.cemb.tok, op->u.cemb.n, op->u.cemb.T, op->u.cemb.d, op->u.cemb.tw,
+	                                   op->u.cemb.pw, op->u.cemb.out, st);
+	case OP_SOFTMAX: return mlsd_softmax_rows(op->u.smax.in, op->u.smax.ld_in, op->u.smax.out, op->u.smax.ld_out,
+	                                   op->u.smax.rows, op->u.smax.cols, op->u.smax.scale, st);
+	case OP_COPY_F32: return mlsd_memcpy(op->u.copy.dst, op->u.copy.src, op->u.copy.nbytes, 2, st);
+	}
+	return mlsd_set_error(-1, "unknown op kind %d", (int)op->kind);
+}
+
+MLB_API int mlctx_prep(MLCtx* C)
+{
+	if (C->err) return C->err;
+	if (!C->n_names || !C->result) return mlctx_fail(C, "mlctx_prep: empty graph");
+	if (!mlt_need32(C, C->result)) return -1;
+	if (resolve_names(C) < 0) return -1;
+	double fl = 0; unsigned nconv = 0;
+	for (int i=0;i<C->n_ops;++i) {
+		MLOp *op = &C->ops[i];
+		if (op->kind == OP_GEMM) {
+			if (!op->u.gemm.C32 && !op->u.gemm.C16) return mlctx_fail(C, "op %d (%s): output never consumed", i, op->label);
+			if (op->u.gemm.conv) nconv++;
+		}
+		fl += op->flops;
+	}
+	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;
+	C->info.mem_params = C->mem_params; C->info.mem_compute = C->mem_compute; C->info.mem_total = C->mem_params + C->mem_compute;
+	if (C->err) return C->err;
+	C->prepared = 1;
+	return 1;
+}
+
+MLB_API int mlctx_compute(MLCtx* C)
+{
+	if (!C->prepared) return mlctx_fail(C, "mlctx_compute before mlctx_prep");
+	for (int i=0;i<C->n_params;++i) if (!C->params[i].loaded)
+		return mlctx_fail(C, "parameter '%s' was never loaded", C->params[i].key);
+	double t0 = now_s();
+	if (C->flags & MLB_F_HIPGRAPH) {
+		if (!C->graph_exec) {
+			if (mlsd_capture_begin(C->stream)) return -1;
+			int rc = 0;
+			for (int i=0;i<C->n_ops && !rc;++i) rc = run_op(C, &C->ops[i]);
+			void *ge = NULL;
+			int rc2 = mlsd_capture_end(C->stream, &ge);
+			if (rc || rc2) return mlctx_fail(C, "hipGraph capture failed");
+			C->graph_exec = ge;
+		}
+		if (mlsd_graph_launch(C->graph_exec, C->stream)) return -1;
+	} else {
+		for (int i=0;i<C->n_ops;++i) {
+			int rc = run_op(C, &C->ops[i]);
+			if (rc) { mlctx_fail(C, "op %d (%s) failed", i, C->ops[i].label); return -1; }
+		}
+	}
+	C->info.t_compute = now_s() - t0;   /* enqueue time: the stream is asynchronous */
+	C->info.n_compute++;
+	return 1;
+}
+
+MLB_API void mlctx_info(const MLCtx* C, MLCtxInfo* out)
+{
+	*out = C->info;
+	out->mem_params = C->mem_params; out->mem_compute = C->mem_compute; out->mem_total = C->mem_params + C->mem_compute;
+}
+
+MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flops)
+{
+	if (i < 0 || i >= C->n_ops) return -1;
+	if (label) {
+		const MLOp *op = &C->ops[i];
+		*label = op->kind == OP_GEMM && !op->label[0] ? mlsd_gemm_variant(&op->u.gemm) : op->label;
+	}
+	if (flops) *flops = C->ops[i].flops;
+	return 1;
+}
+
+MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
+{
+	if (!C->prepared) return mlctx_fail(C, "mlctx_profile_ops before mlctx_prep");
+	void *e0 = NULL, *e1 = NULL;
+	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
+	for (int i=0;i<C->n_ops;++i) {
+		mlsd_event_record(e0, C->stream);
+		if (run_op(C, &C->ops[i])) return -1;
+		mlsd_event_record(e1, C->stream);
+		mlsd_event_sync(e1);
+		float ms = 0; mlsd_event_elapsed_ms(e0, e1, &ms);
+		if (i < n_out) ms_out[i] = ms;
+	}
+	mlsd_event_destroy(e0); mlsd_event_destroy(e1);
+	return C->n_ops;
+}
+
+/* ------------------------------------------------------------------ parameters */
+MLB_API int mlctx_param_count(const MLCtx* C) { return C->n_params; }
+
+MLB_API int mlctx_param_info(const MLCtx* C, int i, const char** key, int* type, int64_t ne[4])
+{
+	if (i < 0 || i >= C->n_params) return -1;
+	if (key) *key = C->params[i].key;
+	if (type) *type = C->params[i].type;
+	if (ne) memcpy(ne, C->params[i].ne, sizeof(C->params[i].ne));
+	return 1;
+}
+
+static uint16_t f32_to_f16_rne(float f)
+{	/* portable IEEE binary32 -> binary16, round to nearest even (what ggml_fp32_to_fp16_row does) */
+	uint32_t x; memcpy(&x, &f, 4);
+	const uint32_t sign = (x >> 16) & 0x8000u;
+	x &= 0x7FFFFFFFu;
+	if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x200u : 0));   /* inf / nan */
+	if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                       /* overflow -> inf */
+	if (x < 0x33000001u) return (uint16_t)sign;                                                    /* underflow -> 0 */
+	int e = (int)(x >> 23) - 127;
+	uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+	int shift = e < -14 ? (13 + (-14 - e)) : 13;
+	uint32_t hm = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (hm & 1))) hm++;
+	uint32_t he = e < -14 ? 0 : (uint32_t)(e + 15);
+	uint32_t h = e < -14 ? hm : ((he << 10) + (hm - 0x400u) );
+	return (uint16_t)(sign | h);
+}
+
+MLB_API uint16_t mlb_f32_to_f16_bits(float f) { return f32_to_f16_rne(f); }
+
+static float f16_to_f32(uint16_t h)
+{
+	uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1F, m = h & 0x3FF, x;
+	if (e == 0) {
+		if (!m) x = sign;
+		else { int s = 0; while (!(m & 0x400)) { m <<= 1; s++; } m &= 0x3FF; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+	} else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+	else x = sign | ((e + 112) << 23) | (m << 13);
+	float f; memcpy(&f, &x, 4); return f;
+}
+
+MLB_API float mlb_f16_bits_to_f32(uint16_t h) { return f16_to_f32(h); }
+
+static int64_t param_dst_index(const MLParam* p, int64_t i)
+{
+	switch (p->layout) {
+	case 1: {
+		const int64_t k0 = i % p->lp[0]; int64_t t = i / p->lp[0];
+		const int64_t k1 = t % p->lp[1]; t /= p->lp[1];
+		const int64_t ci = t % p->lp[2], co = t / p->lp[2];
+		return ((co * p->lp[1] + k1) * p->lp[0] + k0) * p->lp[4] + ci;
+	}
+	case 2: {
+		const int64_t k = i % p->lp[0], row = i / p->lp[0], d = p->lp[1];
+		const int64_t j = row < d ? row : row - d;
+		return ((j >> 5) * 64 + (row < d ? 0 : 32) + (j & 31)) * p->lp[0] + k;
+	}
+	case 3: {
+		const int64_t d = p->lp[1], j = i < d ? i : i - d;
+		return (j >> 5) * 64 + (i < d ? 0 : 32) + (j & 31);
+	}
+	default: return i;
+	}
+}
+
+MLB_API int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void* host, int64_t n_elem)
+{
+	if (!C->prepared) return mlctx_fail(C, "mlctx_param_set before mlctx_prep (names are resolved at prep)");
+	MLParam *p = NULL;
+	for (int i=0;i<C->n_params;++i) if (C->params[i].key && !strcmp(C->params[i].key, key)) { p = &C->params[i]; break; }
+	if (!p) return mlctx_fail(C, "unknown parameter '%s'", key);
+	const int64_t n = p->ne[0]*p->ne[1]*p->ne[2]*p->ne[3];
+	if (n != n_elem) return mlctx_fail(C, "parameter '%s': %lld elements given, %lld expected", key, (long long)n_elem, (long long)n);
+	const size_t esz = p->type == MLT_F16 ? 2 : 4;
+	void *buf = calloc(p->dev_elems, esz);
+	for (int64_t i=0;i<n;++i) {
+		float v = src_type == MLT_F16 ? f16_to_f32(((const uint16_t*)host)[i]) : ((const float*)host)[i];
+		const int64_t o = param_dst_index(p, i);
+		if (p->type == MLT_F16) ((uint16_t*)buf)[o] = f32_to_f16_rne(v); else ((float*)buf)[o] = v;
+	}
+	int rc = mlsd_memcpy(p->dev, buf, p->dev_elems * esz, 0, C->stream);
+	if (!rc) rc = mlsd_stream_sync(C->stream);
+	free(buf);
+	if (rc) return -1;
+	p->loaded = 1;
+	return 1;
+}
+
+/* synthetic weights: restatement of oracle/o_core.c (orc_synth_rule / orc_synth_fill key derivation) */
+static uint64_t mix64(uint64_t z)
+{
+	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+	z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+	z ^= z >> 31; return z;
+}
+
+MLB_API int mlctx_params_synth(MLCtx* C, uint64_t seed)
+{
+	if (!C->prepared) return mlctx_fail(C, "mlctx_params_synth before mlctx_prep");
+	double t0 = now_s();
+	for (int i=0;i<C->n_params;++i) {
+		MLParam *p = &C->params[i];
+		int nd = 4; while (nd > 1 && p->ne[nd-1] == 1) nd--;
+		float offset = 0, scale;
+		const size_t lk = strlen(p->key);
+		if (nd == 1) {
+			if (lk >= 5 && !strcmp(p->key + lk - 5, ".bias")) { offset = 0; scale = 0.05f; }
+			else { offset = 1; scale = 0.1f; }
+		} else {
+			const double fan_in = nd >= 3 ? (double)p->ne[0]*p->ne[1]*p->ne[2] : (double)p->ne[0];
+			scale = (float)(1.0 / sqrt(fan_in));
+		}
+		uint64_t h = 0xCBF29CE484222325ULL;
+		for (const char *s = p->key; *s; ++s) { h ^= (unsigned char)*s; h *= 0x100000001B3ULL; }
+		const uint64_t key = mix64(h ^ (seed * 0x9E3779B97F4A7C15ULL));
+		const float kf = (float)((double)scale * 1.7320508075688772 / 65536.0);
+		const int64_t n = p->ne[0]*p->ne[1]*p->ne[2]*p->ne[3];
+		if (mlsd_synth_fill(p->dev, p->type == MLT_F16 ? 1 : 0, n, key, offset, kf, p->layout,
+				p->lp[0], p->lp[1], p->lp[2], p->lp[3], p->lp[4], C->stream)) return -1;
+		p->loaded = 1;
+	}
+	if (mlsd_stream_sync(C->stream)) return -1;
+	C->info.t_load = now_s() - t0;
+	return 1;
+}

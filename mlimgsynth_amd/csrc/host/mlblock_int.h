@@ -1,0 +1,124 @@
+/* Internal structures of the host-side builder/executor (not part of the C-ABI). */
+#pragma once
+#include "mlblock_amd.h"
+#include "mlsd_kernels.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MLB_API __attribute__((visibility("default")))
+
+int mlsd_set_error(int code, const char* fmt, ...);
+
+typedef enum {
+	OP_GEMM, OP_ATTN, OP_GN, OP_LN, OP_NCHW2NHWC, OP_NHWC2NCHW, OP_TEMB, OP_ACT, OP_CLIP_EMBED, OP_SOFTMAX,
+	OP_COPY_F32,
+} MLOpKind;
+
+typedef struct MLOp {
+	MLOpKind kind;
+	double flops;
+	char label[56];
+	union {
+		mlsd_gemm_args gemm;
+		mlsd_attn_args attn;
+		mlsd_gn_args gn;
+		struct { const float* x; int64_t ldx; int rows, d; float eps; const float *g, *b; void* y16; float* y32; } ln;
+		struct { const float* src; int n_src, C, HW; void* dst; int n_dst, Cpad; const float* scale; float scale0; int mode; } n2h;
+		struct { const float* src; int64_t ld; int n, C, HW; float* dst; float mul, add; } h2n;
+		struct { const float* t; int n, dim; float maxp; void* out; } temb;
+		struct { const float* x; void* y; size_t n; int act; } act;
+		struct { const int32_t* tok; int n, T, d; const void* tw; const float* pw; float* out; } cemb;
+		struct { const float* in; int64_t ld_in; void* out; int64_t ld_out; int rows, cols; float scale; } smax;
+		struct { const void* src; void* dst; size_t nbytes; } copy;
+	} u;
+} MLOp;
+
+struct MLTensor {
+	int64_t ne[4];          /* logical (reference) shape */
+	int n, h, w, c;         /* physical: [n][h*w][c] */
+	float* d32;  int64_t ld32;
+	void*  d16;  int64_t ld16;
+	size_t sz32, sz16;      /* arena sizes (0 = not arena owned) */
+	int prod;               /* index of the producing GEMM op, or -1 */
+	MLTensor *cat_a, *cat_b;/* virtual channel concat (both fp32) */
+	void* silu16;           /* cached fp16 silu(x) (embedding) */
+	size_t sz_silu;
+	int is_input, in_type;
+	void* in_stage;         /* device staging buffer in reference layout (inputs) */
+	size_t in_bytes;
+	/* optional override of the NCHW source of an image input (sampler keeps the latent resident) */
+	const float* in_src; int in_src_n; const float* in_scale; float in_scale0; int in_mode;
+	int released;
+	char name[48];
+};
+
+typedef struct MLParam {
+	char* key;              /* resolved at prep */
+	int type;               /* reference type: MLT_F16 / MLT_F32 */
+	int64_t ne[4];          /* reference shape (ne[0] fastest) */
+	int layout;             /* 0 plain, 1 conv OIHW->OHWI(cin_pad), 2 GEGLU weight interleave, 3 GEGLU bias interleave */
+	int64_t lp[5];
+	void* dev;              /* device data in engine layout */
+	size_t dev_elems;       /* elements allocated (incl. padding) */
+	int loaded;
+} MLParam;
+
+typedef struct { int kind; char* name; int param; } MLNameRec;  /* kind: 0 block begin, 1 named op, 2 param */
+
+typedef struct { void* ptr; size_t size; int rel_op; } MLFreeBlk;   /* rel_op: ops recorded at release time */
+
+struct MLCtx {
+	void* stream;
+	char name[64];
+	char tprefix[32];
+	int flags, wtype;
+	int err;
+	/* plan */
+	MLOp* ops; int n_ops, cap_ops;
+	MLTensor** tensors; int n_tensors, cap_tensors;
+	MLTensor** inputs; int n_inputs, cap_inputs;
+	MLTensor* result;
+	MLNameRec* names; int n_names, cap_names;
+	MLParam* params; int n_params, cap_params;
+	/* device memory */
+	void** chunks; int n_chunks, cap_chunks;
+	char* cur; size_t cur_left;
+	MLFreeBlk* freel; int n_free, cap_free;
+	size_t mem_compute, mem_params, mem_peak_live, mem_live;
+	void* gn_ws; size_t gn_ws_bytes;
+	void* graph_exec;
+	int prepared;
+	MLCtxInfo info;
+};
+
+/* internal helpers shared by mlblock_nn.c and the model builders */
+MLTensor* mlt_new(MLCtx* C, int n, int h, int w, int c);
+void*     mlctx_dalloc(MLCtx* C, size_t nbytes, int is_param);
+void      mlctx_drelease(MLCtx* C, void* p, size_t nbytes);
+MLOp*     mlctx_op_new(MLCtx* C, MLOpKind kind, const char* label);
+int       mlctx_fail(MLCtx* C, const char* fmt, ...);
+MLParam*  mlctx_param_new(MLCtx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3,
+	int layout, int64_t lp0, int64_t lp1);
+MLParam*  mlctx_param_new_at(MLCtx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3,
+	int layout, void* dev);   /* dev != NULL: parameter lives in caller-provided device memory */
+void      mlctx_named_op(MLCtx* C, const char* name);   /* naming record for an op tensor (MLN(name, op)) */
+float*    mlt_need32(MLCtx* C, MLTensor* t);
+void*     mlt_need16(MLCtx* C, MLTensor* t);
+
+MLTensor* mlctx_input_new_seq(MLCtx* C, const char* name, int dtype, int d, int T, int N);
+MLTensor* mlctx_input_new_img(MLCtx* C, const char* name, int w, int h, int c, int n);
+
+/* fused building blocks (mlblock_nn.c) */
+typedef struct {
+	int act;                 /* MLSD_ACT_* */
+	MLTensor* resid;         /* fp32 residual added in the epilogue (same rows x n_out) */
+	MLTensor* rowbias;       /* fp32 [n][n_out] added per image (time embedding) */
+} MLEpilogue;
+MLTensor* mlb_linear_ex(MLCtx* C, MLTensor* x, int n_out, bool bias, const MLEpilogue* ep, int geglu);
+MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int upsample, bool bias, const MLEpilogue* ep);
+MLTensor* mlb_groupnorm_ex(MLCtx* C, MLTensor* x, int n_grp, float eps, int silu, int want_raw16, MLTensor** raw_out);
+MLTensor* mlb_layer_norm_ex(MLCtx* C, MLTensor* x, float eps, int out32);
+MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int d_out, int d_embed, int n_head,
+	bool mask, bool bias, bool bias_out, MLTensor* resid);
+MLTensor* mlb_resnet_ex(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out);
