@@ -92,6 +92,8 @@ typedef struct mlsd_gemm_args {
 	int64_t ldc32;
 	void* C16;              /* fp16 output [M][ldc16] or NULL */
 	int64_t ldc16;
+	const float* bias_m;    /* [M] per-row bias (operands swapped: V^T = Wv . x^T in the VAE attention) or NULL */
+	int act_after_resid;    /* 1: activation applied after the residual add (TAESD block: relu(conv + x), src/tae.c:36-37) */
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -171,6 +173,8 @@ int mlsd_clip_embed(const int32_t* tokens, int n, int T, int d, const void* tok_
  * f<=1: only cond is read).  dt, s_up: fp32 [B] on device. noise may be NULL. */
 int mlsd_sampler_update(float* x, const float* eps, int64_t ld, int B, int C, int HW, float cfg,
                         const float* dt, const float* noise, const float* s_up, void* stream);
+/* dnsamp_noise_add (src/sampling.c:112-117): x[b] += noise[b] * s[b]; x, noise fp32 [B][per], s fp32 [B] on device */
+int mlsd_noise_add(float* x, const float* noise, const float* s, int B, int64_t per, void* stream);
 /* finite check (ltensor_finite_check, src/unet.c:487): counts non-finite values into *count (device int32) */
 int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream);
 /* deterministic synthetic parameter fill, bit-identical to oracle/o_core.c orc_synth_fill.

@@ -102,6 +102,13 @@ __global__ void sampler_update_kernel(float* __restrict__ x, const float* __rest
     }
 }
 
+__global__ void noise_add_kernel(float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ s, int B, long per)
+{
+    const long total = (long)B * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        x[i] = __fadd_rn(x[i], __fmul_rn(noise[i], s[i / per]));   // x += noise*sigma, src/sampling.c:115
+}
+
 __global__ void count_nonfinite_kernel(const float* __restrict__ x, size_t n, int32_t* __restrict__ count)
 {
     int bad = 0;
@@ -206,6 +213,12 @@ MLSD_API int mlsd_sampler_update(float* x, const float* eps, int64_t ld, int B, 
     hipLaunchKernelGGL(sampler_update_kernel, dim3(nblocks((long)B * C * HW)), dim3(256), 0, (hipStream_t)stream, x, eps, (long)ld, B,
                        C, HW, cfg, dt, noise, s_up);
     return mlsd_check_launch("sampler_update");
+}
+
+MLSD_API int mlsd_noise_add(float* x, const float* noise, const float* s, int B, int64_t per, void* stream)
+{
+    hipLaunchKernelGGL(noise_add_kernel, dim3(nblocks((long)B * per)), dim3(256), 0, (hipStream_t)stream, x, noise, s, B, (long)per);
+    return mlsd_check_launch("noise_add");
 }
 
 MLSD_API int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream)

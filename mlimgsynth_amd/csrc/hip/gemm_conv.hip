@@ -37,6 +37,8 @@ struct GemmP {
     int H, W, Cin, OH, OW, KH, KW, stride, pad, ups;
     // epilogue
     const float* bias;
+    const float* biasm;
+    int act_post;
     const float* rowbias;
     int rows_per_batch;
     long ldrb;
@@ -210,7 +212,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     if (n >= p.N) continue;
                     float v = acc[i][j][e];
                     if (p.bias) v += p.bias[n];
+                    if (p.biasm) v += p.biasm[m];
                     if (rbias) v += rbias[n];
+                    if (p.act_post && p.resid) v += p.resid[(long)m * p.ldr + n];
                     switch (p.act) {
                     case MLSD_ACT_SILU: v = silu_f(v); break;
                     case MLSD_ACT_GELU: v = gelu_tanh_f(v); break;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     case MLSD_ACT_RELU: v = fmaxf(v, 0.f); break;
                     default: break;
                     }
-                    if (p.resid) v += p.resid[(long)m * p.ldr + n];
+                    if (!p.act_post && p.resid) v += p.resid[(long)m * p.ldr + n];
                     if (p.C32) p.C32[(long)m * p.ldc32 + n] = v;
                     if (p.C16) p.C16[(long)m * p.ldc16 + n] = (_Float16)v;
                 }
@@ -251,7 +255,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
     p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
     p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample;
-    p.bias = a->bias; p.rowbias = a->rowbias; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+    p.bias = a->bias; p.biasm = a->bias_m; p.act_post = a->act_after_resid; p.rowbias = a->rowbias; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
     p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;

@@ -115,7 +115,7 @@ static void* dalloc_ex(MLCtx* C, size_t nbytes, int is_param, int writer_op)
 		}
 		p = C->cur; C->cur += nbytes; C->cur_left -= nbytes;
 	}
-	if (is_param) C->mem_params += nbytes;
+	if (is_param == 1) C->mem_params += nbytes;
 	else { C->mem_compute += nbytes; C->mem_live += nbytes; if (C->mem_live > C->mem_peak_live) C->mem_peak_live = C->mem_live; }
 	return p;
 }
@@ -178,9 +178,19 @@ void* mlt_need16(MLCtx* C, MLTensor* t)
 	const int64_t rows = (int64_t)t->n * t->h * t->w;
 	if (t->prod >= 0) {
 		MLOp *op = &C->ops[t->prod];
-		t->sz16 = (size_t)rows * t->c * 2;
-		t->d16 = dalloc_ex(C, t->sz16, 0, t->prod); t->ld16 = t->c;
-		op->u.gemm.C16 = t->d16; op->u.gemm.ldc16 = t->c;
+		if (t->c % 8) {
+			/* consumer convs need 8-channel pixels: rows padded with zeros.  The GEMM never writes the pad
+			 * columns, so the buffer is zeroed once here and never recycled (sz16 stays 0). */
+			const int cpad = (t->c + 7) / 8 * 8;
+			const size_t sz = (size_t)rows * cpad * 2;
+			t->d16 = dalloc_ex(C, sz, 2, 0); t->ld16 = cpad;
+			if (t->d16) mlsd_memset(t->d16, 0, sz, C->stream);
+		} else {
+			t->sz16 = (size_t)rows * t->c * 2;
+			t->d16 = dalloc_ex(C, t->sz16, 0, t->prod); t->ld16 = t->c;
+		}
+		op = &C->ops[t->prod];
+		op->u.gemm.C16 = t->d16; op->u.gemm.ldc16 = t->ld16;
 		return t->d16;
 	}
 	if (t->is_input && t->in_type == MLT_F32 && t->h > 1) {
@@ -446,7 +456,11 @@ MLB_API int mlctx_compute(MLCtx* C)
 	} else {
 		for (int i=0;i<C->n_ops;++i) {
 			int rc = run_op(C, &C->ops[i]);
-			if (rc) { mlctx_fail(C, "op %d (%s) failed", i, C->ops[i].label); return -1; }
+			if (rc) {
+				char why[300]; snprintf(why, sizeof(why), "%s", mlsd_last_error());
+				mlsd_set_error(-1, "%s: op %d (%s) failed: %s", C->name, i, C->ops[i].label, why);
+				return -1;
+			}
 		}
 	}
 	C->info.t_compute = now_s() - t0;   /* enqueue time: the stream is asynchronous */

@@ -114,6 +114,7 @@ typedef struct {
 	int act;                 /* MLSD_ACT_* */
 	MLTensor* resid;         /* fp32 residual added in the epilogue (same rows x n_out) */
 	MLTensor* rowbias;       /* fp32 [n][n_out] added per image (time embedding) */
+	int act_post;            /* activation after the residual add (TAESD block) */
 } MLEpilogue;
 MLTensor* mlb_linear_ex(MLCtx* C, MLTensor* x, int n_out, bool bias, const MLEpilogue* ep, int geglu);
 MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int upsample, bool bias, const MLEpilogue* ep);

@@ -49,6 +49,7 @@ MLTensor* mlb_linear_ex(MLCtx* C, MLTensor* x, int n_out, bool bias, const MLEpi
 	g->W_ = wd; g->ldb = n_in; g->M = (int)rows_of(x); g->N = n_out; g->K = n_in;
 	g->bias = bd; g->resid = rd; g->ldr = ldr;
 	g->act = geglu ? MLSD_ACT_GEGLU : (ep ? ep->act : MLSD_ACT_NONE);
+	g->act_after_resid = ep ? ep->act_post : 0;
 	op->flops = 2.0 * g->M * (double)n_out * n_in;
 	y->prod = C->n_ops - 1;
 	return y;
@@ -92,6 +93,7 @@ MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, 
 	g->W_ = wd; g->ldb = (int64_t)k*k*cpad; g->M = x->n*OH*OW; g->N = ch_out; g->K = k*k*cpad;
 	g->bias = bd; g->rowbias = rb; g->rows_per_batch = OH*OW; g->ldrb = ch_out; g->resid = rd; g->ldr = ldr;
 	g->act = ep ? ep->act : MLSD_ACT_NONE;
+	g->act_after_resid = ep ? ep->act_post : 0;
 	op->flops = 2.0 * g->M * (double)ch_out * k * k * ch_in;
 	y->prod = C->n_ops - 1;
 	return y;

@@ -176,3 +176,185 @@ class Unet:
         dx = np.empty_like(x)
         check1(L().unet_denoise_run(ctypes.byref(self.S), fptr(x), fptr(cond), fptr(lab), fptr(sigma), fptr(dx)), "unet_denoise_run")
         return dx
+
+
+def _proto2():
+    l = L()
+    if getattr(l, "_proto2_done", False):
+        return l
+    l.vae_params_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(VaeParams)]
+    l.sdvae_decode_init.argtypes = [vp, ctypes.POINTER(VaeParams), ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(vp)]
+    l.sdvae_decode_build.argtypes = [vp, ctypes.POINTER(VaeParams), vp]
+    l.sdvae_decode_run.argtypes = [vp, vp, FP, FP]
+    l.sdtae_decode_init.argtypes = [vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(vp)]
+    l.sdtae_decode_build.argtypes = [vp, vp]
+    l.sdtae_decode_run.argtypes = [vp, vp, FP, FP]
+    l.clip_params_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(ClipParams)]
+    l.clip_text_encode.argtypes = [vp, ctypes.POINTER(ClipParams), ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint,
+                                   ctypes.POINTER(ctypes.c_int32), FP, FP, c_int, ctypes.c_bool, c_u64]
+    l.rng_philox_randn.argtypes = [vp, ctypes.c_uint, FP]
+    l.dnsamp_schedule.argtypes = [ctypes.POINTER(UnetParams), c_int, c_int, c_f, c_f, FP]
+    l.dnsamp_ancestral.argtypes = [c_f, c_f, c_f, FP, FP]
+    l.mlis_amd_create.restype = vp
+    l.mlis_amd_create.argtypes = [ctypes.POINTER(AmdConfig), vp]
+    l.mlis_amd_destroy.argtypes = [vp]
+    l.mlis_amd_set_cond.argtypes = [vp, FP, FP, FP, FP]
+    l.mlis_amd_set_cond_device.argtypes = [vp, vp, vp, vp, vp]
+    l.mlis_amd_generate.argtypes = [vp, ctypes.POINTER(c_u64), FP, FP]
+    l.mlis_amd_denoise.argtypes = [vp, ctypes.POINTER(c_u64)]
+    l.mlis_amd_decode.argtypes = [vp]
+    l.mlis_amd_latent_device.restype = vp
+    l.mlis_amd_latent_device.argtypes = [vp]
+    l.mlis_amd_image_device.restype = vp
+    l.mlis_amd_image_device.argtypes = [vp]
+    l.mlis_amd_info.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
+                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    l.mlis_amd_unet_ctx.restype = vp
+    l.mlis_amd_unet_ctx.argtypes = [vp]
+    l.mlis_amd_decoder_ctx.restype = vp
+    l.mlis_amd_decoder_ctx.argtypes = [vp]
+    l.mlis_amd_last_unet_ms.restype = c_f
+    l.mlis_amd_last_unet_ms.argtypes = [vp]
+    l.mlis_amd_last_nfe.argtypes = [vp]
+    l._proto2_done = True
+    return l
+
+
+class Rng(ctypes.Structure):
+    _fields_ = [("seed", c_u64), ("offset", ctypes.c_uint32)]
+
+
+def randn(seed, offset, n):
+    """rng_philox_randn of the host library (src/ccommon/rng_philox.c restated)."""
+    r = Rng(seed, offset)
+    out = np.empty(n, np.float32)
+    _proto2().rng_philox_randn(ctypes.byref(r), n, fptr(out))
+    return out, r.offset
+
+
+def schedule(model, n_step, sched=1, f_t_ini=1.0, f_t_end=0.0):
+    P = unet_params(model)
+    sig = np.zeros(n_step + 2, np.float32)
+    n = _proto2().dnsamp_schedule(ctypes.byref(P), n_step, sched, f_t_ini, f_t_end, fptr(sig))
+    check1(n, "dnsamp_schedule")
+    return sig[:n + 1]
+
+
+class Decoder:
+    """sdvae_decode / sdtae_decode (src/vae.c:318-411, src/tae.c:117-136), batched, no tiling."""
+
+    def __init__(self, model, lw, lh, n_batch, tae=False, stream=None, seed=1234):
+        l = _proto2()
+        self.ctx = MLCtx(stream)
+        self.tae, self.lw, self.lh, self.n = tae, lw, lh, n_batch
+        self.t_lat = vp()
+        if tae:
+            check1(l.sdtae_decode_init(self.ctx.h, lw, lh, n_batch, ctypes.byref(self.t_lat)), "sdtae_decode_init")
+            check1(l.sdtae_decode_build(self.ctx.h, self.t_lat), "sdtae_decode_build")
+        else:
+            self.P = VaeParams()
+            check1(l.vae_params_get(model.encode(), ctypes.byref(self.P)), "vae_params_get")
+            check1(l.sdvae_decode_init(self.ctx.h, ctypes.byref(self.P), lw, lh, n_batch, ctypes.byref(self.t_lat)), "sdvae_decode_init")
+            check1(l.sdvae_decode_build(self.ctx.h, ctypes.byref(self.P), self.t_lat), "sdvae_decode_build")
+        self.ctx.params_synth(seed)
+
+    def run(self, latent):
+        latent = np.ascontiguousarray(latent, np.float32)
+        img = np.empty((self.n, 3, self.lh * 8, self.lw * 8), np.float32)
+        f = _proto2().sdtae_decode_run if self.tae else _proto2().sdvae_decode_run
+        check1(f(self.ctx.h, self.t_lat, fptr(latent), fptr(img)), "decode_run")
+        return img
+
+
+def clip_text_encode(model, prefix, toks, want_embed=True, want_feat=False, clip_skip=1, norm=True, seed=1234, stream=None):
+    """clip_text_encode (src/clip.c:439-488) for a batch of prompts; toks int32 [n_prompt][n_tok]."""
+    l = _proto2()
+    P = ClipParams()
+    check1(l.clip_params_get(model.encode(), ctypes.byref(P)), "clip_params_get")
+    toks = np.ascontiguousarray(toks, np.int32)
+    n_prompt, n_tok = toks.shape
+    embed = np.empty((n_prompt, P.n_token, P.d_embed), np.float32) if want_embed else None
+    feat = np.empty((n_prompt, P.d_embed), np.float32) if want_feat else None
+    ctx = MLCtx(stream)
+    check1(l.clip_text_encode(ctx.h, ctypes.byref(P), prefix.encode(), n_prompt, n_tok,
+                              toks.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), fptr(embed), fptr(feat), clip_skip, norm, seed),
+           "clip_text_encode")
+    ctx.destroy()
+    return embed, feat
+
+
+class Generator:
+    """mlis_amd_* generation driver (mlis_generate slice, src/mlimgsynth.c:1634-1773) for one GPU."""
+
+    def __init__(self, model, width, height, n_batch, n_step=20, cfg_scale=7.0, s_ancestral=1.0, sched=1, use_tae=False,
+                 use_hipgraph=False, weight_seed=1234, stream=None):
+        l = _proto2()
+        self.cfg = AmdConfig(model.encode(), width, height, n_batch, n_step, cfg_scale, s_ancestral, sched, int(use_tae),
+                             int(use_hipgraph), weight_seed)
+        self.h = l.mlis_amd_create(ctypes.byref(self.cfg), vp(stream))
+        if not self.h:
+            from ._lib import MlsdError, last_error
+            raise MlsdError("mlis_amd_create failed: " + last_error())
+        self.model, self.w, self.h_px, self.B = model, width, height, n_batch
+        self.P = unet_params(model)
+
+    def set_cond(self, cond, label=None, uncond=None, unlabel=None):
+        a = [np.ascontiguousarray(x, np.float32) if x is not None else None for x in (cond, label, uncond, unlabel)]
+        check1(_proto2().mlis_amd_set_cond(self.h, *[fptr(x) for x in a]), "mlis_amd_set_cond")
+
+    def set_cond_device(self, cond, label=None, uncond=None, unlabel=None):
+        check1(_proto2().mlis_amd_set_cond_device(self.h, vp(cond), vp(label), vp(uncond), vp(unlabel)), "mlis_amd_set_cond_device")
+
+    def generate(self, seeds, want_latents=True, want_images=True):
+        seeds = (c_u64 * self.B)(*[int(s) for s in seeds])
+        lat = np.empty((self.B, 4, self.h_px // 8, self.w // 8), np.float32) if want_latents else None
+        img = np.empty((self.B, 3, self.h_px, self.w), np.float32) if want_images else None
+        check1(_proto2().mlis_amd_generate(self.h, seeds, fptr(lat), fptr(img)), "mlis_amd_generate")
+        return lat, img
+
+    def denoise(self, seeds):
+        seeds = (c_u64 * self.B)(*[int(s) for s in seeds])
+        check1(_proto2().mlis_amd_denoise(self.h, seeds), "mlis_amd_denoise")
+
+    def decode(self):
+        check1(_proto2().mlis_amd_decode(self.h), "mlis_amd_decode")
+
+    def latent_ptr(self):
+        return _proto2().mlis_amd_latent_device(self.h)
+
+    def image_ptr(self):
+        return _proto2().mlis_amd_image_device(self.h)
+
+    def info(self):
+        uf, df, ops, mp, mc = ctypes.c_double(), ctypes.c_double(), c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+        _proto2().mlis_amd_info(self.h, ctypes.byref(uf), ctypes.byref(df), ctypes.byref(ops), ctypes.byref(mp), ctypes.byref(mc))
+        return dict(unet_flops=uf.value, decode_flops=df.value, unet_ops=ops.value, mem_params=mp.value, mem_compute=mc.value)
+
+    def last_unet_ms(self):
+        return _proto2().mlis_amd_last_unet_ms(self.h)
+
+    def last_nfe(self):
+        return _proto2().mlis_amd_last_nfe(self.h)
+
+    def unet_ctx(self):
+        c = MLCtx.__new__(MLCtx)
+        c.h = _proto2().mlis_amd_unet_ctx(self.h)
+        c.destroy = lambda: None
+        return c
+
+    def decoder_ctx(self):
+        c = MLCtx.__new__(MLCtx)
+        c.h = _proto2().mlis_amd_decoder_ctx(self.h)
+        c.destroy = lambda: None
+        return c
+
+    def destroy(self):
+        if self.h:
+            _proto2().mlis_amd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

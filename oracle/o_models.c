@@ -48,7 +48,7 @@ void orc_vae_params_get(const char* model, OrcVaeParams* V)
 	V->ch_x=3; V->ch_z=4; V->ch=128; V->n_res=4; V->n_res_blk=2; memcpy(V->ch_mult,m,sizeof(m));
 	V->d_embed=4; V->f_down=8;
 	V->scale_factor = !strcmp(model,"sdxl") ? 0.13025f : 0.18215f;
-	if (!strcmp(model,"tiny")) { V->ch=32; V->n_res_blk=1; }
+	if (!strcmp(model,"tiny") || !strcmp(model,"tinyxl")) { V->ch=64; V->n_res_blk=1; }
 }
 
 void orc_clip_params_get(const char* model, OrcClipParams* C)

@@ -1,0 +1,161 @@
+"""Decoder / text-encoder / full-generation parity of the HIP engine against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("model,lat,n", [("tiny", 8, 2), ("tiny", 16, 1)])
+def test_vae_decode_parity(model, lat, n):
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 0.5
+    dec = engine.Decoder(model, lat, lat, n)
+    got = dec.run(z)
+    V, P = O.vae_params(model), O.Params(1234)
+    ref = np.stack([O.from_ot(O.L().orc_vae_decode(P.h, b"vae", V, O.to_ot(z[i:i + 1])))[0] for i in range(n)])
+    assert got.shape == ref.shape == (n, 3, lat * 8, lat * 8)
+    err = rel(got - 0.5, ref - 0.5)
+    print("vae", model, lat, "rel-L2", err)
+    assert err < 4e-3                       # tolerance as for the UNet (fp16 attention operands, fp32 order)
+    mine = {k for k, _, _ in dec.ctx.param_list()}
+    assert mine == {k for k, _, _ in P.names()}
+
+
+def test_vae_decode_sd_real_config():
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(4)
+    lat = 8
+    z = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 0.5
+    dec = engine.Decoder("sd1", lat, lat, 1)
+    npar = sum(int(np.prod(ne)) for _, _, ne in dec.ctx.param_list())
+    assert abs(npar - 49.5e6) < 0.2e6       # VAE decoder 49.5 M parameters
+    got = dec.run(z)
+    V, P = O.vae_params("sd1"), O.Params(1234)
+    ref = O.from_ot(O.L().orc_vae_decode(P.h, b"vae", V, O.to_ot(z)))
+    err = rel(got - 0.5, ref - 0.5)
+    print("vae sd1 rel-L2", err)
+    assert err < 4e-3
+
+
+def test_tae_decode_parity():
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(5)
+    lat, n = 8, 2
+    z = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 2
+    dec = engine.Decoder("sd1", lat, lat, n, tae=True)
+    got = dec.run(z)
+    P = O.Params(1234)
+    ref = np.stack([O.from_ot(O.L().orc_tae_decode(P.h, b"tae", O.to_ot(z[i:i + 1])))[0] for i in range(n)])
+    err = rel(got, ref)
+    print("tae rel-L2", err)
+    assert err < 2e-3
+    assert {k for k, _, _ in dec.ctx.param_list()} == {k for k, _, _ in P.names()}
+
+
+@pytest.mark.parametrize("model,prefix,skip,norm,feat", [("tiny", "clip", 1, True, False), ("tiny", "clip2", 2, False, True),
+                                                          ("vit_l", "clip", 1, True, False)])
+def test_clip_text_encode_parity(model, prefix, skip, norm, feat):
+    from mlimgsynth_amd import engine
+    K = O.clip_params(model)
+    rng = np.random.default_rng(6)
+    n_tok = 9
+    toks = rng.integers(0, K.n_vocab - 3, (2, n_tok)).astype(np.int32)
+    emb, ft = engine.clip_text_encode(model, prefix, toks, want_embed=True, want_feat=feat, clip_skip=skip, norm=norm)
+    P = O.Params(1234)
+    for p in range(2):
+        full = np.full(K.n_token, K.tok_pad, np.int32)
+        full[0] = K.tok_start
+        full[1:1 + n_tok] = toks[p]
+        full[1 + n_tok] = K.tok_end
+        ptr = full.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        if feat:
+            # feat forces all layers + final norm; embed then is that same tensor (src/clip.c:446)
+            e_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, -1, 1, 0, 0)).reshape(K.n_token, K.d_embed)
+            f_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, -1, 1, 1, n_tok + 1)).reshape(K.d_embed)
+            assert rel(ft[p], f_ref) < 4e-3
+        else:
+            e_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, skip, int(norm), 0, 0)).reshape(K.n_token, K.d_embed)
+        err = rel(emb[p], e_ref)
+        print("clip", model, "prompt", p, "rel-L2", err)
+        assert err < 4e-3
+
+
+def test_clip_prompt_too_long_is_an_error():
+    from mlimgsynth_amd import engine, _lib
+    with pytest.raises(_lib.MlsdError):
+        engine.clip_text_encode("tiny", "clip", np.zeros((1, 76), np.int32))     # max n_token-2 = 75 (src/clip.c:449-450)
+
+
+@pytest.mark.parametrize("model,steps", [("tiny", 20), ("tinyxl", 6)])
+def test_generate_latent_parity_vs_oracle(model, steps):
+    """Whole denoising loop (schedule, Philox noise, CFG, Euler-a) on the tiny configs: HIP engine vs the
+    oracle's restatement of mlis_generate.  The ancestral loop is chaotic, so the stated tolerance on the FINAL
+    latent is loose (rel-L2 <= 5e-2) while every single evaluation is held to 4e-3 by test_unet_gpu."""
+    from mlimgsynth_amd import engine
+    lat, B = 8, 2
+    U = O.unet_params(model)
+    rng = np.random.default_rng(8)
+    cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    uncond = np.zeros_like(cond) if U.uncond_empty_zero else rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    label = rng.standard_normal(U.ch_adm_in).astype(np.float32) if U.ch_adm_in else None
+    unlabel = rng.standard_normal(U.ch_adm_in).astype(np.float32) if U.ch_adm_in else None
+    g = engine.Generator(model, lat * 8, lat * 8, B, n_step=steps, cfg_scale=7.0, s_ancestral=1.0)
+    g.set_cond(cond, label, uncond, unlabel)
+    seeds = [42, 43]
+    lat_got, img = g.generate(seeds)
+    assert np.isfinite(lat_got).all() and np.isfinite(img).all()
+    assert g.last_nfe() == 2 * steps
+    P = O.Params(1234)
+    for b in range(B):
+        out = np.empty((4, lat, lat), np.float32)
+        tu = ctypes.c_double()
+        nfe = O.L().orc_generate_latent(P.h, b"unet", U, lat, lat, O.to_ot(cond[None, None]),
+                                        O.to_ot(label[None, None, None]) if label is not None else None,
+                                        O.to_ot(uncond[None, None]), O.to_ot(unlabel[None, None, None]) if unlabel is not None else None,
+                                        7.0, steps, 1.0, seeds[b], 0, O.fptr(out), ctypes.byref(tu))
+        assert nfe == 2 * steps
+        err = rel(lat_got[b], out)
+        print(model, "image", b, "final latent rel-L2", err)
+        assert err < 5e-2
+    # the two images used different seeds: different latents
+    assert rel(lat_got[0], lat_got[1]) > 0.1
+    # determinism: a second run with the same seeds is bit-identical
+    lat2, _ = g.generate(seeds, want_images=False)
+    assert np.array_equal(lat2, lat_got)
+
+
+def test_generate_with_hipgraph_matches_plain():
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(9)
+    U = O.unet_params("tiny")
+    cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    unc = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    outs = []
+    for hg in (False, True):
+        g = engine.Generator("tiny", 64, 64, 1, n_step=5, use_hipgraph=hg)
+        g.set_cond(cond, None, unc, None)
+        outs.append(g.generate([7])[0])
+        g.destroy()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_host_rng_and_schedule_match_oracle():
+    from mlimgsynth_amd import engine
+    for seed, off, n in [(0, 0, 12), (42, 3, 5000), (2**63 + 5, 2**32 - 1, 100)]:
+        got, o2 = engine.randn(seed, off, n)
+        assert np.array_equal(got.view(np.uint32), O.randn(seed, off, n).view(np.uint32))
+        assert o2 == (off + 1) % 2**32
+    sig = engine.schedule("sd1", 20)
+    ref = np.empty(64, np.float32)
+    O.L().orc_schedule(20, 1, 1.0, 0.0, O.fptr(ref))
+    assert np.array_equal(sig, ref[:21])
