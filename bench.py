@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the SD denoising hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input on every GPU:
+  rank 0: CLIP text encode (resident towers) -> [N>1: RCCL broadcast of cond/label over xGMI]
+  every rank: 20-step Euler-ancestral denoise of `batch_per_gpu` images (cfg 7 => 40 UNet evaluations
+  per image, cond+uncond batched) + latent decode (KL-VAE) -> [N>1: gather of the final latents to rank 0].
+Inputs are resident in HBM when the timed region starts (weights, token ids); images are independent
+units, sharded over ranks with no per-step collective (weak scaling: batch_per_gpu fixed).
+
+Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+WORKLOADS = {
+    # name: (model, width, height, default batch per GPU)
+    "sdxl": ("sdxl", 1024, 1024, 4),      # BASELINE.json configs[2] (and [3] at 8 GPUs)
+    "sd15": ("sd1", 512, 512, 1),         # BASELINE.json configs[1]
+    "tiny": ("tiny", 64, 64, 2),          # plumbing check only
+    "tinyxl": ("tinyxl", 64, 64, 2),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="sdxl", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-per-gpu", type=int, default=0)
+    ap.add_argument("--denoise-steps", type=int, default=20)
+    ap.add_argument("--cfg", type=float, default=7.0)
+    ap.add_argument("--tae", action="store_true", help="decode with TAESD instead of the KL-VAE")
+    ap.add_argument("--hipgraph", type=int, default=-1, help="replay each UNet evaluation as a hipGraph (default: auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-nfe", type=int, default=1, help="UNet evaluations timed for the CPU baseline sample")
+    ap.add_argument("--kernel-table", default="", help="write the per-kernel time table of one UNet evaluation to this file")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from mlimgsynth_amd import _lib, engine, text
+    L = _lib.lib()
+
+    model, width, height, bdef = WORKLOADS[a.workload]
+    B = a.batch_per_gpu or bdef
+    hipgraph = a.hipgraph if a.hipgraph >= 0 else (1 if a.workload == "sd15" else 0)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- setup (untimed): engine, weights (synthetic, seed 1234), resident text towers on rank 0
+    t_setup = time.time()
+    g = engine.Generator(model, width, height, B, n_step=a.denoise_steps, cfg_scale=a.cfg, s_ancestral=1.0,
+                         use_tae=a.tae, use_hipgraph=bool(hipgraph), weight_seed=1234)
+    P = g.P
+    n_ctx, adm = P.n_ctx, P.ch_adm_in
+    tc = text.TextConditioner(model, width, height, seed=1234) if rank == 0 else None
+    prompt = np.random.default_rng(7).integers(0, 49405 if model in ("sd1", "sdxl") else 900, 8).astype(np.int32)
+    # conditioning buffers on the device (broadcast targets): cond, uncond [77][n_ctx], label, unlabel [adm]
+    d_cond = torch.zeros(2, 77, n_ctx, dtype=torch.float32, device=dev)
+    d_label = torch.zeros(2, max(adm, 1), dtype=torch.float32, device=dev)
+    lat_shape = (B, 4, height // 8, width // 8)
+    d_lat = torch.empty(lat_shape, dtype=torch.float32, device=dev)
+    gathered = [torch.empty(lat_shape, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    info = g.info()
+    t_setup = time.time() - t_setup
+
+    def one_step(idx):
+        if rank == 0:
+            cond, label, ncond, nlabel = tc.encode_pair(prompt, ())
+            d_cond.copy_(torch.from_numpy(np.stack([cond, ncond])), non_blocking=False)
+            if adm:
+                d_label.copy_(torch.from_numpy(np.stack([label, nlabel])), non_blocking=False)
+        if world > 1:
+            dist.broadcast(d_cond, 0)                  # RCCL over xGMI: ~1.3 MB once per batch
+            if adm:
+                dist.broadcast(d_label, 0)
+            torch.cuda.synchronize()
+        cp, lp = d_cond.data_ptr(), d_label.data_ptr()
+        g.set_cond_device(cp, lp if adm else None, cp + 77 * n_ctx * 4, (lp + max(adm, 1) * 4) if adm else None)
+        base = 42 + (idx * world + rank) * B            # independent Philox stream per image: seed 42 + image index
+        g.generate([base + i for i in range(B)], want_latents=False, want_images=False)   # syncs its stream
+        if world > 1:
+            _lib.check(L.mlsd_memcpy(_lib.vp(d_lat.data_ptr()), _lib.vp(g.latent_ptr()), ctypes.c_size_t(d_lat.numel() * 4), 2, None))
+            _lib.check(L.mlsd_device_sync())
+            dist.gather(d_lat, gathered, dst=0)        # 256 KiB per image
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(-1 - i)
+    fence()
+    t0 = time.perf_counter()
+    unet_ms = 0.0
+    for i in range(a.steps):
+        one_step(i)
+        unet_ms += g.last_unet_ms()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    images = a.steps * B * world
+    value = images / el
+    nfe_per_img = 2 * a.denoise_steps if a.cfg > 1 else a.denoise_steps
+    flop_per_img = (info["unet_flops"] / B) * a.denoise_steps + info["decode_flops"] / B     # unet_flops is per batched evaluation
+    out = {
+        "metric": f"images/sec ({a.denoise_steps}-step Euler-a, cfg {a.cfg:g}) {'SDXL 1024x1024' if a.workload == 'sdxl' else a.workload}",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(el / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{a.workload}-{width}x{height}-euler_a-{a.denoise_steps}-cfg{a.cfg:g}-b{B}-{'tae' if a.tae else 'vae'}",
+                   "batch_per_gpu": B, "global_batch": B * world, "unet_evals_per_image": nfe_per_img,
+                   "tflop_per_image": round(flop_per_img / 1e12, 3), "hipgraph": bool(hipgraph),
+                   "parallelism": f"image-sharded x{world}, RCCL bcast cond + gather latents" if world > 1 else "single GPU",
+                   "weights": "synthetic seed 1234", "setup_s": round(t_setup, 1)},
+        "job_tflops": round(value * flop_per_img / 1e12, 1),
+        "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / (world * PEAK_MFMA_F16_TFLOPS), 4),
+        "unet_eval_ms": round(unet_ms / (a.steps * a.denoise_steps), 3),
+    }
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the engine's stream, one UNet evaluation
+    uc = g.unet_ctx()
+    ops = uc.op_list()
+    ms = uc.profile_ops()
+    agg = {}
+    for (lab, fl), t in zip(ops, ms):
+        e = agg.setdefault(lab, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += float(t); e[2] += fl
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    lab, (cnt, tms, fl) = dom
+    achieved = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+    out["roofline"] = {"bound": "mfma", "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
+                       "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": None,
+                       "share_of_eval_time": round(tms / float(ms.sum()), 3)}
+    if a.kernel_table:
+        with open(a.kernel_table, "w") as f:
+            f.write(f"# one UNet evaluation, {a.workload} batch {B} (N={2 * B if a.cfg > 1 else B}); per-launch HIP events\n")
+            f.write(f"# {'kernel':44s} {'launches':>8s} {'total_ms':>10s} {'TFLOP':>9s} {'TFLOP/s':>9s}\n")
+            for k, (c, t, fl_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{k:46s} {c:8d} {t:10.3f} {fl_ / 1e12:9.3f} {fl_ / max(t, 1e-9) / 1e9:9.1f}\n")
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded sample
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            threads = a.cpu_threads or min(os.cpu_count() or 1, 64)
+            O.L().orc_set_threads(threads)
+            U = O.unet_params(model)
+            OP = O.Params(1234)
+            lw, lh = width // 8, height // 8
+            rng = np.random.default_rng(7)
+            cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+            lab_ = rng.standard_normal(max(U.ch_adm_in, 1)).astype(np.float32)
+            ot = lambda x: O.to_ot(x)
+            lat = np.empty((4, lh, lw), np.float32)
+            tu = ctypes.c_double()
+            # synthesise the oracle's weights up front (same (seed, name, shape) rule as the engine) so that the
+            # timed sample contains UNet arithmetic only
+            for key, typ, ne in uc.param_list():
+                OP.get(key, typ == 1, [d for d in ne[::-1]])
+            nfe = O.L().orc_generate_latent(OP.h, b"unet", U, lw, lh, ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
+                                            ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
+                                            a.cfg, a.denoise_steps, 1.0, 42, a.cpu_nfe, O.fptr(lat), ctypes.byref(tu))
+            s_per_nfe = tu.value / max(nfe, 1)
+            unet_flops_1 = info["unet_flops"] / (2 * B if a.cfg > 1 else B)
+            s_per_img = s_per_nfe * (flop_per_img / unet_flops_1)      # decode priced at the UNet's measured FLOP rate
+            out["cpu_baseline"] = {"value": round(1.0 / s_per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
+                                   "s_per_unet_eval": round(s_per_nfe, 3),
+                                   "sample": f"{nfe} of {nfe_per_img} batch-1 UNet evaluations of one {a.workload} image "
+                                             f"(oracle/, fp32 CPU restatement of the reference path, OpenMP {threads} threads), "
+                                             f"extrapolated to a whole image by algorithmic FLOPs"}
+        except Exception as e:  # the baseline is a report, never the product path
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,24 @@ int clip_params_get(const char* model, ClipParams* out);   /* "vit_l" | "vit_h" 
 int clip_text_encode(MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt, unsigned n_tok,
 	const int32_t* toks, float* embed, float* feat, int clip_skip, bool norm, uint64_t synth_seed);
 
+/* resident variant: graph + weights stay on the device between prompts (the reference rebuilds the graph
+ * and re-uploads the weights for every clip_text_encode call, src/clip.c:458-486) */
+typedef struct {
+	MLCtx* C;
+	ClipParams P;
+	MLTensor *t_tokens, *t_embed;
+	unsigned n_prompt;
+	int want_feat;
+	char prefix[16];
+	float* text_proj_host;
+} ClipEncoder;
+int clip_encoder_init(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
+	int clip_skip, bool norm, bool want_feat);         /* then load weights: mlctx_params_synth / mlctx_param_set */
+int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks, float* embed, float* feat);
+void clip_encoder_free(ClipEncoder* E);
+/* SDXL vector conditioning (src/mlimgsynth.c:1542-1557): [pooled | emb(h,w) | emb(0,0) | emb(h,w)], 256 dims each */
+int sdxl_label_build(const float* feat, int n_feat, int width, int height, float* label, int n_label);
+
 /* ---------------------------------------------------------------- RNG / schedule / sampler */
 typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
 void rng_philox_randn(RngPhilox* S, unsigned n, float* out);

@@ -1,6 +1,7 @@
 /* CLIP text encoder on the MI355X plan builder — re-creation of the graph part of the
  * reference's src/clip.c:23-57,319-488 (the BPE tokenizer, src/clip.c:59-315, is host-side
- * integer code outside this file).  Batched over prompts.
+ * integer code outside this file).  Batched over prompts; the graph and its weights can be kept
+ * resident (ClipEncoder) instead of being rebuilt per prompt as in clip_text_encode().
  */
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
@@ -103,13 +104,34 @@ static int param_to_host(MLCtx* C, const char* key, float* out, size_t n)
 	return mlctx_fail(C, "unknown parameter '%s'", key);
 }
 
-/* clip_text_encode, src/clip.c:439-488, for n_prompt prompts of n_tok tokens each */
-MLB_API int clip_text_encode(MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt, unsigned n_tok,
-	const int32_t* toks, float* embed, float* feat, int clip_skip, bool norm, uint64_t synth_seed)
+/* ------------------------------------------------------------------ resident encoder */
+MLB_API int clip_encoder_init(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
+	int clip_skip, bool norm, bool want_feat)
 {
-	if (feat) { clip_skip = -1; norm = true; }               /* :446 */
+	memset(E, 0, sizeof(*E));
+	if (want_feat) { clip_skip = -1; norm = true; }          /* src/clip.c:446 */
+	E->C = C; E->P = *P; E->n_prompt = n_prompt; E->want_feat = want_feat;
+	snprintf(E->prefix, sizeof(E->prefix), "%s", tprefix);
+	mlctx_begin(C, "CLIP text encode");
+	mlctx_set_tprefix(C, tprefix);
+	E->t_tokens = mlctx_input_new_seq(C, "tokens", MLT_I32, P->n_token, n_prompt, 1);
+	E->t_embed = mlb_clip_text(C, E->t_tokens, P, clip_skip, norm);
+	if (!E->t_embed) return -1;
+	if (want_feat) mlctx_param_new(C, "text_proj", MLT_F32, P->d_embed, P->d_embed, 1, 1, 0, 0, 0);   /* mlb_clip_text_proj :418-427 */
+	mlctx_tensor_add(C, "text", E->t_embed);
+	return mlctx_prep(C);
+}
+
+MLB_API void clip_encoder_free(ClipEncoder* E) { if (E) { free(E->text_proj_host); E->text_proj_host = NULL; } }
+
+MLB_API int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks, float* embed, float* feat)
+{
+	MLCtx *C = E->C;
+	const ClipParams *P = &E->P;
 	if (n_tok + 2 > (unsigned)P->n_token) return mlsd_set_error(-1, "prompt too long (max: %d)", P->n_token - 2);   /* :449-450 */
+	if (feat && !E->want_feat) return mlsd_set_error(-1, "clip_encoder_run: encoder built without the pooled feature");
 	const int NT = P->n_token, d = P->d_embed;
+	const unsigned n_prompt = E->n_prompt;
 	int32_t *tokens = (int32_t*)malloc(sizeof(int32_t) * NT * n_prompt);
 	for (unsigned p=0; p<n_prompt; ++p) {                    /* :451-455 */
 		int32_t *t = tokens + (size_t)p*NT;
@@ -119,35 +141,69 @@ MLB_API int clip_text_encode(MLCtx* C, const ClipParams* P, const char* tprefix,
 		for (int i=n_tok+2; i<NT; ++i) t[i] = P->tok_pad;
 	}
 	int R = 1;
-	float *tmp = NULL, *tp = NULL;
-	mlctx_begin(C, "CLIP text encode");
-	mlctx_set_tprefix(C, tprefix);
-	MLTensor *input = mlctx_input_new_seq(C, "tokens", MLT_I32, NT, n_prompt, 1);
-	MLTensor *t_embed = mlb_clip_text(C, input, P, clip_skip, norm);
-	if (!t_embed) { R = -1; goto end; }
-	if (feat) mlctx_param_new(C, "text_proj", MLT_F32, d, d, 1, 1, 0, 0, 0);   /* mlb_clip_text_proj :418-427 */
-	mlctx_tensor_add(C, "text", t_embed);
-	if (mlctx_prep(C) < 0) { R = -1; goto end; }
-	if (mlctx_params_synth(C, synth_seed) < 0) { R = -1; goto end; }
-	if (mlctx_input_set(C, input, tokens, sizeof(int32_t)*NT*n_prompt) < 0) { R = -1; goto end; }
-	if (mlctx_compute(C) < 0) { R = -1; goto end; }
+	float *tmp = NULL;
 	const size_t ne = (size_t)n_prompt * NT * d;
+	if (mlctx_input_set(C, E->t_tokens, tokens, sizeof(int32_t)*NT*n_prompt) < 0) { R = -1; goto end; }
+	if (mlctx_compute(C) < 0) { R = -1; goto end; }
 	tmp = (float*)malloc(ne * 4);
-	if (mlctx_output_get(C, t_embed, tmp, ne*4) < 0) { R = -1; goto end; }
+	if (mlctx_output_get(C, E->t_embed, tmp, ne*4) < 0) { R = -1; goto end; }
 	if (embed) memcpy(embed, tmp, ne*4);
 	if (feat) {
-		/* feat = text_proj^T . x[EOS]  (:428-434): fp32 weights, fp32 activations in the reference; done on the
+		/* feat = text_proj^T . x[EOS]  (:428-434): F32 weights and activations in the reference; done on the
 		 * host in double (d*d MACs per prompt) */
-		char key[96]; snprintf(key, sizeof(key), "%s.text.text_proj", tprefix);
-		tp = (float*)malloc((size_t)d*d*4);
-		if (param_to_host(C, key, tp, (size_t)d*d) < 0) { R = -1; goto end; }
+		if (!E->text_proj_host) {
+			char key[96]; snprintf(key, sizeof(key), "%s.text.text_proj", E->prefix);
+			E->text_proj_host = (float*)malloc((size_t)d*d*4);
+			if (param_to_host(C, key, E->text_proj_host, (size_t)d*d) < 0) { free(E->text_proj_host); E->text_proj_host = NULL; R = -1; goto end; }
+		}
+		const float *tp = E->text_proj_host;
 		for (unsigned p=0; p<n_prompt; ++p) {
 			const float *xe = tmp + ((size_t)p*NT + n_tok + 1) * d;
 			for (int j=0;j<d;++j) { double s=0; for (int i=0;i<d;++i) s += (double)tp[j + (size_t)d*i] * xe[i]; feat[(size_t)p*d + j] = (float)s; }
 		}
 	}
 end:
-	free(tokens); free(tmp); free(tp);
+	free(tokens); free(tmp);
+	return R;
+}
+
+/* clip_text_encode, src/clip.c:439-488 (one-shot: build, load, run, free), for n_prompt prompts */
+MLB_API int clip_text_encode(MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt, unsigned n_tok,
+	const int32_t* toks, float* embed, float* feat, int clip_skip, bool norm, uint64_t synth_seed)
+{
+	if (n_tok + 2 > (unsigned)P->n_token) return mlsd_set_error(-1, "prompt too long (max: %d)", P->n_token - 2);
+	ClipEncoder E;
+	int R = clip_encoder_init(&E, C, P, tprefix, n_prompt, clip_skip, norm, feat != NULL);
+	if (R > 0) R = mlctx_params_synth(C, synth_seed);
+	if (R > 0) R = clip_encoder_run(&E, n_tok, toks, embed, feat);
+	clip_encoder_free(&E);
 	mlctx_end(C);
 	return R;
+}
+
+/* ------------------------------------------------------------------ SDXL label assembly (src/mlimgsynth.c:1485-1499,1542-1557) */
+static size_t sd_timestep_embedding(unsigned nsteps, const float* steps, unsigned dim, float max_period, float* out)
+{
+	unsigned half = dim/2;
+	for (unsigned i=0; i<half; ++i) {
+		float freq = exp(-log(max_period)*i/half);
+		for (unsigned s=0; s<nsteps; ++s) {
+			out[s*dim+i     ] = cos(steps[s] * freq);
+			out[s*dim+i+half] = sin(steps[s] * freq);
+		}
+	}
+	return nsteps * dim;
+}
+
+/* label = [pooled feat (n_feat) | emb(h,w) | emb(0,0) | emb(h,w)], 256 dims per scalar */
+MLB_API int sdxl_label_build(const float* feat, int n_feat, int width, int height, float* label, int n_label)
+{
+	if (n_feat + 6*256 != n_label) return mlsd_set_error(-1, "sdxl_label_build: %d + 1536 != %d", n_feat, n_label);
+	memcpy(label, feat, (size_t)n_feat*4);
+	float *ld = label + n_feat;
+	const float hw[2] = {(float)height, (float)width}, zz[2] = {0, 0};
+	ld += sd_timestep_embedding(2, hw, 256, 10000, ld);   /* original size */
+	ld += sd_timestep_embedding(2, zz, 256, 10000, ld);   /* crop top,left */
+	ld += sd_timestep_embedding(2, hw, 256, 10000, ld);   /* target size */
+	return 1;
 }

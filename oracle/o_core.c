@@ -133,16 +133,20 @@ void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,
 				int64_t j = jp*NR, w = nc-j < NR ? nc-j : NR;
 				pack_B(kc, w, B + (jc+j)*ldb + pc, ldb, Bp + jp*kc*NR);
 			}
-			int64_t nblk = (M+MC-1)/MC;
+			/* 2-D tile parallelism (row blocks x column chunks): convs have few output channels (M) but many
+			 * pixels (N), linears the opposite; each tile packs its own A block (<1 % overhead) */
+			const int64_t nblk = (M+MC-1)/MC, JB = 256, njb = (nc+JB-1)/JB;
 			#pragma omp parallel num_threads(nth)
 			{
 				float *Ap = NULL;
 				if (posix_memalign((void**)&Ap, 64, (size_t)KC*MC*sizeof(float))) Ap = NULL;
-				#pragma omp for schedule(dynamic,1)
-				for (int64_t ib=0; ib<nblk; ++ib) {
+				#pragma omp for schedule(dynamic,1) collapse(2)
+				for (int64_t ib=0; ib<nblk; ++ib)
+				for (int64_t jb=0; jb<njb; ++jb) {
 					int64_t ic = ib*MC, mc = M-ic < MC ? M-ic : MC;
+					int64_t j0 = jb*JB, j1 = j0+JB < nc ? j0+JB : nc;
 					pack_A(kc, mc, A + ic*lda + pc, lda, Ap);
-					for (int64_t jr=0; jr<nc; jr+=NR) {
+					for (int64_t jr=j0; jr<j1; jr+=NR) {
 						int nr = (int)(nc-jr < NR ? nc-jr : NR);
 						for (int64_t ir=0; ir<mc; ir+=MR) {
 							int mr = (int)(mc-ir < MR ? mc-ir : MR);
