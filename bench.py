@@ -71,6 +71,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     from mlimgsynth_amd import _lib, engine, text
+    from mlimgsynth_amd import dist as mdist
     L = _lib.lib()
 
     model, width, height, bdef = WORKLOADS[a.workload]
@@ -91,7 +92,6 @@ def main():
     d_label = torch.zeros(2, max(adm, 1), dtype=torch.float32, device=dev)
     lat_shape = (B, 4, height // 8, width // 8)
     d_lat = torch.empty(lat_shape, dtype=torch.float32, device=dev)
-    gathered = [torch.empty(lat_shape, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     info = g.info()
     t_setup = time.time() - t_setup
 
@@ -102,18 +102,16 @@ def main():
             if adm:
                 d_label.copy_(torch.from_numpy(np.stack([label, nlabel])), non_blocking=False)
         if world > 1:
-            dist.broadcast(d_cond, 0)                  # RCCL over xGMI: ~1.3 MB once per batch
-            if adm:
-                dist.broadcast(d_label, 0)
+            mdist.broadcast_conditioning(d_cond, d_label if adm else None, 0)   # RCCL over xGMI: ~1.3 MB once per batch
             torch.cuda.synchronize()
         cp, lp = d_cond.data_ptr(), d_label.data_ptr()
         g.set_cond_device(cp, lp if adm else None, cp + 77 * n_ctx * 4, (lp + max(adm, 1) * 4) if adm else None)
-        base = 42 + (idx * world + rank) * B            # independent Philox stream per image: seed 42 + image index
-        g.generate([base + i for i in range(B)], want_latents=False, want_images=False)   # syncs its stream
+        # independent Philox stream per image (seed 42 + global image index): results do not depend on the GPU count
+        g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=False)   # syncs its stream
         if world > 1:
             _lib.check(L.mlsd_memcpy(_lib.vp(d_lat.data_ptr()), _lib.vp(g.latent_ptr()), ctypes.c_size_t(d_lat.numel() * 4), 2, None))
             _lib.check(L.mlsd_device_sync())
-            dist.gather(d_lat, gathered, dst=0)        # 256 KiB per image
+            mdist.gather_latents(d_lat, 0)             # 256 KiB per image
 
     def fence():
         torch.cuda.synchronize()
@@ -131,10 +129,7 @@ def main():
         unet_ms += g.last_unet_ms()
     fence()
     el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = mdist.max_over_ranks(el, dev)
 
     if rank != 0:
         if world > 1:

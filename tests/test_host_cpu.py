@@ -1,0 +1,162 @@
+"""CPU-only checks of the product's host side (no compute calls without a GPU):
+  * the C-ABI library loads and exports every symbol that include/*.h declares;
+  * the plan builder, run in "dry" mode (device memory served from host memory, kernel launches
+    refused), produces the reference's parameter names, parameter counts and the algorithmic FLOP
+    totals of SURVEY.md App. C for the real SD1.5 / SDXL / VAE / TAE / CLIP configurations;
+  * host arithmetic that needs no GPU (Philox, schedule, fp16 conversion) matches the oracle / KATs;
+  * compute without a GPU fails loudly (no CPU fallback in the product path).
+"""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def dry():
+    from mlimgsynth_amd import _lib, engine
+    L = _lib.lib()
+    L.mlsd_runtime_dry(1)
+    yield engine
+    L.mlsd_runtime_dry(0)
+
+
+def declared_symbols():
+    syms = set()
+    for h in ("mlsd_kernels.h", "mlblock_amd.h", "mlimgsynth_amd.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"static inline[^{]*\{[^}]*\}", "", src)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src):
+            name = m.group(1)
+            if name not in ("defined", "sizeof"):
+                syms.add(name)
+    return syms
+
+
+def test_cabi_exports_every_declared_symbol():
+    from mlimgsynth_amd import _lib
+    L = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) > 90
+    missing = [s for s in sorted(syms) if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_compute_without_gpu_fails_loudly(dry):
+    from mlimgsynth_amd import _lib
+    un = dry.Unet("tiny", 8, 8, 1, synth=False)
+    with pytest.raises(_lib.MlsdError):
+        un.ctx.params_synth(1234)            # would launch a kernel: refused, no silent CPU path
+    with pytest.raises(_lib.MlsdError):
+        un.ctx.compute()
+
+
+@pytest.mark.parametrize("model,lat,flops_T,params_M", [("sd1", 64, 0.803, 859.5), ("sdxl", 128, 6.761, 2567.5)])
+def test_unet_plan_matches_survey_counts(dry, model, lat, flops_T, params_M):
+    un = dry.Unet(model, lat, lat, 1, synth=False)
+    info = un.ctx.info()
+    npar = sum(int(np.prod(ne)) for _, _, ne in un.ctx.param_list())
+    assert abs(info.flops / 1e12 - flops_T) < 0.002            # SURVEY.md §8d / App. C (2*MAC of conv, linear, QK^T, PV)
+    assert abs(npar / 1e6 - params_M) < 0.2
+    keys = {k for k, _, _ in un.ctx.param_list()}
+    for k in ["unet.in.conv.weight", "unet.time_embed.0.weight", "unet.in.1.0.emb_proj.weight", "unet.mid.1.transf.0.attn2.k_proj.weight",
+              "unet.out.0.0.skip_conv.weight", "unet.out.norm.weight", "unet.out.conv.bias"]:
+        assert k in keys, k
+    if model == "sdxl":
+        assert "unet.label_embed.0.weight" in keys and "unet.in.7.1.transf.9.ff.net.0.proj.weight" in keys
+        assert "unet.in.1.1.norm.weight" not in keys             # SDXL has no attention at the first level
+
+
+def test_unet_param_names_equal_oracle_names(dry):
+    un = dry.Unet("tinyxl", 8, 8, 2, synth=False)
+    U, P = O.unet_params("tinyxl"), O.Params(1)
+    x = np.zeros((1, 4, 8, 8), np.float32)
+    ctx = np.zeros((1, 1, 77, U.n_ctx), np.float32)
+    lab = np.zeros((1, 1, 1, U.ch_adm_in), np.float32)
+    O.from_ot(O.L().orc_unet_graph(P.h, b"unet", U, O.to_ot(x), 1.0, O.to_ot(ctx), O.to_ot(lab)))
+    mine = {k: int(np.prod(ne)) for k, _, ne in un.ctx.param_list()}
+    theirs = {k: int(np.prod(ne)) for k, _, ne in P.names()}
+    assert mine == theirs
+
+
+def test_decoder_and_clip_plans_match_survey_counts(dry):
+    dec = dry.Decoder.__new__(dry.Decoder)            # build without loading weights (needs a GPU)
+    l = dry._proto2()
+    dec.ctx, dec.t_lat = dry.MLCtx(), dry.vp()
+    vp_ = dry.VaeParams()
+    l.vae_params_get(b"sdxl", ctypes.byref(vp_))
+    assert abs(vp_.scale_factor - 0.13025) < 1e-7                  # src/vae.c:43
+    assert l.sdvae_decode_init(dec.ctx.h, ctypes.byref(vp_), 128, 128, 1, ctypes.byref(dec.t_lat)) == 1
+    assert l.sdvae_decode_build(dec.ctx.h, ctypes.byref(vp_), dec.t_lat) == 1
+    info = dec.ctx.info()
+    assert abs(info.flops / 1e12 - 10.470) < 0.01                  # VAE decode 1024^2: 10.470 TFLOP
+    assert abs(sum(int(np.prod(ne)) for _, _, ne in dec.ctx.param_list()) / 1e6 - 49.5) < 0.1
+    tae = dry.MLCtx()
+    tl = dry.vp()
+    assert l.sdtae_decode_init(tae.h, 128, 128, 1, ctypes.byref(tl)) == 1 and l.sdtae_decode_build(tae.h, tl) == 1
+    assert abs(tae.info().flops / 1e12 - 0.565) < 0.002            # TAE decode 1024^2: 0.565 TFLOP
+    keys = {k for k, _, _ in tae.param_list()}
+    assert {"tae.decoder.layers.0.weight", "tae.decoder.layers.2.conv.0.weight", "tae.decoder.layers.6.weight",
+            "tae.decoder.layers.17.conv.4.bias", "tae.decoder.layers.18.weight"} <= keys
+    assert "tae.decoder.layers.6.bias" not in keys                 # the post-upsample convs have no bias (src/tae.c:83-84)
+    from mlimgsynth_amd import text
+    enc = text.ClipEncoder.__new__(text.ClipEncoder)
+    enc.P, enc.ctx, enc.E = dry.ClipParams(), dry.MLCtx(), text.ClipEncoderS()
+    text._l().clip_params_get(b"vit_l", ctypes.byref(enc.P))
+    assert text._l().clip_encoder_init(ctypes.byref(enc.E), enc.ctx.h, ctypes.byref(enc.P), b"clip", 1, 1, True, False) == 1
+    npar = sum(int(np.prod(ne)) for _, _, ne in enc.ctx.param_list())
+    assert abs(npar / 1e6 - 123.0) < 0.2                           # CLIP-L text tower 123.0 M parameters
+    assert abs(enc.ctx.info().flops / 1e12 - 0.013) < 0.001
+    keys = {k for k, _, _ in enc.ctx.param_list()}
+    assert {"clip.text.embed.token.weight", "clip.text.embed.position.weight", "clip.text.encoder.layers.11.mlp.fc2.bias",
+            "clip.text.encoder.layers.0.attn.q_proj.bias", "clip.text.ln_final.weight"} <= keys
+    enc.ctx = None
+
+
+def test_host_philox_schedule_and_f16(dry):
+    from mlimgsynth_amd import engine
+    gold = json.load(open(os.path.join(GOLD, "reference_kats.json")))
+    got, off = engine.randn(0, 0, 12)
+    assert [f"{v:.8f}" for v in got] == gold["rng_seed0_offset0_n12"]          # src/test_rng.c:11-24
+    got, _ = engine.randn(42, 0, 8)
+    assert [f"{v:.8f}" for v in got] == gold["rng_seed42_offset0_n8"]
+    assert off == 1
+    for seed, o, n in [(42, 19, 4096), (2**64 - 1, 7, 33)]:
+        assert np.array_equal(engine.randn(seed, o, n)[0].view(np.uint32), O.randn(seed, o, n).view(np.uint32))
+    sig = engine.schedule("sd1", 20)
+    assert [f"{v:.7g}" for v in sig] == [f"{v:.7g}" for v in gold["sigmas_20_uniform"]]
+    sk = engine.schedule("sd1", 10, sched=2)                                     # Karras: vs the oracle's restatement
+    ref = np.empty(32, np.float32)
+    O.L().orc_schedule(10, 2, 1.0, 0.0, O.fptr(ref))
+    assert np.array_equal(sk, ref[:11])
+    # portable fp16 conversion of the weight loader == numpy RNE, incl. subnormals, ties, overflow
+    l = engine.L()
+    vals = np.concatenate([np.random.default_rng(0).standard_normal(2000).astype(np.float32) * s for s in (1e-7, 1e-4, 1, 300, 7e4)])
+    vals = np.concatenate([vals, np.array([0, -0.0, 65504, 65519.99, 65520, 2**-24, 2**-25, 1.5 * 2**-24, 1 + 2**-11, 1 + 3 * 2**-11], np.float32)])
+    with np.errstate(over="ignore"):
+        exp = vals.astype(np.float16).view(np.uint16)
+    got = np.array([l.mlb_f32_to_f16_bits(float(v)) for v in vals], np.uint16)
+    assert np.array_equal(got, exp)
+    back = np.array([l.mlb_f16_bits_to_f32(int(b)) for b in exp[:4000]], np.float32)
+    assert np.array_equal(back, exp[:4000].view(np.float16).astype(np.float32))
+
+
+def test_sdxl_label_layout(dry):
+    from mlimgsynth_amd import text
+    feat = np.arange(1280, dtype=np.float32)
+    lab = text.sdxl_label(feat, 1024, 768)
+    assert lab.shape == (2816,) and np.array_equal(lab[:1280], feat)
+    # emb(h), emb(w) | emb(0), emb(0) | emb(h), emb(w); each [cos(256/2) | sin] (src/mlimgsynth.c:1485-1499,1548-1557)
+    freq = np.exp(-np.log(10000.0) * np.arange(128) / 128)
+    e = lambda v: np.concatenate([np.cos(v * freq), np.sin(v * freq)])
+    exp = np.concatenate([e(768), e(1024), e(0), e(0), e(768), e(1024)])
+    assert np.abs(lab[1280:] - exp).max() < 5e-4
