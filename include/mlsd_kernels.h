@@ -99,6 +99,12 @@ typedef struct mlsd_gemm_args {
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
+/* staging mode of the A/B tiles: 0 = direct global->LDS (global_load_lds_dwordx4, default), 1 = through registers
+ * (kept for in-process A/B timing) */
+void mlsd_gemm_set_mode(int mode);
+/* diagnostics: force a tile variant (-1 = automatic choice) / the scalar epilogue (1) instead of the wide one (0) */
+void mlsd_gemm_force_variant(int v);
+void mlsd_gemm_set_epilogue(int e);
 
 /* ---------------------------------------------------------------- fused attention
  * Replaces ggml_nn_attention (src/ggml_extend.c:200-222: mul_mat, scale, [diag_mask_inf], soft_max,

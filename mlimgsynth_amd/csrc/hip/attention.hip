@@ -127,52 +127,70 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p)
         const int kv0 = t * 64;
         if (t + 1 < nt) load_kv(t + 1);
 
-        // ---- S^T = K . Q^T  (two 32-key sub-tiles)
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles; the second is skipped when it holds no key at all,
+        //      e.g. keys 64..76 of the 77-token cross attention live in sub-tile 0 of tile 1)
+        const bool sub1 = kv0 + 32 < p.Tk;                                   // wave-uniform
         f32x16 sacc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+            if (kt == 1 && !sub1) continue;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (32 * kt + lr) * KSTR + (16 * ks + 8 * lh) * 2);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kt], 0, 0, 0);
             }
         }
-        // ---- online softmax over the key axis (registers + one cross-half exchange)
+        // ---- online softmax over the key axis (registers + one cross-half exchange).
+        // Raw scores stay unscaled: p = exp2(s*sc - m*sc) is ONE fma + v_exp per element.  Masking only in
+        // tiles that need it (tail of Tk, causal diagonal): the test is wave-uniform.
+        const bool need_mask = (kv0 + 64 > p.Tk) || (p.causal && kv0 + 63 > qw);
+        if (need_mask) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kv0 + 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (key >= p.Tk || (p.causal && key > qrow)) sacc[kt][e] = -1.0e30f;
+                }
+        }
         float mx = -1.0e30f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kv0 + 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float s = sacc[kt][e] * p.sc;
-                if (key >= p.Tk || (p.causal && key > qrow)) s = -1.0e30f;
-                sacc[kt][e] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        // deferred rescale (T13): keep the old reference maximum while the new one exceeds it by less than
+        // 2^6 in the exp2 domain (P <= 64 fits fp16 with full relative precision); the decision is taken for
+        // the whole wave, BEFORE this tile's P is formed, so O, l and P always share one reference.
+        const bool grow = (mx - m_run) * p.sc > 6.0f;
+        if (__any(grow)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * p.sc);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        }
+        const float msc = -m_run * p.sc;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(sacc[kt][e] - m_new);
+                const float pv = exp2f(fmaf(sacc[kt][e], p.sc, msc));
                 sacc[kt][e] = pv;
                 rs += pv;
             }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int d = 0; d < NDV; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        l_run += rs;
 
         // ---- O^T += V^T . P   (P = S^T accumulators as B operand, permuted k order)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && !sub1) continue;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f16x8 pf;
@@ -188,6 +206,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p)
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.f, pf, oacc[d], 0, 0, 0);
                 }
             }
+        }
         __syncthreads();   // every wave is done reading this tile
         if (t + 1 < nt) {
             store_kv();

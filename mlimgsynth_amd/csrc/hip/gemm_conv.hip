@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr int BK = 64;
 
 struct GemmP {
     const _Float16* A;
@@ -50,23 +49,38 @@ struct GemmP {
     _Float16* C16;
     long ldc16;
     int nbm, nbn;
+    int vec;   // 1: every row stride and N are multiples of 4 -> wide (LDS-transposed) epilogue
 };
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
+// c ^ swz(r) so that a ds_read_b128 fragment read (32 lanes = 32 consecutive rows, one logical chunk)
+// touches every bank once (64 banks x 4 B; 16-lane service groups).
+template <int BK>
+__device__ __forceinline__ int row_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ row_swz<BK>(row)) << 4); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
+// 16 zero bytes in global memory: the source of every padded / out-of-range 16-byte chunk of the
+// direct-to-LDS path (global_load_lds has no bounds check and no zero-fill)
+__device__ uint4 g_zero_page[4];
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, bool GLDS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p)
 {
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_IT = BM * 8 / THREADS, B_IT = BN * 8 / THREADS;
-    constexpr int ROWS_PER_IT = THREADS / 8;
-    static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "tile/threads mismatch");
+    constexpr int CPR = BK / 8;                   // 16-byte chunks per tile row
+    constexpr int RB = BK * 2;                    // bytes per tile row
+    constexpr int A_IT = BM * CPR / THREADS, B_IT = BN * CPR / THREADS;
+    constexpr int ROWS_PER_IT = THREADS / CPR;
+    constexpr int ROWS_PER_WAVE = 64 / CPR;       // rows one wave-instruction of the direct-to-LDS path covers
+    static_assert(BM * CPR % THREADS == 0 && BN * CPR % THREADS == 0, "tile/threads mismatch");
+    static_assert(ROWS_PER_IT % 16 == 0, "row swizzle must be invariant over a thread's rows");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                     // [2][BM][128 B]
-    unsigned char* Bs = smem + 2 * BM * 128;      // [2][BN][128 B]
+    unsigned char* As = smem;                     // [2][BM][RB]
+    unsigned char* Bs = smem + 2 * BM * RB;       // [2][BN][RB]
 
     // ---- XCD-aware tile mapping (bijective for any grid size)
     const int nblk = p.nbm * p.nbn;
@@ -83,8 +97,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const int lr = lane & 31, lh = lane >> 5;
 
     // ---- staging assignment: chunk column fixed per thread, A_IT/B_IT rows
-    const int sc = tid & 7;        // 16-byte chunk (8 halfs) within the 64-wide K tile
-    const int sr = tid >> 3;       // first row
+    const int sr = tid / CPR;      // first row
+    // 16-byte chunk (8 halfs) within the 64-wide K tile.  Register staging: the thread writes logical chunk
+    // tid&7 to its swizzled slot.  Direct-to-LDS (GLDS): a wave-instruction writes 1 KiB linearly (lane l ->
+    // row l>>3, slot l&7), so the swizzle moves to the SOURCE: the thread fetches the logical chunk whose
+    // swizzled slot is tid&7 (cdna_hip_programming.md rule 21).  (row>>1)&7 is the same for all of a
+    // thread's rows because consecutive rows are ROWS_PER_IT (a multiple of 16) apart.
+    const int sc = GLDS ? ((tid % CPR) ^ row_swz<BK>(sr)) : (tid % CPR);
     // conv gather state (per thread: position of its chunk in (kh,kw,cin); per row: pixel origin)
     int g_kh = 0, g_kw = 0, g_cin = sc * 8;
     int row_pix[A_IT], row_ih0[A_IT], row_iw0[A_IT];
@@ -150,12 +169,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int r = sr + i * ROWS_PER_IT;
-            *reinterpret_cast<uint4*>(As + buf * BM * 128 + lds_off(r, sc)) = ra[i];
+            *reinterpret_cast<uint4*>(As + buf * BM * RB + lds_off<BK>(r, sc)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int r = sr + i * ROWS_PER_IT;
-            *reinterpret_cast<uint4*>(Bs + buf * BN * 128 + lds_off(r, sc)) = rb[i];
+            *reinterpret_cast<uint4*>(Bs + buf * BN * RB + lds_off<BK>(r, sc)) = rb[i];
+        }
+    };
+
+    // direct global -> LDS staging of one K tile (no VGPR round trip, no ds_write): 16 B per lane per instruction
+    auto stage_tile_glds = [&](int kt, int buf) {
+        const int k = kt * BK + sc * 8;
+        const _Float16* zsrc = reinterpret_cast<const _Float16*>(g_zero_page);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const _Float16* src = zsrc;
+            if (CONV) {
+                const int ih = row_ih0[i] + g_kh, iw = row_iw0[i] + g_kw;
+                if (row_ok[i] && g_kh < p.KH && (unsigned)ih < (unsigned)He && (unsigned)iw < (unsigned)We) {
+                    const int sh = p.ups ? (ih >> 1) : ih, sw = p.ups ? (iw >> 1) : iw;
+                    src = p.A + (long)(row_pix[i] + sh * p.W + sw) * p.lda + g_cin;
+                }
+            } else {
+                if (row_ok[i] && k < p.K) src = p.A + (long)row_pix[i] * p.lda + k;
+            }
+            unsigned char* dst = As + buf * BM * RB + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;   // wave-uniform base
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + sr + i * ROWS_PER_IT;
+            const _Float16* src = (n < p.N && k < p.K) ? p.B + (long)n * p.ldb + k : zsrc;
+            unsigned char* dst = Bs + buf * BN * RB + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        if (CONV) {
+            g_cin += BK;
+            while (g_cin >= p.Cin) { g_cin -= p.Cin; if (++g_kw == p.KW) { g_kw = 0; ++g_kh; } }
         }
     };
 
@@ -168,36 +221,120 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    if (GLDS) stage_tile_glds(0, 0);
+    else { load_tile(0); store_tile(0); }
+    __syncthreads();   // GLDS: the barrier's fence drains the LDS-DMA (vmcnt(0)) before anyone reads the tile
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) load_tile(kt + 1);
-        const unsigned char* Ab = As + cur * BM * 128;
-        const unsigned char* Bb = Bs + cur * BN * 128;
+        if (more) { if (GLDS) stage_tile_glds(kt + 1, cur ^ 1); else load_tile(kt + 1); }
+        const unsigned char* Ab = As + cur * BM * RB;
+        const unsigned char* Bb = Bs + cur * BN * RB;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {   // BK/16 k-steps of the 32x32x16 MFMA
             f16x8 af[TM], bf[TN];
             const int ch = ks * 2 + lh;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(Ab + lds_off(wm * WM + i * 32 + lr, ch));
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(Ab + lds_off<BK>(wm * WM + i * 32 + lr, ch));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + lds_off(wn * WN + j * 32 + lr, ch));
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + lds_off<BK>(wn * WN + j * 32 + lr, ch));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
+        if (more && !GLDS) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
+    if constexpr (WN == 64) {
+        if (p.vec) {
+            // Wide epilogue: each wave transposes its 32x64 fp32 slab through a private 8 KiB LDS region (the
+            // tile buffers are free after the main loop's last barrier) so that a lane owns 4 CONSECUTIVE
+            // columns: bias/residual loads and the stores are 16-byte (fp32) / 8-byte (fp16) accesses, 16 lanes
+            // cover 256 contiguous bytes of a row; 16 store instructions per slab instead of 64 scalar ones.
+            float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[i][j][e];
+                __builtin_amdgcn_wave_barrier();
+                if (!geglu) {
+                    const int c4 = (lane & 15) * 4;
+                    const int n = n0 + wn * WN + c4;
+                    float4 bv = make_float4(0, 0, 0, 0);
+                    if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = it * 4 + (lane >> 4);
+                        const int m = m0 + wm * WM + i * 32 + row;
+                        float4 v = *reinterpret_cast<const float4*>(stg + row * 64 + c4);
+                        if (m >= p.M || n >= p.N) continue;
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                        if (p.rowbias) {
+                            const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        float4 rs = make_float4(0, 0, 0, 0);
+                        if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+                        if (p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                        switch (p.act) {
+                        case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
+                        case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
+                        case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
+                        case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
+                        default: break;
+                        }
+                        if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = v;
+                        if (p.C16) {
+                            f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                            *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
+                        }
+                    }
+                } else {
+                    // slab columns 0..31 = value, 32..63 = gate (weight rows interleaved in blocks of 32)
+                    const int c4 = (lane & 7) * 4;
+                    const int nv = n0 + wn * WN + c4, ng = nv + 32;
+                    const int no = ((n0 + wn * WN) >> 6) * 32 + c4;
+                    float4 bvv = make_float4(0, 0, 0, 0), bgg = bvv;
+                    if (p.bias && ng < p.N) { bvv = *reinterpret_cast<const float4*>(p.bias + nv); bgg = *reinterpret_cast<const float4*>(p.bias + ng); }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 8 + (lane >> 3);
+                        const int m = m0 + wm * WM + i * 32 + row;
+                        const float4 a4 = *reinterpret_cast<const float4*>(stg + row * 64 + c4);
+                        const float4 g4 = *reinterpret_cast<const float4*>(stg + row * 64 + 32 + c4);
+                        if (m >= p.M || ng >= p.N) continue;
+                        float4 v;
+                        v.x = (a4.x + bvv.x) * gelu_tanh_f(g4.x + bgg.x);
+                        v.y = (a4.y + bvv.y) * gelu_tanh_f(g4.y + bgg.y);
+                        v.z = (a4.z + bvv.z) * gelu_tanh_f(g4.z + bgg.z);
+                        v.w = (a4.w + bvv.w) * gelu_tanh_f(g4.w + bgg.w);
+                        if (p.resid) {
+                            const float4 rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + no);
+                            v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                        }
+                        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + no) = v;
+                        if (p.C16) {
+                            f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                            *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + no) = h;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+    }
+    // scalar fallback (N or a stride not a multiple of 4: 3-channel image outputs, padded 4-channel latents)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -227,7 +364,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     if (p.C16) p.C16[(long)m * p.ldc16 + n] = (_Float16)v;
                 }
             } else {
-                // weight rows interleaved in blocks of 32: tile j even = value, j odd = gate
                 if constexpr (TN % 2 == 0) {
 #pragma unroll
                     for (int j = 0; j < TN; j += 2) {
@@ -247,7 +383,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+int g_gemm_mode = 0;   // 0: direct-to-LDS staging (default)  1: register staging
+int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
 {
     GemmP p;
@@ -259,25 +398,44 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
-    constexpr int THREADS = WAVES_M * WAVES_N * 64;
-    constexpr size_t LDS = (size_t)2 * (BM + BN) * 128;
-    const dim3 grid(p.nbm * p.nbn), block(THREADS);
-    if (a->conv) {
-        auto kfn = gemm_kernel<BM, BN, WAVES_M, WAVES_N, true>;
-        if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
-    } else {
-        auto kfn = gemm_kernel<BM, BN, WAVES_M, WAVES_N, false>;
-        if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+    {
+        const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
+        p.vec = !(nout & 3) && !(a->N & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) &&
+                (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
+                (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
-    return mlsd_check_launch("gemm_kernel");
+    constexpr int THREADS = WAVES_M * WAVES_N * 64;
+    constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
+    const dim3 grid(p.nbm * p.nbn), block(THREADS);
+    auto go = [&](auto kfn) -> int {
+        if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+        return mlsd_check_launch("gemm_kernel");
+    };
+    if (g_gemm_mode == 1) {   // register-staged variant (A/B comparisons)
+        return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, false>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, false>);
+    }
+    return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, true>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, true>);
 }
+
+int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
 
 int pick_variant(const mlsd_gemm_args* a)
 {
-    // 0: 128x128 tile, 2x2 waves (wave tile 64x64)   1: 64x128 tile, 2x2 waves (wave tile 32x64, small M)
+    // 0: 128x128x64, 2x2 waves (wave tile 64x64)   1: 64x128x64, 2x2 waves (wave tile 32x64, small M)
+    // 2: 128x128x32   3: 256x128x64, 4x2 waves   4: 128x256x64, 2x4 waves   5: 256x256x64, 4x4 waves? (2x4: wave 128x64)
+    if (g_gemm_variant >= 0) return g_gemm_variant;
     if (a->M <= 64) return 1;
+    // 128x128 (2 blocks/CU, 64 KB LDS each) vs 256x128 (1 block/CU): the bigger tile moves 25 % fewer
+    // operand bytes per FLOP (measured +8..15 % on wide outputs) but quantises worse.  Pick by the
+    // fill of the last round of blocks over the 256 CUs.
+    auto fill = [&](int bm, int bn, int slots) {
+        const long blocks = (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
+        const long rounds = (blocks + slots - 1) / slots;
+        return (double)blocks / (double)(rounds * slots);
+    };
+    const double e0 = fill(128, 128, 512), e3 = 1.08 * fill(256, 128, 256);
+    if (a->M >= 2048 && a->N >= 1920 && e3 > e0) return 3;
     return 0;
 }
 
@@ -300,16 +458,28 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     if (!a->C32 && !a->C16) return mlsd_set_error(-1, "mlsd_gemm: no output");
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
-    case 1: return launch<64, 128, 2, 2>(a, st);   // small M: wave tile 32x64
-    default: return launch<128, 128, 2, 2>(a, st);
+    case 1: return launch<64, 128, 64, 2, 2>(a, st);   // small M: wave tile 32x64
+    case 2: return launch<128, 128, 32, 2, 2>(a, st);
+    case 3: return launch<256, 128, 64, 4, 2>(a, st);
+    case 4: return launch<128, 256, 64, 2, 4>(a, st);
+    case 5: return launch<256, 256, 64, 2, 4>(a, st);  // wave tile 128x64
+    default: return launch<128, 128, 64, 2, 2>(a, st);
     }
 }
+
+MLSD_API void mlsd_gemm_set_mode(int mode) { g_gemm_mode = mode; }
+MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
+MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     switch (pick_variant(a)) {
-    case 1: return a->conv ? "gemm_kernel<64,128,2,2,conv>" : "gemm_kernel<64,128,2,2,linear>";
-    default: return a->conv ? "gemm_kernel<128,128,2,2,conv>" : "gemm_kernel<128,128,2,2,linear>";
+    case 1: return a->conv ? "gemm_kernel<64,128,64,2,2,conv>" : "gemm_kernel<64,128,64,2,2,linear>";
+    case 2: return a->conv ? "gemm_kernel<128,128,32,2,2,conv>" : "gemm_kernel<128,128,32,2,2,linear>";
+    case 3: return a->conv ? "gemm_kernel<256,128,64,4,2,conv>" : "gemm_kernel<256,128,64,4,2,linear>";
+    case 4: return a->conv ? "gemm_kernel<128,256,64,2,4,conv>" : "gemm_kernel<128,256,64,2,4,linear>";
+    case 5: return a->conv ? "gemm_kernel<256,256,64,2,4,conv>" : "gemm_kernel<256,256,64,2,4,linear>";
+    default: return a->conv ? "gemm_kernel<128,128,64,2,2,conv>" : "gemm_kernel<128,128,64,2,2,linear>";
     }
 }
 
