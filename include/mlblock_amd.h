@@ -44,6 +44,8 @@ void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
+/* GEMM tile autotuning on the first mlctx_compute of a plan (default on; results cached per shape) */
+void   mlctx_set_autotune(int on);
 
 /* ---- graph definition (src/mlblock.h:115-160) */
 void      mlctx_block_begin(MLCtx* C);

@@ -94,6 +94,7 @@ typedef struct mlsd_gemm_args {
 	int64_t ldc16;
 	const float* bias_m;    /* [M] per-row bias (operands swapped: V^T = Wv . x^T in the VAE attention) or NULL */
 	int act_after_resid;    /* 1: activation applied after the residual add (TAESD block: relu(conv + x), src/tae.c:36-37) */
+	int tile_variant;       /* 0 = automatic choice; k+1 = use tile variant k (set by the plan's autotuner) */
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -104,6 +105,7 @@ const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
 void mlsd_gemm_set_mode(int mode);
 /* diagnostics: force a tile variant (-1 = automatic choice) / the scalar epilogue (1) instead of the wide one (0) */
 void mlsd_gemm_force_variant(int v);
+int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
 
 /* ---------------------------------------------------------------- fused attention

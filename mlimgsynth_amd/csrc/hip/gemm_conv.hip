@@ -9,23 +9,28 @@
 // consecutive channels of one input pixel: coalesced NHWC loads, no im2col buffer in HBM.
 //
 // Structure (one block = WAVES_M x WAVES_N wavefronts of 64 lanes):
-//   * BK = 64; A and B tiles are staged global -> registers -> LDS (the gather needs per-lane
-//     zero-fill, so register staging), two LDS buffers, ONE barrier per K-tile: the loads of
-//     tile t+1 are issued before the MFMAs of tile t and written to the other buffer after them.
-//   * LDS rows are 128 B (64 halfs); the 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7):
-//     a ds_read_b128 fragment read (lanes = 32 different rows, same logical chunk) is
-//     bank-conflict free on the 64-bank LDS (cdna_hip_programming.md T2).
+//   * A and B tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no
+//     ds_write); padded / out-of-range chunks read a 16-byte zero page.  The LDS image is lane-linear
+//     per wave-instruction, so the bank-conflict XOR swizzle is applied to the SOURCE chunk index
+//     (cdna_hip_programming.md rule 21) and again on the fragment read: ds_read_b128 of 32 rows
+//     x one logical chunk touches every bank once.
+//   * NSTAGE-deep LDS ring, ONE raw s_barrier per K tile, counted s_waitcnt vmcnt(N): the loads of the
+//     next NSTAGE-2 tiles stay in flight across the barrier (never drained to 0 inside the loop).
+//       iteration kt:  wait(tile kt landed) ; barrier ; issue tile kt+NSTAGE-1 into the slot that
+//                      tile kt-1 just vacated ; MFMAs on tile kt
+//     RAW: a wave's own counted wait + the barrier order every wave's DMA before any fragment read.
+//     WAR: a slot is refilled only after the barrier that every wave reaches after its reads of it.
 //   * each wave owns a (TM*32) x (TN*32) sub-tile: TM*TN accumulators of 16 fp32 registers.
 //   * blockIdx is remapped so that the blocks of one XCD (blockIdx % 8) walk a contiguous
 //     range of tiles: neighbouring tiles share the A panel in that XCD's L2 (T1).
-//   * epilogue fuses bias, per-batch-row bias (time embedding), activation, GEGLU gating,
-//     fp32 residual add, and writes fp32 and/or fp16.
+//   * epilogue: each wave transposes its slab through LDS so a lane owns 4 consecutive columns;
+//     bias, per-image row bias (time embedding), activation, GEGLU gating, fp32 residual and the
+//     fp32 / fp16 stores are 16-byte / 8-byte accesses.
 #include <hip/hip_runtime.h>
 #include "common.hpp"
 #include "mlsd_kernels.h"
 
 namespace {
-
 
 struct GemmP {
     const _Float16* A;
@@ -60,11 +65,18 @@ __device__ __forceinline__ int row_swz(int row) { return BK == 64 ? ((row >> 1) 
 template <int BK>
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ row_swz<BK>(row)) << 4); }
 
-// 16 zero bytes in global memory: the source of every padded / out-of-range 16-byte chunk of the
-// direct-to-LDS path (global_load_lds has no bounds check and no zero-fill)
+// 16 zero bytes in global memory: the source of every padded / out-of-range 16-byte chunk
+// (global_load_lds has no bounds check and no zero-fill)
 __device__ uint4 g_zero_page[4];
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, bool GLDS>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt immediate range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p)
 {
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
@@ -73,14 +85,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     constexpr int CPR = BK / 8;                   // 16-byte chunks per tile row
     constexpr int RB = BK * 2;                    // bytes per tile row
     constexpr int A_IT = BM * CPR / THREADS, B_IT = BN * CPR / THREADS;
+    constexpr int LPT = A_IT + B_IT;              // LDS-DMA instructions per thread per K tile
     constexpr int ROWS_PER_IT = THREADS / CPR;
-    constexpr int ROWS_PER_WAVE = 64 / CPR;       // rows one wave-instruction of the direct-to-LDS path covers
+    constexpr int ROWS_PER_WAVE = 64 / CPR;       // rows one wave-instruction covers
+    constexpr int STAGE_BYTES = (BM + BN) * RB;
     static_assert(BM * CPR % THREADS == 0 && BN * CPR % THREADS == 0, "tile/threads mismatch");
     static_assert(ROWS_PER_IT % 16 == 0, "row swizzle must be invariant over a thread's rows");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                     // [2][BM][RB]
-    unsigned char* Bs = smem + 2 * BM * RB;       // [2][BN][RB]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE][A tile | B tile]; ONE LDS object
 
     // ---- XCD-aware tile mapping (bijective for any grid size)
     const int nblk = p.nbm * p.nbn;
@@ -96,16 +109,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // ---- staging assignment: chunk column fixed per thread, A_IT/B_IT rows
-    const int sr = tid / CPR;      // first row
-    // 16-byte chunk (8 halfs) within the 64-wide K tile.  Register staging: the thread writes logical chunk
-    // tid&7 to its swizzled slot.  Direct-to-LDS (GLDS): a wave-instruction writes 1 KiB linearly (lane l ->
-    // row l>>3, slot l&7), so the swizzle moves to the SOURCE: the thread fetches the logical chunk whose
-    // swizzled slot is tid&7 (cdna_hip_programming.md rule 21).  (row>>1)&7 is the same for all of a
-    // thread's rows because consecutive rows are ROWS_PER_IT (a multiple of 16) apart.
-    const int sc = GLDS ? ((tid % CPR) ^ row_swz<BK>(sr)) : (tid % CPR);
-    // conv gather state (per thread: position of its chunk in (kh,kw,cin); per row: pixel origin)
-    int g_kh = 0, g_kw = 0, g_cin = sc * 8;
+    // ---- staging assignment.  A wave-instruction writes 1 KiB of LDS linearly (lane l -> row l/CPR, slot
+    // l%CPR); the thread therefore fetches the LOGICAL chunk whose swizzled slot is tid%CPR.  row_swz is the
+    // same for all of a thread's rows (they are ROWS_PER_IT, a multiple of 16, apart).
+    const int sr = tid / CPR;
+    const int sc = (tid % CPR) ^ row_swz<BK>(sr);
+    int g_kh = 0, g_kw = 0, g_cin = sc * 8;       // conv: position of this thread's chunk in (kh, kw, cin)
     int row_pix[A_IT], row_ih0[A_IT], row_iw0[A_IT];
     bool row_ok[A_IT];
     if (CONV) {
@@ -132,56 +141,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         }
     }
     const int He = p.ups ? p.H * 2 : p.H, We = p.ups ? p.W * 2 : p.W;
+    const _Float16* zsrc = reinterpret_cast<const _Float16*>(g_zero_page);
 
-    uint4 ra[A_IT], rb[B_IT];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto load_tile = [&](int kt) {
+    // issue the LDS-DMA of K tile kt into ring slot `slot` (exactly LPT instructions per thread, always)
+    auto stage_tile = [&](int kt, int slot) {
         const int k = kt * BK + sc * 8;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            uint4 v = zero4;
-            if (CONV) {
-                const int ih = row_ih0[i] + g_kh, iw = row_iw0[i] + g_kw;
-                if (row_ok[i] && g_kh < p.KH && (unsigned)ih < (unsigned)He && (unsigned)iw < (unsigned)We) {
-                    const int sh = p.ups ? (ih >> 1) : ih, sw = p.ups ? (iw >> 1) : iw;
-                    const long off = (long)(row_pix[i] + sh * p.W + sw) * p.lda + g_cin;
-                    v = *reinterpret_cast<const uint4*>(p.A + off);
-                }
-            } else {
-                if (row_ok[i] && k < p.K) v = *reinterpret_cast<const uint4*>(p.A + (long)row_pix[i] * p.lda + k);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + sr + i * ROWS_PER_IT;
-            uint4 v = zero4;
-            if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.B + (long)n * p.ldb + k);
-            rb[i] = v;
-        }
-        if (CONV) {  // advance this thread's chunk by one K tile
-            g_cin += BK;
-            while (g_cin >= p.Cin) { g_cin -= p.Cin; if (++g_kw == p.KW) { g_kw = 0; ++g_kh; } }
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int r = sr + i * ROWS_PER_IT;
-            *reinterpret_cast<uint4*>(As + buf * BM * RB + lds_off<BK>(r, sc)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int r = sr + i * ROWS_PER_IT;
-            *reinterpret_cast<uint4*>(Bs + buf * BN * RB + lds_off<BK>(r, sc)) = rb[i];
-        }
-    };
-
-    // direct global -> LDS staging of one K tile (no VGPR round trip, no ds_write): 16 B per lane per instruction
-    auto stage_tile_glds = [&](int kt, int buf) {
-        const int k = kt * BK + sc * 8;
-        const _Float16* zsrc = reinterpret_cast<const _Float16*>(g_zero_page);
+        unsigned char* As = smem + slot * STAGE_BYTES;
+        unsigned char* Bs = As + BM * RB;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const _Float16* src = zsrc;
@@ -194,7 +160,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             } else {
                 if (row_ok[i] && k < p.K) src = p.A + (long)row_pix[i] * p.lda + k;
             }
-            unsigned char* dst = As + buf * BM * RB + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;   // wave-uniform base
+            unsigned char* dst = As + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;   // wave-uniform base
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -202,11 +168,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + sr + i * ROWS_PER_IT;
             const _Float16* src = (n < p.N && k < p.K) ? p.B + (long)n * p.ldb + k : zsrc;
-            unsigned char* dst = Bs + buf * BN * RB + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;
+            unsigned char* dst = Bs + (wave * ROWS_PER_WAVE + i * ROWS_PER_IT) * RB;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        if (CONV) {
+        if (CONV) {  // advance this thread's chunk by one K tile
             g_cin += BK;
             while (g_cin >= p.Cin) { g_cin -= p.Cin; if (++g_kw == p.KW) { g_kw = 0; ++g_kh; } }
         }
@@ -221,33 +187,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = (p.K + BK - 1) / BK;
-    if (GLDS) stage_tile_glds(0, 0);
-    else { load_tile(0); store_tile(0); }
-    __syncthreads();   // GLDS: the barrier's fence drains the LDS-DMA (vmcnt(0)) before anyone reads the tile
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) { if (GLDS) stage_tile_glds(kt + 1, cur ^ 1); else load_tile(kt + 1); }
-        const unsigned char* Ab = As + cur * BM * RB;
-        const unsigned char* Bb = Bs + cur * BN * RB;
+    // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {   // BK/16 k-steps of the 32x32x16 MFMA
-            f16x8 af[TM], bf[TN];
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nkt) stage_tile(s, s);
+
+    int slot = 0;                                  // ring slot of tile kt
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tiles kt+1 .. kt+NSTAGE-2 may stay in flight; tile kt must have landed
+        const int ahead = min(NSTAGE - 2, nkt - 1 - kt);
+        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (NSTAGE >= 3 && ahead == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // raw barrier: no implicit vmcnt(0) drain
+        if (kt + NSTAGE - 1 < nkt) {
+            int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
+            stage_tile(kt + NSTAGE - 1, fill);     // refill the slot tile kt-1 vacated (all waves passed the barrier)
+        }
+        const unsigned char* Ab = smem + slot * STAGE_BYTES;
+        const unsigned char* Bb = Ab + BM * RB;
+        // fragments are double-buffered in registers: the ds_read_b128 of k-step ks+1 are issued before the
+        // MFMAs of k-step ks, so LDS latency hides under matrix work instead of stalling every k-step
+        constexpr int KS = BK / 16;                // k-steps of the 32x32x16 MFMA per tile
+        f16x8 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int ks, int b) {
             const int ch = ks * 2 + lh;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(Ab + lds_off<BK>(wm * WM + i * 32 + lr, ch));
+            for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const f16x8*>(Ab + lds_off<BK>(wm * WM + i * 32 + lr, ch));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + lds_off<BK>(wn * WN + j * 32 + lr, ch));
+            for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f16x8*>(Bb + lds_off<BK>(wn * WN + j * 32 + lr, ch));
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
         }
-        if (more && !GLDS) store_tile(cur ^ 1);
-        __syncthreads();
+        if (++slot == NSTAGE) slot = 0;
     }
+    __syncthreads();   // every wave is done with the ring: it becomes the epilogue's staging space
 
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
@@ -383,10 +365,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
-int g_gemm_mode = 0;   // 0: direct-to-LDS staging (default)  1: register staging
 int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
 {
     GemmP p;
@@ -405,30 +386,44 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
-    constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
+    constexpr size_t RING = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    constexpr size_t EPI = (size_t)WAVES_M * WAVES_N * 32 * 64 * 4;      // 8 KiB per wave
+    constexpr size_t LDS = RING > EPI ? RING : EPI;
     const dim3 grid(p.nbm * p.nbn), block(THREADS);
     auto go = [&](auto kfn) -> int {
         if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_kernel");
     };
-    if (g_gemm_mode == 1) {   // register-staged variant (A/B comparisons)
-        return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, false>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, false>);
-    }
-    return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, true>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, true>);
+    return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE>);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
 
+struct Variant { const char* name; int bm, bn, slots; };
+const Variant kVariants[] = {
+    {"128x128x64s2", 128, 128, 512},   // 0: 64 KB ring, 2 blocks/CU
+    {"64x128x64s2", 64, 128, 768},     // 1: small M
+    {"128x128x32s4", 128, 128, 512},   // 2: 4-deep ring of 16 KB stages, 2 blocks/CU
+    {"256x128x64s2", 256, 128, 256},   // 3: 8 waves, 96 KB, 1 block/CU
+    {"256x128x32s3", 256, 128, 512},   // 4: 8 waves, 3-deep ring of 24 KB stages (72 KB), 2 blocks/CU
+    {"128x128x64s3", 128, 128, 256},   // 5: 3-deep ring, 96 KB, 1 block/CU
+    {"256x256x32s3", 256, 256, 256},   // 6: 8 waves (wave tile 128x64), 96 KB
+    {"256x128x32s4", 256, 128, 256},   // 7: 4-deep, 96 KB
+    {"256x256x32s3w16", 256, 256, 256}, // 8: 16 waves (4x4, wave tile 64x64), 96 KB ring, 1 block/CU
+    {"256x256x64s2w16", 256, 256, 256}, // 9: 16 waves, 128 KB ring
+    {"256x256x32s4w16", 256, 256, 256}, // 10: 16 waves, 4-deep 128 KB ring
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
 int pick_variant(const mlsd_gemm_args* a)
 {
-    // 0: 128x128x64, 2x2 waves (wave tile 64x64)   1: 64x128x64, 2x2 waves (wave tile 32x64, small M)
-    // 2: 128x128x32   3: 256x128x64, 4x2 waves   4: 128x256x64, 2x4 waves   5: 256x256x64, 4x4 waves? (2x4: wave 128x64)
-    if (g_gemm_variant >= 0) return g_gemm_variant;
+    if (g_gemm_variant >= 0 && g_gemm_variant < kNumVariants) return g_gemm_variant;
+    if (a->tile_variant > 0 && a->tile_variant <= kNumVariants) return a->tile_variant - 1;
     if (a->M <= 64) return 1;
-    // 128x128 (2 blocks/CU, 64 KB LDS each) vs 256x128 (1 block/CU): the bigger tile moves 25 % fewer
-    // operand bytes per FLOP (measured +8..15 % on wide outputs) but quantises worse.  Pick by the
-    // fill of the last round of blocks over the 256 CUs.
+    // 128x128 (2 blocks/CU) vs 256x128 (1 block/CU): the bigger tile moves 25 % fewer operand bytes per
+    // FLOP (measured +8..15 % on wide outputs) but quantises worse.  Pick by the fill of the last round
+    // of blocks over the 256 CUs.
     auto fill = [&](int bm, int bn, int slots) {
         const long blocks = (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
         const long rounds = (blocks + slots - 1) / slots;
@@ -458,29 +453,31 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     if (!a->C32 && !a->C16) return mlsd_set_error(-1, "mlsd_gemm: no output");
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
-    case 1: return launch<64, 128, 64, 2, 2>(a, st);   // small M: wave tile 32x64
-    case 2: return launch<128, 128, 32, 2, 2>(a, st);
-    case 3: return launch<256, 128, 64, 4, 2>(a, st);
-    case 4: return launch<128, 256, 64, 2, 4>(a, st);
-    case 5: return launch<256, 256, 64, 2, 4>(a, st);  // wave tile 128x64
-    default: return launch<128, 128, 64, 2, 2>(a, st);
+    case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);
+    case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
+    case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
+    case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
+    case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
+    case 6: return launch<256, 256, 32, 2, 4, 3>(a, st);
+    case 7: return launch<256, 128, 32, 4, 2, 4>(a, st);
+    case 8: return launch<256, 256, 32, 4, 4, 3>(a, st);
+    case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 10: return launch<256, 256, 32, 4, 4, 4>(a, st);
+    default: return launch<128, 128, 64, 2, 2, 2>(a, st);
     }
 }
 
-MLSD_API void mlsd_gemm_set_mode(int mode) { g_gemm_mode = mode; }
+MLSD_API void mlsd_gemm_set_mode(int mode) { (void)mode; }   /* kept for ABI stability: staging is always direct-to-LDS */
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 
+MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
+
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
-    switch (pick_variant(a)) {
-    case 1: return a->conv ? "gemm_kernel<64,128,64,2,2,conv>" : "gemm_kernel<64,128,64,2,2,linear>";
-    case 2: return a->conv ? "gemm_kernel<128,128,32,2,2,conv>" : "gemm_kernel<128,128,32,2,2,linear>";
-    case 3: return a->conv ? "gemm_kernel<256,128,64,4,2,conv>" : "gemm_kernel<256,128,64,4,2,linear>";
-    case 4: return a->conv ? "gemm_kernel<128,256,64,2,4,conv>" : "gemm_kernel<128,256,64,2,4,linear>";
-    case 5: return a->conv ? "gemm_kernel<256,256,64,2,4,conv>" : "gemm_kernel<256,256,64,2,4,linear>";
-    default: return a->conv ? "gemm_kernel<128,128,64,2,2,conv>" : "gemm_kernel<128,128,64,2,2,linear>";
-    }
+    static thread_local char buf[64];
+    snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[pick_variant(a)].name, a->conv ? "conv" : "linear");
+    return buf;
 }
 
 }  // extern "C"

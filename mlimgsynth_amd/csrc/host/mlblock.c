@@ -58,7 +58,7 @@ static void ctx_reset(MLCtx* C)
 	for (int i=0;i<C->n_chunks;++i) mlsd_free(C->chunks[i]);
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
-	C->err = 0; C->prepared = 0;
+	C->err = 0; C->prepared = 0; C->tuned = 0;
 	memset(&C->info, 0, sizeof(C->info));
 }
 
@@ -414,6 +414,54 @@ static int run_op(MLCtx* C, MLOp* op)
 	return mlsd_set_error(-1, "unknown op kind %d", (int)op->kind);
 }
 
+/* ------------------------------------------------------------------ GEMM tile autotuner
+ * "Measure, don't guess": the best tile variant depends on how the grid of a given (M,N,K) quantises over
+ * the 256 CUs and on the reduction length, so every distinct GEMM/conv shape of a plan is timed once per
+ * candidate variant (HIP events on the plan's stream, min of 3) and the winner is stored in the op.  Results
+ * are cached process-wide by shape.  Outputs written during tuning are overwritten by the first real run. */
+typedef struct { int conv, M, N, K, act, OH, stride, ups, out; int best; } TuneKey;
+static TuneKey g_tune[512];
+static int g_ntune = 0;
+static int g_autotune = 1;
+
+MLB_API void mlctx_set_autotune(int on) { g_autotune = on; }
+
+static int tune_gemm(MLCtx* C, MLOp* op)
+{
+	mlsd_gemm_args *g = &op->u.gemm;
+	TuneKey k = { g->conv, g->M, g->N, g->K, g->act, g->OH, g->stride, g->upsample, (g->C32 ? 1 : 0) | (g->C16 ? 2 : 0) | (g->resid ? 4 : 0), 0 };
+	for (int i=0;i<g_ntune;++i) {
+		TuneKey *t = &g_tune[i];
+		if (t->conv==k.conv && t->M==k.M && t->N==k.N && t->K==k.K && t->act==k.act && t->OH==k.OH && t->stride==k.stride &&
+		    t->ups==k.ups && t->out==k.out) { g->tile_variant = t->best; return 1; }
+	}
+	static const int cand_big[] = {0, 3, 4, 9}, cand_small[] = {1, 0};
+	const int *cand = g->M <= 64 ? cand_small : cand_big;
+	const int ncand = g->M <= 64 ? 2 : 4;
+	void *e0 = NULL, *e1 = NULL;
+	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
+	float best_ms = 1e30f; int best = 0;
+	for (int c=0;c<ncand;++c) {
+		g->tile_variant = cand[c] + 1;
+		if (mlsd_gemm(g, C->stream)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }   /* warm-up */
+		float mn = 1e30f;
+		for (int r=0;r<3;++r) {
+			mlsd_event_record(e0, C->stream);
+			if (mlsd_gemm(g, C->stream)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
+			mlsd_event_record(e1, C->stream);
+			mlsd_event_sync(e1);
+			float ms = 0; mlsd_event_elapsed_ms(e0, e1, &ms);
+			if (ms < mn) mn = ms;
+		}
+		if (mn < best_ms) { best_ms = mn; best = cand[c] + 1; }
+	}
+	mlsd_event_destroy(e0); mlsd_event_destroy(e1);
+	g->tile_variant = best;
+	k.best = best;
+	if (g_ntune < 512) g_tune[g_ntune++] = k;
+	return 1;
+}
+
 MLB_API int mlctx_prep(MLCtx* C)
 {
 	if (C->err) return C->err;
@@ -442,6 +490,21 @@ MLB_API int mlctx_compute(MLCtx* C)
 	for (int i=0;i<C->n_params;++i) if (!C->params[i].loaded)
 		return mlctx_fail(C, "parameter '%s' was never loaded", C->params[i].key);
 	double t0 = now_s();
+	if (!C->tuned && g_autotune && !mlsd_runtime_is_dry()) {
+		/* first evaluation: run eagerly, timing the tile variants of every not-yet-seen GEMM shape on its real
+		 * operands (the ops before it have already produced them) */
+		for (int i=0;i<C->n_ops;++i) {
+			if (C->ops[i].kind == OP_GEMM && !C->ops[i].u.gemm.tile_variant && tune_gemm(C, &C->ops[i]) < 0) return -1;
+			if (run_op(C, &C->ops[i])) {
+				char why[300]; snprintf(why, sizeof(why), "%s", mlsd_last_error());
+				mlsd_set_error(-1, "%s: op %d (%s) failed: %s", C->name, i, C->ops[i].label, why);
+				return -1;
+			}
+		}
+		C->tuned = 1;
+		C->info.n_compute++;
+		return 1;
+	}
 	if (C->flags & MLB_F_HIPGRAPH) {
 		if (!C->graph_exec) {
 			if (mlsd_capture_begin(C->stream)) return -1;

@@ -88,7 +88,7 @@ struct MLCtx {
 	size_t mem_compute, mem_params, mem_peak_live, mem_live;
 	void* gn_ws; size_t gn_ws_bytes;
 	void* graph_exec;
-	int prepared;
+	int prepared, tuned;
 	MLCtxInfo info;
 };
 

@@ -15,7 +15,7 @@ class GemmArgs(ctypes.Structure):
                 ("pad", c_int), ("upsample", c_int), ("W_", vp), ("ldb", c_i64), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("bias", vp), ("rowbias", vp), ("rows_per_batch", c_int), ("ldrb", c_i64),
                 ("resid", vp), ("ldr", c_i64), ("act", c_int), ("C32", vp), ("ldc32", c_i64), ("C16", vp),
-                ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int)]
+                ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int), ("tile_variant", c_int)]
 
 
 class AttnArgs(ctypes.Structure):
