@@ -55,6 +55,7 @@ struct GemmP {
     long ldc16;
     int nbm, nbn;
     int vec;   // 1: every row stride and N are multiples of 4 -> wide (LDS-transposed) epilogue
+    int dbg;   // diagnostics (timing-only builds of the loop): bit0 = no refills in the loop, bit1 = no MFMA/ds_read
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -76,7 +77,7 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE, int DBG = 0, bool REG = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p)
 {
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // l%CPR); the thread therefore fetches the LOGICAL chunk whose swizzled slot is tid%CPR.  row_swz is the
     // same for all of a thread's rows (they are ROWS_PER_IT, a multiple of 16, apart).
     const int sr = tid / CPR;
-    const int sc = (tid % CPR) ^ row_swz<BK>(sr);
+    const int sc = REG ? (tid % CPR) : ((tid % CPR) ^ row_swz<BK>(sr));   // REG: swizzle applied on the ds_write instead
     int g_kh = 0, g_kw = 0, g_cin = sc * 8;       // conv: position of this thread's chunk in (kh, kw, cin)
     int row_pix[A_IT], row_ih0[A_IT], row_iw0[A_IT];
     bool row_ok[A_IT];
@@ -178,6 +179,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         }
     };
 
+    // register-staged alternative (REG): global_load_dwordx4 -> VGPR -> ds_write_b128.  The LDS-DMA path is
+    // limited by its issue rate (~64 cycles per 1 KiB wave-instruction per CU, measured: the whole 256x256
+    // kernel runs at exactly that rate); ordinary loads return at the L1 rate and the ds_write costs ~13 cycles.
+    uint4 ra[A_IT], rb[B_IT];
+    auto load_tile_reg = [&](int kt) {
+        const int k = kt * BK + sc * 8;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (CONV) {
+                const int ih = row_ih0[i] + g_kh, iw = row_iw0[i] + g_kw;
+                if (row_ok[i] && g_kh < p.KH && (unsigned)ih < (unsigned)He && (unsigned)iw < (unsigned)We) {
+                    const int sh = p.ups ? (ih >> 1) : ih, sw = p.ups ? (iw >> 1) : iw;
+                    v = *reinterpret_cast<const uint4*>(p.A + (long)(row_pix[i] + sh * p.W + sw) * p.lda + g_cin);
+                }
+            } else {
+                if (row_ok[i] && k < p.K) v = *reinterpret_cast<const uint4*>(p.A + (long)row_pix[i] * p.lda + k);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + sr + i * ROWS_PER_IT;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.B + (long)n * p.ldb + k);
+            rb[i] = v;
+        }
+        if (CONV) {
+            g_cin += BK;
+            while (g_cin >= p.Cin) { g_cin -= p.Cin; if (++g_kw == p.KW) { g_kw = 0; ++g_kh; } }
+        }
+    };
+    auto store_tile_reg = [&](int slot) {
+        unsigned char* As = smem + slot * STAGE_BYTES;
+        unsigned char* Bs = As + BM * RB;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(As + lds_off<BK>(sr + i * ROWS_PER_IT, sc)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(Bs + lds_off<BK>(sr + i * ROWS_PER_IT, sc)) = rb[i];
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -187,22 +229,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = (p.K + BK - 1) / BK;
-    // prologue: NSTAGE-1 tiles in flight
+    if constexpr (REG) {
+        load_tile_reg(0);
+        store_tile_reg(0);
+    } else {
+        // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nkt) stage_tile(s, s);
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nkt) stage_tile(s, s);
+    }
 
     int slot = 0;                                  // ring slot of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
-        // tiles kt+1 .. kt+NSTAGE-2 may stay in flight; tile kt must have landed
-        const int ahead = min(NSTAGE - 2, nkt - 1 - kt);
-        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
-        else if (NSTAGE >= 3 && ahead == 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();              // raw barrier: no implicit vmcnt(0) drain
-        if (kt + NSTAGE - 1 < nkt) {
-            int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
-            stage_tile(kt + NSTAGE - 1, fill);     // refill the slot tile kt-1 vacated (all waves passed the barrier)
+        if constexpr (REG) {
+            __syncthreads();                       // tile kt visible (its ds_writes precede this barrier)
+            if (kt + 1 < nkt && !(DBG & 1)) load_tile_reg(kt + 1);   // in flight during the MFMAs of tile kt
+        } else {
+            // tiles kt+1 .. kt+NSTAGE-2 may stay in flight; tile kt must have landed
+            const int ahead = min(NSTAGE - 2, nkt - 1 - kt);
+            if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+            else if (NSTAGE >= 3 && ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // raw barrier: no implicit vmcnt(0) drain
+            if (kt + NSTAGE - 1 < nkt && !(DBG & 1)) {
+                int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
+                stage_tile(kt + NSTAGE - 1, fill); // refill the slot tile kt-1 vacated (all waves passed the barrier)
+            }
         }
         const unsigned char* Ab = smem + slot * STAGE_BYTES;
         const unsigned char* Bb = Ab + BM * RB;
@@ -217,6 +269,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f16x8*>(Bb + lds_off<BK>(wn * WN + j * 32 + lr, ch));
         };
+        if constexpr (!(DBG & 2)) {
         load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -227,6 +280,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
         }
+        }
+        if constexpr (REG) { if (kt + 1 < nkt && !(DBG & 1)) store_tile_reg(slot ^ 1); }   // other slot: last read in iteration kt-1
         if (++slot == NSTAGE) slot = 0;
     }
     __syncthreads();   // every wave is done with the ring: it becomes the epilogue's staging space
@@ -365,9 +420,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
+int g_gemm_dbg = 0;
 int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, bool REG = false>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
 {
     GemmP p;
@@ -385,6 +441,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
+    p.dbg = g_gemm_dbg;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr size_t RING = (size_t)NSTAGE * (BM + BN) * BK * 2;
     constexpr size_t EPI = (size_t)WAVES_M * WAVES_N * 32 * 64 * 4;      // 8 KiB per wave
@@ -395,7 +452,11 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_kernel");
     };
-    return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE>);
+#ifdef MLSD_GEMM_EXPERIMENTS   /* timing-only builds of the loop: no refills (1) / no MFMA (2); see DESIGN.md */
+    if (!a->conv && g_gemm_dbg == 1) return go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 1, REG>);
+    if (!a->conv && g_gemm_dbg == 2) return go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 2, REG>);
+#endif
+    return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
@@ -413,6 +474,11 @@ const Variant kVariants[] = {
     {"256x256x32s3w16", 256, 256, 256}, // 8: 16 waves (4x4, wave tile 64x64), 96 KB ring, 1 block/CU
     {"256x256x64s2w16", 256, 256, 256}, // 9: 16 waves, 128 KB ring
     {"256x256x32s4w16", 256, 256, 256}, // 10: 16 waves, 4-deep 128 KB ring
+    {"256x256x64s2w8", 256, 256, 256},  // 11: 8 waves (2x4, wave tile 128x64), 128 KB ring
+    {"256x256x32s4w8", 256, 256, 256},  // 12: 8 waves, 4-deep ring of 32 KB stages
+    {"256x256x64r2w16", 256, 256, 256}, // 13: as 9 but register-staged tiles (global_load -> ds_write)
+    {"128x128x64r2", 128, 128, 512},    // 14: as 0 but register-staged
+    {"256x128x64r2", 256, 128, 256},    // 15: as 3 but register-staged
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -454,15 +520,22 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
     case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);
-    case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
+    case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
+#ifdef MLSD_GEMM_EXPERIMENTS   /* variants that lost the tile study on MI355X (kept reproducible, not built by default) */
+    case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
     case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
     case 6: return launch<256, 256, 32, 2, 4, 3>(a, st);
     case 7: return launch<256, 128, 32, 4, 2, 4>(a, st);
     case 8: return launch<256, 256, 32, 4, 4, 3>(a, st);
-    case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
     case 10: return launch<256, 256, 32, 4, 4, 4>(a, st);
+    case 11: return launch<256, 256, 64, 2, 4, 2>(a, st);
+    case 12: return launch<256, 256, 32, 2, 4, 4>(a, st);
+    case 13: return launch<256, 256, 64, 4, 4, 2, true>(a, st);
+    case 14: return launch<128, 128, 64, 2, 2, 2, true>(a, st);
+    case 15: return launch<256, 128, 64, 4, 2, 2, true>(a, st);
+#endif
     default: return launch<128, 128, 64, 2, 2, 2>(a, st);
     }
 }
@@ -470,6 +543,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
 MLSD_API void mlsd_gemm_set_mode(int mode) { (void)mode; }   /* kept for ABI stability: staging is always direct-to-LDS */
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
+MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
 
 MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 
