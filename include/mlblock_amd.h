@@ -31,6 +31,7 @@ enum MLCtxFlags {           /* src/mlblock.h:29-36 */
 	MLB_F_QUIET = 2,
 	MLB_F_DUMP = 4,
 	MLB_F_HIPGRAPH = 8,     /* new: capture the plan into a hipGraph at prep and replay it */
+	MLB_F_OPSHAPES = 16,    /* diagnostics: mlctx_op_info labels GEMMs with their MxNxK */
 };
 
 /* ---- context lifecycle (mlctx_begin/end/prep/compute: src/mlblock.c:54-345) */

@@ -38,7 +38,7 @@ struct AttnP {
 };
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p)
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const AttnP p)
 {
     constexpr int DQK = (DH + 15) / 16 * 16;       // QK^T reduction length (zero padded)
     constexpr int NKS = DQK / 16;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p)
         const bool grow = (mx - m_run) * p.sc > 6.0f;
         if (__any(grow)) {
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * p.sc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p)
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(fmaf(sacc[kt][e], p.sc, msc));
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], p.sc, msc));   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
                 sacc[kt][e] = pv;
                 rs += pv;
             }

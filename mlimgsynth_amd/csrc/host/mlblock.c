@@ -542,7 +542,16 @@ MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flo
 	if (i < 0 || i >= C->n_ops) return -1;
 	if (label) {
 		const MLOp *op = &C->ops[i];
-		*label = op->kind == OP_GEMM && !op->label[0] ? mlsd_gemm_variant(&op->u.gemm) : op->label;
+		static _Thread_local char buf[96];
+		if (op->kind == OP_GEMM) {
+			const mlsd_gemm_args *g = &op->u.gemm;
+			snprintf(buf, sizeof(buf), "%s%s%s", op->label[0] ? op->label : mlsd_gemm_variant(g), C->flags & MLB_F_OPSHAPES ? " " : "", "");
+			if (C->flags & MLB_F_OPSHAPES) {
+				size_t l = strlen(buf);
+				snprintf(buf + l, sizeof(buf) - l, "%dx%dx%d%s%s", g->M, g->N, g->K, g->C32 ? " f32" : "", g->resid ? "+res" : "");
+			}
+			*label = buf;
+		} else *label = op->label;
 	}
 	if (flops) *flops = C->ops[i].flops;
 	return 1;
