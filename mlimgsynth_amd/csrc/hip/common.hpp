@@ -32,14 +32,18 @@ int mlsd_check_launch(const char* what);
     } while (0)
 
 // ---- small device helpers -------------------------------------------------
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// tanh-approximation GELU (ggml_gelu)
+// Activations on the fast hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): they sit in GEMM
+// epilogues where a libm-grade tanhf (~30 VALU instructions) costs a quarter of a short-K main loop.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_sigmoid(x); }
+// tanh-approximation GELU (ggml_gelu): 0.5 x (1 + tanh(u)) == x * sigmoid(2u)
 __device__ __forceinline__ float gelu_tanh_f(float x)
 {
     const float c = 0.7978845608028654f, a = 0.044715f;
-    return 0.5f * x * (1.0f + tanhf(c * x * (1.0f + a * x * x)));
+    const float u = c * x * (1.0f + a * x * x);
+    return x * fast_sigmoid(2.0f * u);
 }
-__device__ __forceinline__ float gelu_quick_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_quick_f(float x) { return x * fast_sigmoid(1.702f * x); }
 
 __device__ __forceinline__ float wave_sum(float v)
 {

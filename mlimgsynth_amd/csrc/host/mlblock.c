@@ -59,6 +59,7 @@ static void ctx_reset(MLCtx* C)
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0;
+	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->info, 0, sizeof(C->info));
 }
 

@@ -88,6 +88,8 @@ struct MLCtx {
 	size_t mem_compute, mem_params, mem_peak_live, mem_live;
 	void* gn_ws; size_t gn_ws_bytes;
 	void* graph_exec;
+	/* batched cross-attention K/V projection of the (step-constant) context: one GEMM for all layers */
+	struct { MLTensor* ctx; char* wbase; char* out16; int n_in, n_total, n_used; } kvb;
 	int prepared, tuned;
 	MLCtxInfo info;
 };
@@ -123,3 +125,6 @@ MLTensor* mlb_layer_norm_ex(MLCtx* C, MLTensor* x, float eps, int out32);
 MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int d_out, int d_embed, int n_head,
 	bool mask, bool bias, bool bias_out, MLTensor* resid);
 MLTensor* mlb_resnet_ex(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out);
+/* announce that `ctx` feeds cross-attention K/V projections totalling n_total output columns: they are computed by
+ * ONE GEMM recorded here; mlb_attn_mhead then only takes column slices (parameters keep their per-layer names) */
+int mlb_cross_kv_batch(MLCtx* C, MLTensor* ctx, int n_total);

@@ -308,6 +308,26 @@ static MLTensor* fused_proj(MLCtx* C, MLTensor* x, int d_embed, bool bias, const
 	return y;
 }
 
+int mlb_cross_kv_batch(MLCtx* C, MLTensor* ctx, int n_total)
+{	/* The context is the same tensor for every cross-attention layer (src/unet.c:130-132), so all
+	 * k_proj/v_proj GEMMs share their A operand: 70 launches of 616x2560x2048 (135 TFLOP/s, 100 blocks each)
+	 * become one 616 x n_total x 2048 launch that fills the chip. */
+	if (!ctx || n_total <= 0 || C->err) return -1;
+	const int n_in = ctx->c;
+	const void *xd = mlt_need16(C, ctx);
+	if (!xd) return -1;
+	const int64_t rows = rows_of(ctx);
+	C->kvb.ctx = ctx; C->kvb.n_in = n_in; C->kvb.n_total = n_total; C->kvb.n_used = 0;
+	C->kvb.wbase = (char*)mlctx_dalloc(C, (size_t)n_total * n_in * 2, 1);
+	C->kvb.out16 = (char*)mlctx_dalloc(C, (size_t)rows * n_total * 2, 0);
+	MLOp *op = mlctx_op_new(C, OP_GEMM, "");
+	mlsd_gemm_args *g = &op->u.gemm;
+	g->A = xd; g->lda = ctx->ld16; g->W_ = C->kvb.wbase; g->ldb = n_in; g->M = (int)rows; g->N = n_total; g->K = n_in;
+	g->C16 = C->kvb.out16; g->ldc16 = n_total;
+	op->flops = 2.0 * rows * (double)n_total * n_in;
+	return 1;
+}
+
 MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int d_out, int d_embed, int n_head,
 	bool mask, bool bias, bool bias_out, MLTensor* resid)
 {
@@ -330,12 +350,28 @@ MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int
 	} else {
 		if (k != v) { mlctx_fail(C, "attention: k and v must share their input"); return NULL; }
 		MLTensor *qp = MLN("q_proj", mlb_linear_ex(C, q, d_embed, bias, NULL, 0));
-		MLTensor *kv = fused_proj(C, k, d_embed, bias, n_kv, 2);
-		if (!qp || !kv) return NULL;
-		const char *pq = (const char*)mlt_need16(C, qp), *pk = (const char*)mlt_need16(C, kv);
-		record_attn(C, pq, d_embed, pk, 2*d_embed, pk + (size_t)d_embed*2, 2*d_embed, a->d16, d_embed,
-			nb, Tq, Tk, n_head, d_head, mask);
-		mlb_release(C, qp); mlb_release(C, kv);
+		if (!qp) return NULL;
+		if (C->kvb.ctx == k && !bias && k->c == C->kvb.n_in && C->kvb.n_used + 2*d_embed <= C->kvb.n_total) {
+			/* slices of the batched context projection: parameters registered under the reference's names */
+			const int off = C->kvb.n_used, n_in = k->c;
+			for (int i=0;i<2;++i) {
+				mlctx_block_begin(C);
+				mlctx_param_new_at(C, "weight", MLT_F16, n_in, d_embed, 1, 1, 0, C->kvb.wbase + (size_t)(off + i*d_embed) * n_in * 2);
+				mlctx_named_op(C, n_kv[i]);
+			}
+			C->kvb.n_used += 2*d_embed;
+			const char *pq = (const char*)mlt_need16(C, qp), *pk = C->kvb.out16 + (size_t)off * 2;
+			record_attn(C, pq, d_embed, pk, C->kvb.n_total, pk + (size_t)d_embed*2, C->kvb.n_total, a->d16, d_embed,
+				nb, Tq, Tk, n_head, d_head, mask);
+			mlb_release(C, qp);
+		} else {
+			MLTensor *kv = fused_proj(C, k, d_embed, bias, n_kv, 2);
+			if (!kv) return NULL;
+			const char *pq = (const char*)mlt_need16(C, qp), *pk = (const char*)mlt_need16(C, kv);
+			record_attn(C, pq, d_embed, pk, 2*d_embed, pk + (size_t)d_embed*2, 2*d_embed, a->d16, d_embed,
+				nb, Tq, Tk, n_head, d_head, mask);
+			mlb_release(C, qp); mlb_release(C, kv);
+		}
 	}
 	MLEpilogue ep = {0}; ep.resid = resid;
 	MLTensor *o = MLN("out_proj", mlb_linear_ex(C, a, d_out, bias_out, &ep, 0));

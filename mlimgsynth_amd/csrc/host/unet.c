@@ -96,10 +96,26 @@ static MLTensor* mlb_unet__embed(MLCtx* C, MLTensor* time, MLTensor* label, cons
 	return emb;
 }
 
+/* total width of all cross-attention k/v projections of the graph (same walk as __in/__mid/__out) */
+static int unet_cross_kv_width(const UnetParams* P)
+{
+	int total = 0, im = 0, ds = 1;
+	for (; P->ch_mult[im]; ++im) {
+		if (im) ds *= 2;
+		if (static_vector_in(P->attn_res, ds)) total += P->n_res_blk * P->transf_depth[im] * 2 * P->n_ch * P->ch_mult[im];          /* in  */
+	}
+	im--;
+	total += P->transf_depth[im] * 2 * P->n_ch * P->ch_mult[im];                                                                  /* mid */
+	for (; im >= 0; --im, ds /= 2)
+		if (static_vector_in(P->attn_res, ds)) total += (P->n_res_blk + 1) * P->transf_depth[im] * 2 * P->n_ch * P->ch_mult[im];   /* out */
+	return total;
+}
+
 MLB_API MLTensor* mlb_unet_denoise(MLCtx* C, MLTensor* x, MLTensor* time, MLTensor* ctx, MLTensor* label, const UnetParams* P)
 {
 	char name[64];
 	mlctx_block_begin(C);
+	if (mlb_cross_kv_batch(C, ctx, unet_cross_kv_width(P)) < 0) return NULL;
 	MLTensor *emb = mlb_unet__embed(C, time, label, P);
 	if (!emb) return NULL;
 
