@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int GN_MAXG = 32;
-constexpr int GN_MAXPP = 6;   // channel pairs per thread: supports C up to 2*256*6 = 3072
+constexpr int GN_MAXQ = 3;    // channel quads per thread: supports C up to 4*256*3 = 3072
 
 struct GnP {
     const float *x1, *x2;
@@ -41,57 +41,87 @@ __device__ __forceinline__ const float* gn_src(const GnP& p, int img, int pix, i
     return c < p.C1 ? p.x1 + ((long)img * p.HW + pix) * p.ld1 + c : p.x2 + ((long)img * p.HW + pix) * p.ld2 + (c - p.C1);
 }
 
+// Thread mapping shared by both passes: a thread owns fixed channel quads (16-byte loads) and walks the
+// pixels of its chunk with a fixed stride, so there is no per-element index arithmetic:
+//   Q = C/4 quads per pixel.  Q >= 256: every thread owns quads tid, tid+256, .. and visits every pixel.
+//                             Q <  256: PL = 256/Q pixel lanes; thread = (lane pl, quad q), pixel stride PL.
+struct GnMap { int PL, NQ, pl, q0; bool active; };
+__device__ __forceinline__ GnMap gn_map(int Q, int tid)
+{
+    GnMap m;
+    if (Q >= 256) { m.PL = 1; m.NQ = (Q + 255) / 256; m.pl = 0; m.q0 = tid; m.active = true; }
+    else { m.PL = 256 / Q; m.NQ = 1; m.pl = tid / Q; m.q0 = tid - m.pl * Q; m.active = m.pl < m.PL; }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void gn_stats(const GnP p)
 {
-    __shared__ float s1[256 * GN_MAXPP], s2[256 * GN_MAXPP];
+    // per (thread, quad, channel pair): shifted sum and sum of squares.  A quad may straddle two groups
+    // (channels per group is even but not always a multiple of 4), a pair never does.
+    __shared__ float s1[256 * GN_MAXQ * 2], s2[256 * GN_MAXQ * 2];
     const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int C2p = p.C >> 1;  // channel pairs
-    int PL, PP;
-    if (C2p >= 256) { PL = 1; PP = (C2p + 255) / 256; } else { PL = 256 / C2p; PP = 1; }
-    const int pl = C2p >= 256 ? 0 : tid / C2p;
-    const int pbase = C2p >= 256 ? tid : tid % C2p;
-    const bool active = pl < PL;
+    const int Q = p.C >> 2;
+    const GnMap m = gn_map(Q, tid);
     const int pix0 = chunk * p.pix_per_chunk;
     const int pix1 = min(pix0 + p.pix_per_chunk, p.HW);
 
-    float a1[GN_MAXPP][2], a2[GN_MAXPP][2], K[GN_MAXPP];
+    float a1[GN_MAXQ][2], a2[GN_MAXQ][2], K[GN_MAXQ][2];
+    const float* base[GN_MAXQ];
+    long ld[GN_MAXQ];
 #pragma unroll
-    for (int i = 0; i < GN_MAXPP; ++i) {
+    for (int i = 0; i < GN_MAXQ; ++i) {
         a1[i][0] = a1[i][1] = a2[i][0] = a2[i][1] = 0.f;
-        K[i] = 0.f;
-        const int pr = pbase + i * 256;
-        if (i < PP && pr < C2p) { const int g = (2 * pr) / p.cg; K[i] = *gn_src(p, img, 0, g * p.cg); }
+        K[i][0] = K[i][1] = 0.f;
+        base[i] = nullptr; ld[i] = 0;
+        const int q = m.q0 + i * 256;
+        if (i < m.NQ && q < Q) {
+            const int c = 4 * q;
+            K[i][0] = *gn_src(p, img, 0, (c / p.cg) * p.cg);
+            K[i][1] = *gn_src(p, img, 0, ((c + 2) / p.cg) * p.cg);
+            base[i] = gn_src(p, img, 0, c);
+            ld[i] = c < p.C1 ? p.ld1 : p.ld2;
+        }
     }
-    if (active) {
-        for (int pix = pix0 + pl; pix < pix1; pix += PL) {
+    if (m.active) {
+        // 4 pixels per trip: 4*NQ independent 16-byte loads in flight per thread (HBM latency, not issue, bounds this pass)
+        for (int pix = pix0 + m.pl; pix < pix1; pix += 4 * m.PL) {
 #pragma unroll
-            for (int i = 0; i < GN_MAXPP; ++i) {
-                const int pr = pbase + i * 256;
-                if (i < PP && pr < C2p) {
-                    const float2 v = *reinterpret_cast<const float2*>(gn_src(p, img, pix, 2 * pr));
-                    const float d0 = v.x - K[i], d1 = v.y - K[i];
-                    a1[i][0] += d0; a1[i][1] += d1;
-                    a2[i][0] += d0 * d0; a2[i][1] += d1 * d1;
+            for (int i = 0; i < GN_MAXQ; ++i) {
+                if (base[i]) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int px = pix + u * m.PL;
+                        v[u] = px < pix1 ? *reinterpret_cast<const float4*>(base[i] + (long)px * ld[i])
+                                         : make_float4(K[i][0], K[i][0], K[i][1], K[i][1]);   // contributes exactly 0
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d0 = v[u].x - K[i][0], d1 = v[u].y - K[i][0], d2 = v[u].z - K[i][1], d3 = v[u].w - K[i][1];
+                        a1[i][0] += d0 + d1; a2[i][0] += d0 * d0 + d1 * d1;
+                        a1[i][1] += d2 + d3; a2[i][1] += d2 * d2 + d3 * d3;
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < GN_MAXPP; ++i) {
-        s1[i * 256 + tid] = a1[i][0] + a1[i][1];
-        s2[i * 256 + tid] = a2[i][0] + a2[i][1];
+    for (int i = 0; i < GN_MAXQ; ++i) {
+        s1[(i * 256 + tid) * 2] = a1[i][0]; s1[(i * 256 + tid) * 2 + 1] = a1[i][1];
+        s2[(i * 256 + tid) * 2] = a2[i][0]; s2[(i * 256 + tid) * 2 + 1] = a2[i][1];
     }
     __syncthreads();
     if (tid < p.G) {
-        // deterministic combine: pairs of group g are [g*cg/2, (g+1)*cg/2), over all pixel lanes
+        // deterministic combine: channel pairs [g*cg/2, (g+1)*cg/2) of group g, over all pixel lanes
         const int g = tid, pr0 = g * (p.cg >> 1), pr1 = pr0 + (p.cg >> 1);
         float t1 = 0.f, t2 = 0.f;
         for (int pr = pr0; pr < pr1; ++pr) {
-            if (C2p >= 256) {
-                const int i = pr >> 8, t = pr & 255;
-                t1 += s1[i * 256 + t]; t2 += s2[i * 256 + t];
+            const int q = pr >> 1, half = pr & 1;
+            if (Q >= 256) {
+                const int i = q >> 8, t = q & 255;
+                t1 += s1[(i * 256 + t) * 2 + half]; t2 += s2[(i * 256 + t) * 2 + half];
             } else {
-                for (int l = 0; l < PL; ++l) { t1 += s1[l * C2p + pr]; t2 += s2[l * C2p + pr]; }
+                for (int l = 0; l < m.PL; ++l) { t1 += s1[(l * Q + q) * 2 + half]; t2 += s2[(l * Q + q) * 2 + half]; }
             }
         }
         float* w = p.ws + (((long)img * p.nchunk + chunk) * p.G + g) * 2;
@@ -112,10 +142,10 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
         for (int c = 0; c < p.nchunk; ++c) { t1 += w[(long)c * p.G * 2]; t2 += w[(long)c * p.G * 2 + 1]; }
         const double cnt = (double)p.cg * p.HW;
         const double K = *gn_src(p, img, 0, tid * p.cg);
-        const double m = t1 / cnt;
-        double var = t2 / cnt - m * m;
+        const double mu = t1 / cnt;
+        double var = t2 / cnt - mu * mu;
         if (var < 0) var = 0;
-        g_mean[tid] = (float)(K + m);
+        g_mean[tid] = (float)(K + mu);
         g_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     __syncthreads();
@@ -126,23 +156,53 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
         sh[c] = p.beta[c] - g_mean[g] * s;
     }
     __syncthreads();
+    const int Q = p.C >> 2;
+    const GnMap m = gn_map(Q, tid);
     const int pix0 = chunk * p.pix_per_chunk;
     const int pix1 = min(pix0 + p.pix_per_chunk, p.HW);
-    const int Q = p.C >> 2;  // channel quads
-    const long total = (long)(pix1 - pix0) * Q;
-    for (long idx = tid; idx < total; idx += 256) {
-        const int pix = pix0 + (int)(idx / Q), c = (int)(idx % Q) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(gn_src(p, img, pix, c));
-        const float4 s = *reinterpret_cast<const float4*>(sc + c);
-        const float4 b = *reinterpret_cast<const float4*>(sh + c);
-        float y0 = v.x * s.x + b.x, y1 = v.y * s.y + b.y, y2 = v.z * s.z + b.z, y3 = v.w * s.w + b.w;
-        if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-        const long o = ((long)img * p.HW + pix) * p.C + c;
-        f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
-        *reinterpret_cast<f16x4*>(p.y16 + o) = h;
-        if (p.raw16) {
-            f16x4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            *reinterpret_cast<f16x4*>(p.raw16 + o) = r;
+    float4 s4[GN_MAXQ], b4[GN_MAXQ];
+    const float* base[GN_MAXQ];
+    long ld[GN_MAXQ];
+#pragma unroll
+    for (int i = 0; i < GN_MAXQ; ++i) {
+        base[i] = nullptr; ld[i] = 0;
+        s4[i] = b4[i] = make_float4(0, 0, 0, 0);
+        const int q = m.q0 + i * 256;
+        if (i < m.NQ && q < Q) {
+            const int c = 4 * q;
+            s4[i] = *reinterpret_cast<const float4*>(sc + c);
+            b4[i] = *reinterpret_cast<const float4*>(sh + c);
+            base[i] = gn_src(p, img, 0, c);
+            ld[i] = c < p.C1 ? p.ld1 : p.ld2;
+        }
+    }
+    if (!m.active) return;
+    for (int pix = pix0 + m.pl; pix < pix1; pix += 4 * m.PL) {
+#pragma unroll
+        for (int i = 0; i < GN_MAXQ; ++i) {
+            if (base[i]) {
+                float4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = pix + u * m.PL;
+                    vv[u] = px < pix1 ? *reinterpret_cast<const float4*>(base[i] + (long)px * ld[i]) : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = pix + u * m.PL;
+                    if (px >= pix1) continue;
+                    const float4 v = vv[u];
+                    float y0 = v.x * s4[i].x + b4[i].x, y1 = v.y * s4[i].y + b4[i].y, y2 = v.z * s4[i].z + b4[i].z, y3 = v.w * s4[i].w + b4[i].w;
+                    if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+                    const long o = ((long)img * p.HW + px) * p.C + 4 * (m.q0 + i * 256);
+                    f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+                    *reinterpret_cast<f16x4*>(p.y16 + o) = h;
+                    if (p.raw16) {
+                        f16x4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                        *reinterpret_cast<f16x4*>(p.raw16 + o) = r;
+                    }
+                }
+            }
         }
     }
 }
@@ -242,7 +302,7 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
     if (a->n_grp <= 0 || a->n_grp > GN_MAXG || C % a->n_grp) return mlsd_set_error(-1, "mlsd_groupnorm: bad group count %d for C=%d", a->n_grp, C);
     const int cg = C / a->n_grp;
     if ((cg & 1) || (a->C1 & 3) || (a->C2 & 3)) return mlsd_set_error(-1, "mlsd_groupnorm: need even channels/group and C1,C2 %% 4 == 0 (C1=%d C2=%d cg=%d)", a->C1, a->C2, cg);
-    if (C > 2 * 256 * GN_MAXPP) return mlsd_set_error(-1, "mlsd_groupnorm: C=%d too large", C);
+    if (C > 4 * 256 * GN_MAXQ) return mlsd_set_error(-1, "mlsd_groupnorm: C=%d too large", C);
     if ((a->ld1 & 3) || (a->C2 && (a->ld2 & 3))) return mlsd_set_error(-1, "mlsd_groupnorm: strides must be multiples of 4");
     if (!a->ws || !a->y16) return mlsd_set_error(-1, "mlsd_groupnorm: null workspace/output");
     GnP p;
