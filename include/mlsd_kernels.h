@@ -95,6 +95,13 @@ typedef struct mlsd_gemm_args {
 	const float* bias_m;    /* [M] per-row bias (operands swapped: V^T = Wv . x^T in the VAE attention) or NULL */
 	int act_after_resid;    /* 1: activation applied after the residual add (TAESD block: relu(conv + x), src/tae.c:36-37) */
 	int tile_variant;       /* 0 = automatic choice; k+1 = use tile variant k (set by the plan's autotuner) */
+	/* split-K (small-M, long-K problems that cannot fill 256 CUs with output tiles: the SD1.5 batch-1 convs):
+	 * ksplit > 1 slices K over gridDim.y, each slice writes fp32 partial sums to ws, a second kernel sums the
+	 * slices in fixed order and applies the epilogue.  Ignored (no split) for GEGLU, when ws is NULL, or when
+	 * N / the output strides are not multiples of 4. */
+	int ksplit;
+	void* ws;               /* >= mlsd_gemm_splitk_ws_bytes(M, N, ksplit) bytes, 16-byte aligned */
+	size_t ws_bytes;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -107,6 +114,9 @@ void mlsd_gemm_set_mode(int mode);
 void mlsd_gemm_force_variant(int v);
 int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
+/* timing-only builds of the main loop (needs -DMLSD_GEMM_EXPERIMENTS; otherwise ignored) */
+void mlsd_gemm_set_debug(int d);
+size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit);
 
 /* ---------------------------------------------------------------- fused attention
  * Replaces ggml_nn_attention (src/ggml_extend.c:200-222: mul_mat, scale, [diag_mask_inf], soft_max,

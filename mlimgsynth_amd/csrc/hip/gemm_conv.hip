@@ -27,6 +27,8 @@
 //     bias, per-image row bias (time embedding), activation, GEGLU gating, fp32 residual and the
 //     fp32 / fp16 stores are 16-byte / 8-byte accesses.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
 #include "common.hpp"
 #include "mlsd_kernels.h"
 
@@ -56,6 +58,10 @@ struct GemmP {
     int nbm, nbn;
     int vec;   // 1: every row stride and N are multiples of 4 -> wide (LDS-transposed) epilogue
     int dbg;   // diagnostics (timing-only builds of the loop): bit0 = no refills in the loop, bit1 = no MFMA/ds_read
+    // split-K: blockIdx.y = slice z owns K tiles [z*kt_per, (z+1)*kt_per) and writes its raw fp32 partial sums to
+    // C32 + z*ws_stride (the epilogue fields are cleared by the launcher; splitk_reduce applies them)
+    int kt_per;
+    long ws_stride;
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -115,7 +121,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // same for all of a thread's rows (they are ROWS_PER_IT, a multiple of 16, apart).
     const int sr = tid / CPR;
     const int sc = REG ? (tid % CPR) : ((tid % CPR) ^ row_swz<BK>(sr));   // REG: swizzle applied on the ds_write instead
-    int g_kh = 0, g_kw = 0, g_cin = sc * 8;       // conv: position of this thread's chunk in (kh, kw, cin)
+    const int nkt_all = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * p.kt_per;        // split-K slice (kt_per == nkt_all, gridDim.y == 1 when not split)
+    const int nkt = min(p.kt_per, nkt_all - kt0);
+    int g_kh = 0, g_kw = 0, g_cin = kt0 * BK + sc * 8;   // conv: position of this thread's chunk in (kh, kw, cin)
     int row_pix[A_IT], row_ih0[A_IT], row_iw0[A_IT];
     bool row_ok[A_IT];
     if (CONV) {
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 
     // issue the LDS-DMA of K tile kt into ring slot `slot` (exactly LPT instructions per thread, always)
     auto stage_tile = [&](int kt, int slot) {
-        const int k = kt * BK + sc * 8;
+        const int k = (kt0 + kt) * BK + sc * 8;
         unsigned char* As = smem + slot * STAGE_BYTES;
         unsigned char* Bs = As + BM * RB;
 #pragma unroll
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // kernel runs at exactly that rate); ordinary loads return at the L1 rate and the ds_write costs ~13 cycles.
     uint4 ra[A_IT], rb[B_IT];
     auto load_tile_reg = [&](int kt) {
-        const int k = kt * BK + sc * 8;
+        const int k = (kt0 + kt) * BK + sc * 8;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -228,7 +237,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nkt = (p.K + BK - 1) / BK;
     if constexpr (REG) {
         load_tile_reg(0);
         store_tile_reg(0);
@@ -288,6 +296,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
+    float* const C32 = p.C32 ? p.C32 + (long)blockIdx.y * p.ws_stride : nullptr;
     if constexpr (WN == 64) {
         if (p.vec) {
             // Wide epilogue: each wave transposes its 32x64 fp32 slab through a private 8 KiB LDS region (the
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         default: break;
                         }
                         if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
-                        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = v;
+                        if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + n) = v;
                         if (p.C16) {
                             f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                             *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             const float4 rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + no);
                             v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
                         }
-                        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + no) = v;
+                        if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + no) = v;
                         if (p.C16) {
                             f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                             *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + no) = h;
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     default: break;
                     }
                     if (!p.act_post && p.resid) v += p.resid[(long)m * p.ldr + n];
-                    if (p.C32) p.C32[(long)m * p.ldc32 + n] = v;
+                    if (C32) C32[(long)m * p.ldc32 + n] = v;
                     if (p.C16) p.C16[(long)m * p.ldc16 + n] = (_Float16)v;
                 }
             } else {
@@ -411,13 +420,62 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         v = v * gelu_tanh_f(g);
                         const int no = ((n0 + wn * WN + j * 32) >> 6) * 32 + lr;
                         if (p.resid) v += p.resid[(long)m * p.ldr + no];
-                        if (p.C32) p.C32[(long)m * p.ldc32 + no] = v;
+                        if (C32) C32[(long)m * p.ldc32 + no] = v;
                         if (p.C16) p.C16[(long)m * p.ldc16 + no] = (_Float16)v;
                     }
                 }
             }
         }
     }
+}
+
+// ---- split-K second pass: sum the slices in fixed order (deterministic), then the same epilogue as above.
+// One thread per 4 consecutive columns; only launched when the wide-epilogue alignment conditions hold.
+__global__ __launch_bounds__(256) void splitk_reduce(const GemmP p, const float* __restrict__ ws, int nsplit)
+{
+    const int n4 = p.N >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(ws + (long)m * p.N + n);
+    for (int z = 1; z < nsplit; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + z * p.ws_stride + (long)m * p.N + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+    if (p.rowbias) {
+        const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    float4 rs = make_float4(0, 0, 0, 0);
+    if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+    if (p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+    switch (p.act) {
+    case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
+    case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
+    case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
+    case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
+    default: break;
+    }
+    if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+    if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = v;
+    if (p.C16) {
+        f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
+    }
+}
+
+// number of K slices mlsd_gemm will actually use for these args (1 = no split)
+int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
+{
+    const int nkt = (a->K + BK - 1) / BK;
+    int s = a->ksplit;
+    if (s <= 1 || a->act == MLSD_ACT_GEGLU || !a->ws) { if (kt_per_out) *kt_per_out = nkt; return 1; }
+    if (s > nkt) s = nkt;
+    const int per = (nkt + s - 1) / s;
+    if (kt_per_out) *kt_per_out = per;
+    return (nkt + per - 1) / per;
 }
 
 int g_gemm_dbg = 0;
@@ -442,14 +500,31 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
     p.dbg = g_gemm_dbg;
+    int kt_per;
+    const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
+    p.kt_per = nsplit > 1 ? kt_per : (a->K + BK - 1) / BK;
+    p.ws_stride = 0;
+    GemmP pe = p;                                  // the epilogue as requested (second pass of a split-K launch)
+    if (nsplit > 1) {
+        const size_t need = (size_t)nsplit * a->M * a->N * sizeof(float);
+        if (a->ws_bytes < need || ((uintptr_t)a->ws & 15))
+            return mlsd_set_error(-1, "mlsd_gemm: split-K workspace too small or misaligned (%zu < %zu)", (size_t)a->ws_bytes, need);
+        p.bias = p.biasm = p.rowbias = p.resid = nullptr; p.act = 0; p.act_post = 0;
+        p.C16 = nullptr; p.C32 = (float*)a->ws; p.ldc32 = a->N; p.ws_stride = (long)a->M * a->N;
+        pe.ws_stride = p.ws_stride;
+    }
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr size_t RING = (size_t)NSTAGE * (BM + BN) * BK * 2;
     constexpr size_t EPI = (size_t)WAVES_M * WAVES_N * 32 * 64 * 4;      // 8 KiB per wave
     constexpr size_t LDS = RING > EPI ? RING : EPI;
-    const dim3 grid(p.nbm * p.nbn), block(THREADS);
+    const dim3 grid(p.nbm * p.nbn, nsplit), block(THREADS);
     auto go = [&](auto kfn) -> int {
         if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+        if (nsplit > 1) {
+            const long n = (long)a->M * (a->N >> 2);
+            hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
+        }
         return mlsd_check_launch("gemm_kernel");
     };
 #ifdef MLSD_GEMM_EXPERIMENTS   /* timing-only builds of the loop: no refills (1) / no MFMA (2); see DESIGN.md */
@@ -547,10 +622,16 @@ MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
 
 MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 
+MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
+
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[pick_variant(a)].name, a->conv ? "conv" : "linear");
+    const int v = pick_variant(a);
+    const int bk = strstr(kVariants[v].name, "x32") ? 32 : 64;
+    const int ns = splitk_slices(a, bk, nullptr);
+    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
+    else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;
 }
 

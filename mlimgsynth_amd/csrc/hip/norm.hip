@@ -133,13 +133,26 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C]
     __shared__ float g_mean[GN_MAXG], g_rstd[GN_MAXG];
+    __shared__ double r1[8][GN_MAXG], r2[8][GN_MAXG];
     float* sc = sm;
     float* sh = sm + p.C;
     const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    {
+        // partial sums of the image's chunks: 8 stripes of chunks per group in parallel, then a fixed-order
+        // combine (deterministic; a serial walk over up to 256 chunks was most of this kernel at batch 1)
+        const int g = tid & 31, st = tid >> 5;
+        double t1 = 0, t2 = 0;
+        if (g < p.G) {
+            const float* w = p.ws + ((long)img * p.nchunk * p.G + g) * 2;
+            for (int c = st; c < p.nchunk; c += 8) { t1 += w[(long)c * p.G * 2]; t2 += w[(long)c * p.G * 2 + 1]; }
+        }
+        r1[st][g] = t1; r2[st][g] = t2;
+    }
+    __syncthreads();
     if (tid < p.G) {
         double t1 = 0, t2 = 0;
-        const float* w = p.ws + ((long)img * p.nchunk * p.G + tid) * 2;
-        for (int c = 0; c < p.nchunk; ++c) { t1 += w[(long)c * p.G * 2]; t2 += w[(long)c * p.G * 2 + 1]; }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) { t1 += r1[st][tid]; t2 += r2[st][tid]; }
         const double cnt = (double)p.cg * p.HW;
         const double K = *gn_src(p, img, 0, tid * p.cg);
         const double mu = t1 / cnt;
@@ -207,10 +220,14 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
     }
 }
 
-int gn_chunks(int HW)
+// pixel chunks per image: >= 16 pixels each, and enough blocks (n_img * chunks ~ 1024) to occupy 256 CUs at batch 1
+int gn_chunks(int HW, int n_img)
 {
+    int cap = 1024 / (n_img > 0 ? n_img : 1);
+    if (cap < 64) cap = 64;
+    if (cap > 256) cap = 256;
     int c = HW / 16;
-    if (c > 64) c = 64;
+    if (c > cap) c = cap;
     if (c < 1) c = 1;
     return c;
 }
@@ -293,7 +310,7 @@ extern "C" {
 
 MLSD_API size_t mlsd_groupnorm_ws_bytes(int n_img, int HW, int n_grp)
 {
-    return (size_t)n_img * gn_chunks(HW) * n_grp * 2 * sizeof(float);
+    return (size_t)n_img * gn_chunks(HW, n_img) * n_grp * 2 * sizeof(float);
 }
 
 MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
@@ -309,7 +326,7 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
     p.x1 = a->x1; p.x2 = a->x2; p.ld1 = a->ld1; p.ld2 = a->ld2; p.C1 = a->C1; p.C2 = a->C2; p.C = C;
     p.HW = a->HW; p.G = a->n_grp; p.cg = cg; p.eps = a->eps; p.gamma = a->gamma; p.beta = a->beta; p.silu = a->silu;
     p.y16 = (_Float16*)a->y16; p.raw16 = (_Float16*)a->raw16; p.ws = (float*)a->ws;
-    p.nchunk = gn_chunks(a->HW);
+    p.nchunk = gn_chunks(a->HW, a->n_img);
     p.pix_per_chunk = (a->HW + p.nchunk - 1) / p.nchunk;
     p.nchunk = (a->HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
     const dim3 grid(p.nchunk, a->n_img);

@@ -56,6 +56,7 @@ static void ctx_reset(MLCtx* C)
 	C->n_params = 0;
 	C->n_ops = 0;
 	for (int i=0;i<C->n_chunks;++i) mlsd_free(C->chunks[i]);
+	if (C->splitk_ws) { mlsd_free(C->splitk_ws); C->splitk_ws = NULL; C->splitk_ws_bytes = 0; }
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0;
@@ -420,45 +421,91 @@ static int run_op(MLCtx* C, MLOp* op)
  * the 256 CUs and on the reduction length, so every distinct GEMM/conv shape of a plan is timed once per
  * candidate variant (HIP events on the plan's stream, min of 3) and the winner is stored in the op.  Results
  * are cached process-wide by shape.  Outputs written during tuning are overwritten by the first real run. */
-typedef struct { int conv, M, N, K, act, OH, stride, ups, out; int best; } TuneKey;
+typedef struct { int conv, M, N, K, act, OH, stride, ups, out; int best, ksplit; } TuneKey;
 static TuneKey g_tune[512];
 static int g_ntune = 0;
 static int g_autotune = 1;
 
 MLB_API void mlctx_set_autotune(int on) { g_autotune = on; }
 
+#define SPLITK_WS_BYTES ((size_t)128 << 20)
+
+static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
+{
+	if (!C->splitk_ws) {
+		if (mlsd_malloc(&C->splitk_ws, SPLITK_WS_BYTES)) return -1;
+		C->splitk_ws_bytes = SPLITK_WS_BYTES;
+		C->mem_compute += SPLITK_WS_BYTES;
+	}
+	g->ws = C->splitk_ws; g->ws_bytes = C->splitk_ws_bytes;
+	return 0;
+}
+
+static int time_gemm(MLCtx* C, mlsd_gemm_args* g, void* e0, void* e1, float* ms_out)
+{
+	if (mlsd_gemm(g, C->stream)) return -1;   /* warm-up */
+	float mn = 1e30f;
+	for (int r=0;r<3;++r) {
+		mlsd_event_record(e0, C->stream);
+		if (mlsd_gemm(g, C->stream)) return -1;
+		mlsd_event_record(e1, C->stream);
+		mlsd_event_sync(e1);
+		float ms = 0; mlsd_event_elapsed_ms(e0, e1, &ms);
+		if (ms < mn) mn = ms;
+	}
+	*ms_out = mn;
+	return 0;
+}
+
 static int tune_gemm(MLCtx* C, MLOp* op)
 {
 	mlsd_gemm_args *g = &op->u.gemm;
-	TuneKey k = { g->conv, g->M, g->N, g->K, g->act, g->OH, g->stride, g->upsample, (g->C32 ? 1 : 0) | (g->C16 ? 2 : 0) | (g->resid ? 4 : 0), 0 };
+	TuneKey k = { g->conv, g->M, g->N, g->K, g->act, g->OH, g->stride, g->upsample, (g->C32 ? 1 : 0) | (g->C16 ? 2 : 0) | (g->resid ? 4 : 0), 0, 0 };
 	for (int i=0;i<g_ntune;++i) {
 		TuneKey *t = &g_tune[i];
 		if (t->conv==k.conv && t->M==k.M && t->N==k.N && t->K==k.K && t->act==k.act && t->OH==k.OH && t->stride==k.stride &&
-		    t->ups==k.ups && t->out==k.out) { g->tile_variant = t->best; return 1; }
+		    t->ups==k.ups && t->out==k.out) {
+			g->tile_variant = t->best; g->ksplit = t->ksplit;
+			if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+			return 1;
+		}
 	}
-	static const int cand_big[] = {0, 3, 4, 9}, cand_small[] = {1, 0};
-	const int *cand = g->M <= 64 ? cand_small : cand_big;
-	const int ncand = g->M <= 64 ? 2 : 4;
+	/* candidates: (tile variant, K slices) */
+	int cv[16], cs[16], nc = 0;
+	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
+	else { cv[nc]=0; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=9; cs[nc++]=1; }
+	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
+	if (g->M > 64 && t128 < 512) { cv[nc]=1; cs[nc++]=1; }   /* short problems: more, smaller blocks hide the fill latency */
+	/* split-K: output tiles alone cannot occupy the 256 CUs (2 resident blocks each) and K is long enough to slice */
+	const int nkt = (g->K + 63) / 64;
+	if (t128 <= 192 && nkt >= 8 && g->act != MLSD_ACT_GEGLU && !(g->N & 3)) {
+		static const int targets[] = {256, 512, 1024};
+		for (int vi=0; vi<2; ++vi) {
+			const int v = vi ? 1 : 0;                       /* 128x128 and 64x128 tiles */
+			if (v == 1 && g->M > 512) continue;
+			const long tiles = (long)((g->M + (v ? 63 : 127)) / (v ? 64 : 128)) * ((g->N + 127) / 128);
+			int last = 1;
+			for (int ti=0; ti<3; ++ti) {
+				int s = (int)((targets[ti] + tiles / 2) / tiles);
+				if (s > nkt / 2) s = nkt / 2;               /* >= 2 K tiles per slice */
+				while (s > 1 && (size_t)s * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) --s;
+				if (s <= last || nc >= 16) continue;
+				cv[nc] = v; cs[nc++] = s; last = s;
+			}
+		}
+	}
 	void *e0 = NULL, *e1 = NULL;
 	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
-	float best_ms = 1e30f; int best = 0;
-	for (int c=0;c<ncand;++c) {
-		g->tile_variant = cand[c] + 1;
-		if (mlsd_gemm(g, C->stream)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }   /* warm-up */
-		float mn = 1e30f;
-		for (int r=0;r<3;++r) {
-			mlsd_event_record(e0, C->stream);
-			if (mlsd_gemm(g, C->stream)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
-			mlsd_event_record(e1, C->stream);
-			mlsd_event_sync(e1);
-			float ms = 0; mlsd_event_elapsed_ms(e0, e1, &ms);
-			if (ms < mn) mn = ms;
-		}
-		if (mn < best_ms) { best_ms = mn; best = cand[c] + 1; }
+	float best_ms = 1e30f; int best = 0, best_s = 1;
+	for (int c=0;c<nc;++c) {
+		g->tile_variant = cv[c] + 1; g->ksplit = cs[c];
+		float ms;
+		if ((cs[c] > 1 && splitk_ws_get(C, g)) || time_gemm(C, g, e0, e1, &ms)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
+		if (ms < best_ms) { best_ms = ms; best = cv[c] + 1; best_s = cs[c]; }
 	}
 	mlsd_event_destroy(e0); mlsd_event_destroy(e1);
-	g->tile_variant = best;
-	k.best = best;
+	g->tile_variant = best; g->ksplit = best_s;
+	k.best = best; k.ksplit = best_s;
 	if (g_ntune < 512) g_tune[g_ntune++] = k;
 	return 1;
 }

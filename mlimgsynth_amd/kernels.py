@@ -15,7 +15,8 @@ class GemmArgs(ctypes.Structure):
                 ("pad", c_int), ("upsample", c_int), ("W_", vp), ("ldb", c_i64), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("bias", vp), ("rowbias", vp), ("rows_per_batch", c_int), ("ldrb", c_i64),
                 ("resid", vp), ("ldr", c_i64), ("act", c_int), ("C32", vp), ("ldc32", c_i64), ("C16", vp),
-                ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int), ("tile_variant", c_int)]
+                ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int), ("tile_variant", c_int),
+                ("ksplit", c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -32,6 +33,18 @@ class GnArgs(ctypes.Structure):
 
 def gemm(args, stream=None):
     check(lib().mlsd_gemm(ctypes.byref(args), vp(stream)), "mlsd_gemm")
+
+
+def gemm_splitk_ws_bytes(m, n, ksplit):
+    f = lib().mlsd_gemm_splitk_ws_bytes
+    f.restype = ctypes.c_size_t
+    return f(m, n, ksplit)
+
+
+def gemm_variant(args):
+    f = lib().mlsd_gemm_variant
+    f.restype = ctypes.c_char_p
+    return f(ctypes.byref(args)).decode()
 
 
 def attention(args, stream=None):

@@ -153,6 +153,73 @@ def test_gemm_rejects_bad_args(K):
         kernels.gemm(a)
 
 
+@pytest.mark.parametrize("M,N,Kd,ksplit,variant,act,post", [
+    (128, 1280, 2304, 6, 0, 0, 0), (100, 256, 1096, 5, 2, 1, 0), (2, 1280, 1280, 4, 2, 1, 0), (512, 320, 640, 10, 1, 4, 1),
+    (130, 132, 72, 64, 0, 2, 0)])
+def test_gemm_split_k(K, M, N, Kd, ksplit, variant, act, post):
+    """K sliced over gridDim.y + fixed-order reduce: same result as the oracle linear (and as the unsplit kernel
+    up to fp32 summation order), every epilogue term applied exactly once by the second pass."""
+    kernels, _lib = K
+    rng = np.random.default_rng(M + N + Kd)
+    A = f16r(rng.standard_normal((M, Kd)))
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    P = O.Params()
+    y = O.from_ot(O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias))).reshape(M, N)
+    actf = {0: lambda v: v, 1: lambda v: v / (1 + np.exp(-v)), 4: lambda v: np.maximum(v, 0),
+            2: lambda v: 0.5 * v * (1 + np.tanh(0.7978845608028654 * v * (1 + 0.044715 * v * v)))}[act]
+    ref = actf(y + res) if post else actf(y) + res
+    dA, dW, dB, dR = dev(_lib, A.astype(np.float16)), dev(_lib, W.astype(np.float16)), dev(_lib, bias), dev(_lib, res)
+    dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
+    assert nws == ksplit * M * N * 4
+    ws = _lib.DeviceBuffer(nws)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, resid=dR.ptr, ldr=N,
+                         act=act, act_after_resid=post, C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N,
+                         tile_variant=variant, ksplit=ksplit, ws=ws.ptr, ws_bytes=nws)
+    if ksplit > 1 and min(ksplit, (Kd + 63) // 64) > 1:
+        assert "k/" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    c32 = dC32.download((M, N), np.float32)
+    assert rel(c32, ref) < 2e-5
+    assert rel(dC16.download((M, N), np.float16).astype(np.float32), ref) < 1e-3
+    a.ksplit = 0
+    kernels.gemm(a)
+    assert rel(dC32.download((M, N), np.float32), c32) < 2e-6
+    # a workspace that is too small is an error, never a silent unsplit run
+    a.ksplit, a.ws_bytes = ksplit, 16
+    if min(ksplit, (Kd + 63) // 64) > 1:
+        with pytest.raises(_lib.MlsdError):
+            kernels.gemm(a)
+
+
+def test_conv2d_split_k(K):
+    """3x3 implicit-GEMM conv at the SD1.5 8x8-latent shape class (M=128, long K): slices start mid-(kh,kw)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(11)
+    n, h, w, cin, cout = 2, 8, 8, 200, 64
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    P = O.Params()
+    ref = np.stack([O.from_ot(O.L().orc_conv2d(O.to_ot(x[i][None]), P.set("w", wt, f16=True), P.set("b", bias), 1, 1))[0]
+                    for i in range(n)])
+    x_nhwc = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16)
+    dX, dW, dB = dev(_lib, x_nhwc), dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias)
+    M, Kd = n * h * w, 9 * cin
+    for ksplit in (3, 7, 14):
+        dC = _lib.DeviceBuffer(M * cout * 4)
+        nws = kernels.gemm_splitk_ws_bytes(M, cout, ksplit)
+        ws = _lib.DeviceBuffer(nws)
+        a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=h, OW=w, KH=3, KW=3, stride=1, pad=1,
+                             W_=dW.ptr, ldb=Kd, M=M, N=cout, K=Kd, bias=dB.ptr, C32=dC.ptr, ldc32=cout, ksplit=ksplit,
+                             ws=ws.ptr, ws_bytes=nws)
+        kernels.gemm(a)
+        got = dC.download((n, h, w, cout), np.float32).transpose(0, 3, 1, 2)
+        assert rel(got, ref) < 2e-5, ksplit
+
+
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("nb,heads,dh,tq,tk,causal", [
     (1, 2, 64, 256, 256, 0), (2, 3, 64, 100, 77, 0), (1, 4, 64, 77, 77, 1), (1, 2, 40, 200, 200, 0),
