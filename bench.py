@@ -16,6 +16,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -23,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_GBS = 8000.0              # HBM3E (MI355X_MICROARCH.md: ~8 TB/s)
 
 WORKLOADS = {
     # name: (model, width, height, default batch per GPU)
@@ -159,24 +161,45 @@ def main():
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the engine's stream, one UNet evaluation
     uc = g.unet_ctx()
     ops = uc.op_list()
+    nbytes = uc.op_bytes()
     ms = uc.profile_ops()
     agg = {}
-    for (lab, fl), t in zip(ops, ms):
-        e = agg.setdefault(lab, [0, 0.0, 0.0])
-        e[0] += 1; e[1] += float(t); e[2] += fl
+    for (lab, fl), t, nb in zip(ops, ms, nbytes):
+        lab = re.sub(r",k/\d+>", ">", lab)       # split-K launches run the same kernel instantiation
+        e = agg.setdefault(lab, [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += float(t); e[2] += fl; e[3] += nb
     dom = max(agg.items(), key=lambda kv: kv[1][1])
-    lab, (cnt, tms, fl) = dom
-    achieved = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
-    out["roofline"] = {"bound": "mfma", "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
-                       "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": None,
+    lab, (cnt, tms, fl, nb) = dom
+    tflops = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+    gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+    # the bound is the roof the kernel is closer to (GEMM/attention: MFMA; norms and short split-K GEMMs: HBM)
+    if tflops / PEAK_MFMA_F16_TFLOPS >= gbs / PEAK_HBM_GBS:
+        roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / PEAK_MFMA_F16_TFLOPS, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    # HBM-side traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", f"r1_{a.workload}_b{B}_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as fh:
+                k = json.load(fh)["kernels"].get(lab)
+            if k:
+                traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
+        except Exception:
+            pass
+    out["roofline"] = {**roof, "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
+                       "algorithmic_gb_per_eval": round(nb / 1e9, 3), "algorithmic_tflop_per_eval": round(fl / 1e12, 3),
+                       "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src,
                        "share_of_eval_time": round(tms / float(ms.sum()), 3)}
     if a.kernel_table:
         with open(a.kernel_table, "w") as f:
             f.write(f"# one UNet evaluation, {a.workload} batch {B} (N={2 * B if a.cfg > 1 else B}); per-launch HIP events\n")
-            f.write(f"# {'kernel':44s} {'launches':>8s} {'total_ms':>10s} {'TFLOP':>9s} {'TFLOP/s':>9s}\n")
-            for k, (c, t, fl_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{k:46s} {c:8d} {t:10.3f} {fl_ / 1e12:9.3f} {fl_ / max(t, 1e-9) / 1e9:9.1f}\n")
+            f.write(f"# {'kernel':44s} {'launches':>8s} {'total_ms':>10s} {'TFLOP':>9s} {'TFLOP/s':>9s} {'alg_GB':>9s} {'GB/s':>9s}\n")
+            for k, (c, t, fl_, nb_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{k:46s} {c:8d} {t:10.3f} {fl_ / 1e12:9.3f} {fl_ / max(t, 1e-9) / 1e9:9.1f} {nb_ / 1e9:9.3f} {nb_ / max(t, 1e-9) / 1e6:9.1f}\n")
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded sample
     if world == 1 and not a.no_cpu_baseline:

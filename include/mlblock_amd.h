@@ -92,6 +92,8 @@ typedef struct MLCtxInfo {
 void mlctx_info(const MLCtx* C, MLCtxInfo* out);
 /* per-op listing for profiling: returns kernel label, flops of op i */
 int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flops);
+/* algorithmic HBM bytes of op i (operands read once, outputs written once) */
+double mlctx_op_bytes(const MLCtx* C, int i);
 /* time every op individually with HIP events (diagnostics; synchronises) */
 int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out);
 

@@ -107,8 +107,7 @@ typedef struct mlsd_gemm_args {
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
-/* staging mode of the A/B tiles: 0 = direct global->LDS (global_load_lds_dwordx4, default), 1 = through registers
- * (kept for in-process A/B timing) */
+/* tile order inside an XCD's range: column panels `mode` tiles wide (default 8; 0 = row-major).  A/B timing knob. */
 void mlsd_gemm_set_mode(int mode);
 /* diagnostics: force a tile variant (-1 = automatic choice) / the scalar epilogue (1) instead of the wide one (0) */
 void mlsd_gemm_force_variant(int v);

@@ -62,6 +62,7 @@ struct GemmP {
     // C32 + z*ws_stride (the epilogue fields are cleared by the launcher; splitk_reduce applies them)
     int kt_per;
     long ws_stride;
+    int gw;    // tile-order panel width (0: row-major)
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -109,7 +110,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    // Tile order inside the XCD's contiguous range: column panels of p.gw tiles, rows fastest inside a panel,
+    // so the ~32 blocks an XCD runs concurrently cover a (32/gw) x gw patch: per K step the XCD's L2 takes
+    // 32/gw + gw distinct operand tiles instead of 1 + 32 (row-major order on a wide output).
+    int bm, bn;
+    if (p.gw > 0 && p.nbn > p.gw) {
+        const int per_panel = p.gw * p.nbm;
+        const int panel = bid / per_panel;
+        const int first = panel * p.gw;
+        const int w = min(p.gw, p.nbn - first);
+        const int r = bid - panel * per_panel;
+        bm = r / w; bn = first + (r - bm * w);
+    } else {
+        bm = bid / p.nbn; bn = bid - bm * p.nbn;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,6 +493,7 @@ int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
 }
 
 int g_gemm_dbg = 0;
+int g_gemm_panel = 8;   // tile-order panel width in tiles (0: row-major)
 int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, bool REG = false>
@@ -500,6 +515,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
     p.dbg = g_gemm_dbg;
+    p.gw = g_gemm_panel;
     int kt_per;
     const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
     p.kt_per = nsplit > 1 ? kt_per : (a->K + BK - 1) / BK;
@@ -615,7 +631,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     }
 }
 
-MLSD_API void mlsd_gemm_set_mode(int mode) { (void)mode; }   /* kept for ABI stability: staging is always direct-to-LDS */
+MLSD_API void mlsd_gemm_set_mode(int mode) { g_gemm_panel = mode < 0 ? 0 : mode; }   /* tile-order panel width (A/B timing) */
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }

@@ -473,7 +473,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	/* candidates: (tile variant, K slices) */
 	int cv[16], cs[16], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
-	else { cv[nc]=0; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=9; cs[nc++]=1; }
+	else { cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
 	if (g->M > 64 && t128 < 512) { cv[nc]=1; cs[nc++]=1; }   /* short problems: more, smaller blocks hide the fill latency */
 	/* split-K: output tiles alone cannot occupy the 256 CUs (2 resident blocks each) and K is long enough to slice */
@@ -501,7 +501,9 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		g->tile_variant = cv[c] + 1; g->ksplit = cs[c];
 		float ms;
 		if ((cs[c] > 1 && splitk_ws_get(C, g)) || time_gemm(C, g, e0, e1, &ms)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
-		if (ms < best_ms) { best_ms = ms; best = cv[c] + 1; best_s = cs[c]; }
+		/* candidates are listed in order of preference: a later one must win by 3 % (keeps the choice, and with
+		 * it the kernel mix of a profile, stable against timing noise between near-equal variants) */
+		if (ms < (c ? 0.97f : 1.f) * best_ms) { best_ms = ms; best = cv[c] + 1; best_s = cs[c]; }
 	}
 	mlsd_event_destroy(e0); mlsd_event_destroy(e1);
 	g->tile_variant = best; g->ksplit = best_s;
@@ -603,6 +605,42 @@ MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flo
 	}
 	if (flops) *flops = C->ops[i].flops;
 	return 1;
+}
+
+/* Algorithmic HBM bytes of op i: every operand read once, every output written once (DESIGN.md "roofline"). */
+MLB_API double mlctx_op_bytes(const MLCtx* C, int i)
+{
+	if (i < 0 || i >= C->n_ops) return 0;
+	const MLOp *op = &C->ops[i];
+	switch (op->kind) {
+	case OP_GEMM: {
+		const mlsd_gemm_args *g = &op->u.gemm;
+		const double nout = g->act == MLSD_ACT_GEGLU ? g->N / 2 : g->N;
+		double b = g->conv ? 2.0 * g->n_img * g->H * g->W * g->Cin : 2.0 * g->M * (double)g->K;
+		b += 2.0 * g->N * (double)g->K;
+		if (g->bias) b += 4.0 * g->N;
+		if (g->rowbias) b += 4.0 * (g->M / (g->rows_per_batch > 0 ? g->rows_per_batch : 1)) * (double)g->N;
+		if (g->resid) b += 4.0 * g->M * nout;
+		if (g->C32) b += 4.0 * g->M * nout;
+		if (g->C16) b += 2.0 * g->M * nout;
+		return b;
+	}
+	case OP_ATTN: {
+		const mlsd_attn_args *a = &op->u.attn;
+		const double D = (double)a->n_head * a->d_head;
+		return 2.0 * a->n_batch * D * (2.0 * a->Tq + 2.0 * a->Tk);
+	}
+	case OP_GN: {
+		const mlsd_gn_args *a = &op->u.gn;
+		const double n = (double)a->n_img * a->HW * (a->C1 + a->C2);
+		return n * (4.0 + 2.0 + (a->raw16 ? 2.0 : 0.0));
+	}
+	case OP_LN: return (double)op->u.ln.rows * op->u.ln.d * (4.0 + (op->u.ln.y16 ? 2.0 : 0.0) + (op->u.ln.y32 ? 4.0 : 0.0));
+	case OP_SOFTMAX: return (double)op->u.smax.rows * op->u.smax.cols * 6.0;
+	case OP_ACT: return (double)op->u.act.n * 6.0;
+	case OP_COPY_F32: return 2.0 * op->u.copy.nbytes;
+	default: return 0;
+	}
 }
 
 MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)

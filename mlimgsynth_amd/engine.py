@@ -66,6 +66,8 @@ def L():
         l.mlctx_info.argtypes = [vp, ctypes.POINTER(CtxInfo)]
         l.mlctx_op_info.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
         l.mlctx_profile_ops.argtypes = [vp, FP, c_int]
+        l.mlctx_op_bytes.argtypes = [vp, c_int]
+        l.mlctx_op_bytes.restype = ctypes.c_double
         l.mlctx_compute.argtypes = [vp]
         l.mlctx_sync.argtypes = [vp]
         l.unet_params_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(UnetParams)]
@@ -124,6 +126,11 @@ class MLCtx:
             L().mlctx_op_info(self.h, i, ctypes.byref(lab), ctypes.byref(fl))
             out.append((lab.value.decode(), fl.value))
         return out
+
+    def op_bytes(self):
+        f = L().mlctx_op_bytes
+        f.restype = ctypes.c_double
+        return [f(self.h, i) for i in range(self.info().n_ops)]
 
     def profile_ops(self):
         n = self.info().n_ops

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerate the committed profile summaries of one workload on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh <workload> <batch> <tag>      e.g.  tools/profile_round.sh sdxl 4 r1
+# Writes under gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
+set -u
+WL=${1:-sdxl}; B=${2:-4}; TAG=${3:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
+ARGS="--workload $WL --batch-per-gpu $B --steps 1 --warmup 1 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -- python3 $R/bench.py $ARGS > $OUT/kt_$WL.log 2>&1 < /dev/null
+for f in $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1); do cp $f $OUT/${TAG}_${WL}_b${B}_rocprofv3_kernel_stats.csv; done
+find $OUT/kt_$WL -name "*kernel_trace.csv" -delete
+# HBM-side counters: one pass each, with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# Target: tools/unet_eval.py = the same UNet plan (same shapes, same tuned kernels) evaluated 10x on the NULL stream;
+# rocprofv3's counter service segfaults at the first launch on the engine's own HIP stream when bench.py itself is
+# the target (ROCm 7.2), and bench.py's roofline is per launch of a UNet evaluation anyway.
+case $WL in sdxl) UARGS="sdxl 128 $((2*B)) 10";; sd15) UARGS="sd1 64 $((2*B)) 10";; *) UARGS="$WL 8 $((2*B)) 10";; esac
+if [ "${SKIP_KT:-0}" = "1" ]; then :; fi
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${C}_$WL -- python3 $R/tools/unet_eval.py $UARGS > $OUT/pmc_${C}_$WL.log 2>&1 < /dev/null
+done
+F=$(find $OUT/pmc_FETCH_SIZE_$WL -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE_$WL -name "*counter_collection.csv" | head -1)
+if [ -n "$F" ] && [ -n "$W" ]; then python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_b${B}_pmc_traffic.json "$F" "$W"; fi
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+cd $R
+timeout 600 python3 bench.py --workload $WL --batch-per-gpu $B --kernel-table $OUT/${TAG}_${WL}_b${B}_unet_eval_kernel_table.txt > $OUT/${TAG}_${WL}_b${B}_bench.json 2> $OUT/bench_$WL.log < /dev/null
+tail -1 $OUT/${TAG}_${WL}_b${B}_bench.json
