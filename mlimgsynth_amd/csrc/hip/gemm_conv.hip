@@ -261,6 +261,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             if (s < nkt) stage_tile(s, s);
     }
 
+    // Residual prefetch (tiles with register headroom: 128x320, 8 waves at <= 256 VGPRs): the fp32 residual tile is
+    // as many bytes as the tile's output and, loaded in the epilogue, is pure exposed latency for a short-K GEMM
+    // (every CU reaches its epilogue at the same time).  Issued here, right after the first K tile's staging loads,
+    // it lands under the main loop.  Layout = the wide epilogue's (lane owns 4 consecutive columns); addresses are
+    // clamped instead of predicated so that every wave issues exactly NPRE loads (the counted vmcnt below).
+    constexpr bool PRE = (BM == 128 && BN == 320) && !REG;
+    constexpr int NPRE = PRE ? TM * ((TN / 2) * 8 + (TN % 2) * 4) : 1;
+    float4 rpre[NPRE];
+    bool pre = false;
+    if constexpr (PRE) {
+        pre = p.resid && p.vec && p.act != MLSD_ACT_GEGLU;
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int jc = 0; jc < TN; jc += 2) {
+                    const bool pair = jc + 1 < TN;
+                    const int slab0 = i * ((TN / 2) * 8 + (TN % 2) * 4) + (jc / 2) * 8;
+                    const int c4 = pair ? (lane & 15) * 4 : (lane & 7) * 4;
+                    const int n = min(n0 + wn * WN + jc * 32 + c4, p.N - 4);
+#pragma unroll
+                    for (int it = 0; it < (pair ? 8 : 4); ++it) {
+                        const int row = pair ? it * 4 + (lane >> 4) : it * 8 + (lane >> 3);
+                        const int m = min(m0 + wm * WM + i * 32 + row, p.M - 1);
+                        rpre[slab0 + it] = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+                    }
+                }
+            }
+        }
+    }
+
     int slot = 0;                                  // ring slot of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (REG) {
@@ -269,7 +300,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         } else {
             // tiles kt+1 .. kt+NSTAGE-2 may stay in flight; tile kt must have landed
             const int ahead = min(NSTAGE - 2, nkt - 1 - kt);
-            if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+            if (PRE && NSTAGE == 2 && pre && kt == 0) wait_vmcnt<NPRE>();   // tile 0 landed; the residual prefetch may still fly
+            else if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
             else if (NSTAGE >= 3 && ahead == 1) wait_vmcnt<LPT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();          // raw barrier: no implicit vmcnt(0) drain
@@ -311,59 +343,87 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
     float* const C32 = p.C32 ? p.C32 + (long)blockIdx.y * p.ws_stride : nullptr;
-    if constexpr (WN == 64) {
-        if (p.vec) {
-            // Wide epilogue: each wave transposes its 32x64 fp32 slab through a private 8 KiB LDS region (the
-            // tile buffers are free after the main loop's last barrier) so that a lane owns 4 CONSECUTIVE
-            // columns: bias/residual loads and the stores are 16-byte (fp32) / 8-byte (fp16) accesses, 16 lanes
-            // cover 256 contiguous bytes of a row; 16 store instructions per slab instead of 64 scalar ones.
-            float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+    if (p.vec) {
+        // Wide epilogue: each wave transposes its accumulators, 32 rows x 64 (or a last 32) columns at a time,
+        // through a private 8 KiB LDS region (the tile buffers are free after the main loop's last barrier) so
+        // that a lane owns 4 CONSECUTIVE columns: bias/residual loads and the stores are 16-byte (fp32) / 8-byte
+        // (fp16) accesses, 16 lanes cover 256 contiguous bytes of a row; 16 store instructions per 32x64 slab
+        // instead of 64 scalar ones.
+        float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        // bias, row bias, residual, activation and both stores for 4 consecutive columns of row m
+        auto finish4 = [&](int m, int n, float4 v, const float4 bv, const float4 rs_pre, const bool have_pre) {
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+            if (p.rowbias) {
+                const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            float4 rs = make_float4(0, 0, 0, 0);
+            if (have_pre) rs = rs_pre;
+            else if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+            if (p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+            switch (p.act) {
+            case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
+            case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
+            case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
+            case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
+            default: break;
+            }
+            if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+            if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + n) = v;
+            if (p.C16) {
+                f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
+            }
+        };
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int jc = 0; jc < TN; jc += 2) {
+                const bool pair = jc + 1 < TN;             // 64-column slab, or the last 32 columns of an odd TN
+                const int cb = n0 + wn * WN + jc * 32;     // first column of the slab
+                const int SLAB0 = PRE ? i * ((TN / 2) * 8 + (TN % 2) * 4) + (jc / 2) * 8 : 0;   // this slab's first entry in rpre[]
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) {
+                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 64 + lr] = acc[i][jc][e];
+                    if (pair) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 64 + 32 + lr] = acc[i][pair ? jc + 1 : jc][e];
+                }
                 __builtin_amdgcn_wave_barrier();
-                if (!geglu) {
+                if (!geglu && pair) {
                     const int c4 = (lane & 15) * 4;
-                    const int n = n0 + wn * WN + c4;
+                    const int n = cb + c4;
                     float4 bv = make_float4(0, 0, 0, 0);
                     if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
                         const int row = it * 4 + (lane >> 4);
                         const int m = m0 + wm * WM + i * 32 + row;
-                        float4 v = *reinterpret_cast<const float4*>(stg + row * 64 + c4);
+                        const float4 v = *reinterpret_cast<const float4*>(stg + row * 64 + c4);
+                        float4 rp = make_float4(0, 0, 0, 0);
+                        if constexpr (PRE) rp = rpre[SLAB0 + it];
                         if (m >= p.M || n >= p.N) continue;
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
-                        if (p.rowbias) {
-                            const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                        }
-                        float4 rs = make_float4(0, 0, 0, 0);
-                        if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
-                        if (p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
-                        switch (p.act) {
-                        case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
-                        case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
-                        case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
-                        case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
-                        default: break;
-                        }
-                        if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
-                        if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + n) = v;
-                        if (p.C16) {
-                            f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                            *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
-                        }
+                        finish4(m, n, v, bv, rp, PRE && pre);
                     }
-                } else {
+                } else if (!geglu) {
+                    const int c4 = (lane & 7) * 4;
+                    const int n = cb + c4;
+                    float4 bv = make_float4(0, 0, 0, 0);
+                    if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 8 + (lane >> 3);
+                        const int m = m0 + wm * WM + i * 32 + row;
+                        const float4 v = *reinterpret_cast<const float4*>(stg + row * 64 + c4);
+                        float4 rp = make_float4(0, 0, 0, 0);
+                        if constexpr (PRE) rp = rpre[SLAB0 + it];
+                        if (m >= p.M || n >= p.N) continue;
+                        finish4(m, n, v, bv, rp, PRE && pre);
+                    }
+                } else if (pair) {
                     // slab columns 0..31 = value, 32..63 = gate (weight rows interleaved in blocks of 32)
                     const int c4 = (lane & 7) * 4;
-                    const int nv = n0 + wn * WN + c4, ng = nv + 32;
-                    const int no = ((n0 + wn * WN) >> 6) * 32 + c4;
+                    const int nv = cb + c4, ng = nv + 32;
+                    const int no = (cb >> 6) * 32 + c4;
                     float4 bvv = make_float4(0, 0, 0, 0), bgg = bvv;
                     if (p.bias && ng < p.N) { bvv = *reinterpret_cast<const float4*>(p.bias + nv); bgg = *reinterpret_cast<const float4*>(p.bias + ng); }
 #pragma unroll
@@ -391,8 +451,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            return;
         }
+        return;
     }
     // scalar fallback (N or a stride not a multiple of 4: 3-channel image outputs, padded 4-channel latents)
 #pragma unroll
@@ -570,6 +630,7 @@ const Variant kVariants[] = {
     {"256x256x64r2w16", 256, 256, 256}, // 13: as 9 but register-staged tiles (global_load -> ds_write)
     {"128x128x64r2", 128, 128, 512},    // 14: as 0 but register-staged
     {"256x128x64r2", 256, 128, 256},    // 15: as 3 but register-staged
+    {"128x320x64s2", 128, 320, 256},    // 16: 8 waves (4x2, wave tile 32x160): N = 1280 / 640 outputs in exactly 4 / 2 tile columns
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -614,6 +675,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 16:
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
 #ifdef MLSD_GEMM_EXPERIMENTS   /* variants that lost the tile study on MI355X (kept reproducible, not built by default) */
     case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
     case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
@@ -644,7 +708,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
     const int v = pick_variant(a);
-    const int bk = strstr(kVariants[v].name, "x32") ? 32 : 64;
+    const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = splitk_slices(a, bk, nullptr);
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");

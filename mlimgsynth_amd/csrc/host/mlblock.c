@@ -475,7 +475,10 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else { cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
-	if (g->M > 64 && t128 < 512) { cv[nc]=1; cs[nc++]=1; }   /* short problems: more, smaller blocks hide the fill latency */
+	if (g->M > 64 && t128 < 512) { cv[nc]=1; cs[nc++]=1; }
+	/* 128x320: outputs whose width is a multiple of 320 (N = 1280, 640) in whole tile columns, e.g. 8192x1280 =
+	 * 256 tiles = one per CU where 256x256 tiles give 160 */
+	if (g->M > 64 && g->N >= 320 && g->act != MLSD_ACT_GEGLU) { cv[nc]=16; cs[nc++]=1; }   /* short problems: more, smaller blocks hide the fill latency */
 	/* split-K: output tiles alone cannot occupy the 256 CUs (2 resident blocks each) and K is long enough to slice */
 	const int nkt = (g->K + 63) / 64;
 	if (t128 <= 192 && nkt >= 8 && g->act != MLSD_ACT_GEGLU && !(g->N & 3)) {
@@ -600,6 +603,10 @@ MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flo
 				size_t l = strlen(buf);
 				snprintf(buf + l, sizeof(buf) - l, "%dx%dx%d%s%s", g->M, g->N, g->K, g->C32 ? " f32" : "", g->resid ? "+res" : "");
 			}
+			*label = buf;
+		} else if (op->kind == OP_ATTN && (C->flags & MLB_F_OPSHAPES)) {
+			const mlsd_attn_args *a = &op->u.attn;
+			snprintf(buf, sizeof(buf), "%s b%d h%d d%d %dx%d", op->label, a->n_batch, a->n_head, a->d_head, a->Tq, a->Tk);
 			*label = buf;
 		} else *label = op->label;
 	}

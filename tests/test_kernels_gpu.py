@@ -153,6 +153,62 @@ def test_gemm_rejects_bad_args(K):
         kernels.gemm(a)
 
 
+BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16]   # kVariants[] indices instantiated by the default build (gemm_conv.hip)
+
+
+@pytest.mark.parametrize("variant", BUILT_TILE_VARIANTS)
+@pytest.mark.parametrize("M,N,Kd", [(300, 200, 136), (1000, 640, 320), (257, 1284, 72)])
+def test_gemm_every_tile_variant(K, variant, M, N, Kd):
+    """Each built tile (incl. the 128x320 one whose waves own an odd number of 32-column slabs) against the oracle
+    linear, with every epilogue term on; ragged M/N/K edges."""
+    kernels, _lib = K
+    rng = np.random.default_rng(variant * 31 + M)
+    A = f16r(rng.standard_normal((M, Kd)))
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    P = O.Params()
+    y = O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias))
+    O.L().orc_silu(y)
+    ref = O.from_ot(y).reshape(M, N) + res
+    dA, dW, dB, dR = dev(_lib, A.astype(np.float16)), dev(_lib, W.astype(np.float16)), dev(_lib, bias), dev(_lib, res)
+    dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, resid=dR.ptr, ldr=N, act=1,
+                         C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N, tile_variant=variant + 1)
+    kernels.gemm(a)
+    assert rel(dC32.download((M, N), np.float32), ref) < 2e-5
+    assert rel(dC16.download((M, N), np.float16).astype(np.float32), ref) < 1e-3
+
+
+@pytest.mark.parametrize("variant", BUILT_TILE_VARIANTS)
+def test_conv2d_every_tile_variant(K, variant):
+    kernels, _lib = K
+    rng = np.random.default_rng(variant)
+    n, h, w, cin, cout = 2, 12, 10, 40, 328
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    P = O.Params()
+    pw, pb = P.set("w", wt, f16=True), P.set("b", bias)
+    ref = np.stack([O.from_ot(O.L().orc_conv2d(O.to_ot(x[i:i + 1]), pw, pb, 1, 1))[0] for i in range(n)])
+    dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    dW, dB = dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias)
+    M = n * h * w
+    dC = _lib.DeviceBuffer(M * cout * 4)
+    a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=h, OW=w, KH=3, KW=3, stride=1, pad=1,
+                         W_=dW.ptr, ldb=9 * cin, M=M, N=cout, K=9 * cin, bias=dB.ptr, C32=dC.ptr, ldc32=cout,
+                         tile_variant=variant + 1)
+    kernels.gemm(a)
+    assert rel(dC.download((n, h, w, cout), np.float32).transpose(0, 3, 1, 2), ref) < 2e-5
+
+
+def test_gemm_geglu_rejected_on_odd_slab_tile(K):
+    kernels, _lib = K
+    a = kernels.GemmArgs(A=16, lda=64, W_=16, ldb=64, M=128, N=128, K=64, C32=16, ldc32=64, act=kernels.ACT_GEGLU, tile_variant=17)
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a)
+
+
 @pytest.mark.parametrize("M,N,Kd,ksplit,variant,act,post", [
     (128, 1280, 2304, 6, 0, 0, 0), (100, 256, 1096, 5, 2, 1, 0), (2, 1280, 1280, 4, 2, 1, 0), (512, 320, 640, 10, 1, 4, 1),
     (130, 132, 72, 64, 0, 2, 0)])
