@@ -107,6 +107,25 @@ void clip_encoder_free(ClipEncoder* E);
 /* SDXL vector conditioning (src/mlimgsynth.c:1542-1557): [pooled | emb(h,w) | emb(0,0) | emb(h,w)], 256 dims each */
 int sdxl_label_build(const float* feat, int n_feat, int width, int height, float* label, int n_label);
 
+/* ---- CLIP BPE tokenizer (host).  Replaces clip_tokenize and helpers, src/clip.c:59-278 (public entry
+ * mlis_text_tokenize, include/mlimgsynth.h); pinned by the 14 KATs of src/test_text_tokenize_clip.c:41-66.
+ * The merge table is run-time data here (the reference compiles src/clip_merges.c.h in): id pairs in rank order
+ * (token 512+i = merge i) or OpenAI's public bpe_simple_vocab_16e6.txt / merges.txt.  All functions return
+ * counts (>= 0) or < 0 on error (mlsd_last_error()). */
+typedef struct ClipTokenizer ClipTokenizer;
+ClipTokenizer* clip_tokr_new(void);
+void clip_tokr_free(ClipTokenizer* T);
+int clip_tokr_set_merges(ClipTokenizer* T, const int32_t* pairs /* [n][2] */, int n);
+int clip_tokr_load_merges_txt(ClipTokenizer* T, const char* path, int max_merges /* <= 0: CLIP's 48894 */);
+int clip_tokr_n_merges(const ClipTokenizer* T);
+int clip_tokr_n_vocab(const ClipTokenizer* T);              /* 512 + merges + start/end */
+int clip_tokr_byte_to_token(int byte);                      /* clip_tokr_byte_to_token, src/clip.c:113-125 */
+int clip_tokr_token_to_byte(int token);
+/* text (UTF-8, len < 0: NUL-terminated) -> token ids without BOS/EOS/padding; returns the count */
+int clip_tokenize(const ClipTokenizer* T, const char* text, int64_t len, int32_t* out, int max_out);
+/* bytes a byte/merge token stands for; returns the byte count (may exceed max: nothing is written past it) */
+int clip_token_decode(const ClipTokenizer* T, int32_t token, char* out, int max, int* end_of_word);
+
 /* ---------------------------------------------------------------- RNG / schedule / sampler */
 typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
 void rng_philox_randn(RngPhilox* S, unsigned n, float* out);

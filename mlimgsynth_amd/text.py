@@ -116,3 +116,79 @@ class TextConditioner:
         if self.model in ("sdxl", "tinyxl") and len(neg_toks) == 0:
             ncond = np.zeros_like(ncond)
         return cond, label, ncond, nlabel
+
+
+class ClipTokenizer:
+    """CLIP BPE tokenizer (csrc/host/clip_tokenizer.c; reference clip_tokenize, src/clip.c:59-278).
+
+    The merge table is data the user supplies: `from_pairs` (int32 [n][2], rank order) or `from_file` (OpenAI's
+    bpe_simple_vocab_16e6.txt / a merges.txt)."""
+
+    def __init__(self):
+        l = _proto2()
+        l.clip_tokr_new.restype = vp
+        l.clip_tokr_free.argtypes = [vp]
+        l.clip_tokr_set_merges.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), c_int]
+        l.clip_tokr_load_merges_txt.argtypes = [vp, ctypes.c_char_p, c_int]
+        l.clip_tokr_n_vocab.argtypes = [vp]
+        l.clip_tokr_n_merges.argtypes = [vp]
+        l.clip_tokenize.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), c_int]
+        l.clip_token_decode.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, c_int, ctypes.POINTER(c_int)]
+        self._l = l
+        self.h = vp(l.clip_tokr_new())
+
+    @classmethod
+    def from_pairs(cls, pairs):
+        t = cls()
+        p = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        check1(t._l.clip_tokr_set_merges(t.h, p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(p)), "clip_tokr_set_merges")
+        return t
+
+    @classmethod
+    def from_file(cls, path, max_merges=0):
+        t = cls()
+        r = t._l.clip_tokr_load_merges_txt(t.h, str(path).encode(), max_merges)
+        if r < 0:
+            check1(r, "clip_tokr_load_merges_txt")
+        return t
+
+    @property
+    def n_vocab(self):
+        return self._l.clip_tokr_n_vocab(self.h)
+
+    @property
+    def n_merges(self):
+        return self._l.clip_tokr_n_merges(self.h)
+
+    def encode(self, text):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        out = np.empty(max(len(raw), 1), np.int32)       # a word never yields more tokens than bytes
+        n = self._l.clip_tokenize(self.h, raw, len(raw), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.size)
+        if n < 0:
+            check1(n, "clip_tokenize")
+        return [int(v) for v in out[:n]]
+
+    def token_bytes(self, token):
+        buf = ctypes.create_string_buffer(256)
+        eow = c_int(0)
+        n = self._l.clip_token_decode(self.h, token, buf, 256, ctypes.byref(eow))
+        if n < 0:
+            check1(n, "clip_token_decode")
+        return buf.raw[:n], bool(eow.value)
+
+    def decode(self, tokens):
+        out = bytearray()
+        for t in tokens:
+            b, eow = self.token_bytes(t)
+            out += b
+            if eow:
+                out += b" "
+        return out.decode("utf-8", errors="replace").rstrip()
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._l.clip_tokr_free(self.h)
+                self.h = None
+        except Exception:
+            pass
