@@ -107,6 +107,19 @@ void clip_encoder_free(ClipEncoder* E);
 /* SDXL vector conditioning (src/mlimgsynth.c:1542-1557): [pooled | emb(h,w) | emb(0,0) | emb(h,w)], 256 dims each */
 int sdxl_label_build(const float* feat, int n_feat, int width, int height, float* label, int n_label);
 
+/* ---- text conditioning on resident towers: mlis_text_cond_encode / mlis_clip_tokens_encode
+ * (src/mlimgsynth.c:1423-1468,1501-1563).  model "sd1" | "sdxl" | "tiny" | "tinyxl"; tokens without BOS/EOS/padding.
+ * cond [77][n_ctx]; label [n_label] (SDXL: pooled bigG feature || size embeddings; NULL for SD1). */
+typedef struct MLIS_AmdTextCond MLIS_AmdTextCond;
+MLIS_AmdTextCond* mlis_amd_textcond_create(const char* model, int width, int height, uint64_t weight_seed, void* stream);
+void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T);
+int mlis_amd_textcond_dims(const MLIS_AmdTextCond* T, int* n_ctx, int* n_label);
+double mlis_amd_textcond_flops(const MLIS_AmdTextCond* T);
+int mlis_amd_textcond_encode(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, float* cond, float* label);
+/* prompt + negative prompt; an EMPTY negative prompt on SDXL zeroes ncond (uncond_empty_zero, :1702-1703) */
+int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg,
+	float* cond, float* label, float* ncond, float* nlabel);
+
 /* ---- CLIP BPE tokenizer (host).  Replaces clip_tokenize and helpers, src/clip.c:59-278 (public entry
  * mlis_text_tokenize, include/mlimgsynth.h); pinned by the 14 KATs of src/test_text_tokenize_clip.c:41-66.
  * The merge table is run-time data here (the reference compiles src/clip_merges.c.h in): id pairs in rank order

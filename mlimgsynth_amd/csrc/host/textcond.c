@@ -1,0 +1,117 @@
+/* Text conditioning of the generation driver on resident CLIP towers.
+ *
+ * Follows mlis_text_cond_encode / mlis_clip_tokens_encode (reference src/mlimgsynth.c:1423-1468,1501-1563):
+ *   SD1.x : cond = CLIP-L embedding, clip_skip 1, final norm                                  [77][768]
+ *   SDXL  : cond = CLIP-L embedding (clip_skip 2, no norm) || CLIP-bigG embedding (same)      [77][2048]
+ *           label = bigG pooled feature (all layers + norm + text_proj) || size embeddings    [2816]
+ *           (sd_timestep_embedding of (h,w),(0,0),(h,w), src/mlimgsynth.c:1485-1499,1542-1557)
+ *   empty negative prompt on SDXL => uncond zeroed (uncond_empty_zero, :1702-1703); unlabel still computed.
+ * The reference rebuilds each CLIP graph and re-uploads its weights per prompt (src/clip.c:458-486); here the
+ * towers are built once and stay in HBM.  "tiny"/"tinyxl" use the 3-layer test tower. */
+#include "mlblock_int.h"
+#include "mlimgsynth_amd.h"
+
+struct MLIS_AmdTextCond {
+	char model[16];
+	int width, height, xl;
+	int n_enc;
+	MLCtx* ctx[3];
+	ClipEncoder enc[3];     /* SD1: [0] ; SDXL: [0] CLIP-L embed, [1] bigG embed (skip 2), [2] bigG pooled feature */
+	int n_ctx, n_label;
+	float *e1, *e2, *feat;
+};
+
+MLB_API void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T)
+{
+	if (!T) return;
+	for (int i=0;i<T->n_enc;++i) { clip_encoder_free(&T->enc[i]); if (T->ctx[i]) mlctx_destroy(T->ctx[i]); }
+	free(T->e1); free(T->e2); free(T->feat);
+	free(T);
+}
+
+static int tower_add(MLIS_AmdTextCond* T, const char* tower, const char* prefix, int clip_skip, bool norm, bool want_feat,
+	uint64_t seed, void* stream)
+{
+	const int i = T->n_enc;
+	ClipParams P;
+	if (clip_params_get(tower, &P) < 0) return -1;
+	T->ctx[i] = mlctx_new(stream);
+	if (!T->ctx[i]) return mlsd_set_error(-1, "textcond: mlctx_new failed");
+	T->n_enc = i + 1;
+	if (clip_encoder_init(&T->enc[i], T->ctx[i], &P, prefix, 1, clip_skip, norm, want_feat) < 0) return -1;
+	if (mlctx_params_synth(T->ctx[i], seed) < 0) return -1;
+	return 1;
+}
+
+MLB_API MLIS_AmdTextCond* mlis_amd_textcond_create(const char* model, int width, int height, uint64_t weight_seed, void* stream)
+{
+	MLIS_AmdTextCond *T = calloc(1, sizeof(*T));
+	if (!T) return NULL;
+	snprintf(T->model, sizeof(T->model), "%s", model ? model : "");
+	T->width = width; T->height = height;
+	int rc = -1;
+	if (!strcmp(T->model, "sd1") || !strcmp(T->model, "tiny")) {
+		rc = tower_add(T, T->model[0] == 's' ? "vit_l" : "tiny", "clip", 1, true, false, weight_seed, stream);
+	} else if (!strcmp(T->model, "sdxl") || !strcmp(T->model, "tinyxl")) {
+		const char *t1 = T->model[0] == 's' ? "vit_l" : "tiny", *t2 = T->model[0] == 's' ? "vit_bigg" : "tiny";
+		T->xl = 1;
+		rc = tower_add(T, t1, "clip", 2, false, false, weight_seed, stream);
+		if (rc > 0) rc = tower_add(T, t2, "clip2", 2, false, false, weight_seed, stream);
+		if (rc > 0) rc = tower_add(T, t2, "clip2", 1, true, true, weight_seed, stream);
+	} else mlsd_set_error(-1, "textcond: unknown model '%s'", T->model);
+	if (rc < 0) { mlis_amd_textcond_destroy(T); return NULL; }
+	const int d1 = T->enc[0].P.d_embed, d2 = T->xl ? T->enc[1].P.d_embed : 0;
+	T->n_ctx = d1 + d2;
+	/* tinyxl: adm = 64 + 32 (shrunken size embedding, zeros) so the UNet's label width stays a multiple of 32 */
+	T->n_label = !T->xl ? 0 : (!strcmp(T->model, "sdxl") ? d2 + 1536 : d2 + 32);
+	T->e1 = malloc(sizeof(float) * 77 * (size_t)d1);
+	T->e2 = T->xl ? malloc(sizeof(float) * 77 * (size_t)d2) : NULL;
+	T->feat = T->xl ? malloc(sizeof(float) * (size_t)d2) : NULL;
+	if (!T->e1 || (T->xl && (!T->e2 || !T->feat))) { mlis_amd_textcond_destroy(T); mlsd_set_error(-1, "textcond: out of memory"); return NULL; }
+	return T;
+}
+
+MLB_API int mlis_amd_textcond_dims(const MLIS_AmdTextCond* T, int* n_ctx, int* n_label)
+{
+	if (!T) return -1;
+	if (n_ctx) *n_ctx = T->n_ctx;
+	if (n_label) *n_label = T->n_label;
+	return 1;
+}
+
+MLB_API double mlis_amd_textcond_flops(const MLIS_AmdTextCond* T)
+{
+	double f = 0;
+	for (int i=0; T && i<T->n_enc; ++i) { MLCtxInfo I; mlctx_info(T->ctx[i], &I); f += I.flops; }
+	return f;
+}
+
+MLB_API int mlis_amd_textcond_encode(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, float* cond, float* label)
+{
+	if (!T || !cond || n_tok < 0 || (n_tok && !toks)) return mlsd_set_error(-1, "textcond_encode: bad arguments");
+	static const int32_t none = 0;
+	if (!toks) toks = &none;
+	if (!T->xl) return clip_encoder_run(&T->enc[0], (unsigned)n_tok, toks, cond, NULL);
+	if (!label) return mlsd_set_error(-1, "textcond_encode: SDXL needs a label output");
+	const int d1 = T->enc[0].P.d_embed, d2 = T->enc[1].P.d_embed, nt = T->enc[0].P.n_token;
+	if (clip_encoder_run(&T->enc[0], (unsigned)n_tok, toks, T->e1, NULL) < 0) return -1;
+	if (clip_encoder_run(&T->enc[1], (unsigned)n_tok, toks, T->e2, NULL) < 0) return -1;
+	if (clip_encoder_run(&T->enc[2], (unsigned)n_tok, toks, NULL, T->feat) < 0) return -1;
+	for (int t=0;t<nt;++t) {   /* concat along the embedding axis, src/mlimgsynth.c:1530-1539 */
+		memcpy(cond + (size_t)t * (d1 + d2), T->e1 + (size_t)t * d1, sizeof(float) * d1);
+		memcpy(cond + (size_t)t * (d1 + d2) + d1, T->e2 + (size_t)t * d2, sizeof(float) * d2);
+	}
+	if (!strcmp(T->model, "sdxl")) return sdxl_label_build(T->feat, d2, T->width, T->height, label, T->n_label);
+	memcpy(label, T->feat, sizeof(float) * d2);
+	memset(label + d2, 0, sizeof(float) * (size_t)(T->n_label - d2));
+	return 1;
+}
+
+MLB_API int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg,
+	float* cond, float* label, float* ncond, float* nlabel)
+{
+	if (mlis_amd_textcond_encode(T, toks, n_tok, cond, label) < 0) return -1;
+	if (mlis_amd_textcond_encode(T, neg, n_neg, ncond, nlabel) < 0) return -1;
+	if (T->xl && n_neg == 0) memset(ncond, 0, sizeof(float) * 77 * (size_t)T->n_ctx);
+	return 1;
+}

@@ -71,51 +71,66 @@ def sdxl_label(feat, width, height):
 
 
 class TextConditioner:
-    """mlis_text_cond_encode (src/mlimgsynth.c:1501-1563) on resident encoders.
-
-    SD1.x : cond = CLIP-L embed (clip_skip 1, final norm)                         [77][768]
-    SDXL  : cond = CLIP-L embed (clip_skip 2, no norm) || CLIP-bigG embed (same)   [77][2048]
-            label = bigG pooled feature (all layers + norm + text_proj) || size embeddings   [2816]
-            empty negative prompt => uncond zeroed (uncond_empty_zero, mlimgsynth.c:1702-1703); unlabel is still
-            computed from the empty prompt.
-    tiny / tinyxl use the "tiny" tower so tests stay fast."""
+    """mlis_text_cond_encode (src/mlimgsynth.c:1501-1563) on resident encoders: thin wrapper over the C object
+    MLIS_AmdTextCond (csrc/host/textcond.c), which holds the towers and does the SD1.5 / SDXL assembly."""
 
     def __init__(self, model, width, height, seed=1234, stream=None):
-        self.model, self.w, self.h = model, width, height
-        if model in ("sd1", "tiny"):
-            tower = "vit_l" if model == "sd1" else "tiny"
-            self.enc = [ClipEncoder(tower, "clip", 1, clip_skip=1, norm=True, seed=seed, stream=stream)]
-        elif model in ("sdxl", "tinyxl"):
-            t1, t2 = ("vit_l", "vit_bigg") if model == "sdxl" else ("tiny", "tiny")
-            self.enc = [ClipEncoder(t1, "clip", 1, clip_skip=2, norm=False, seed=seed, stream=stream),
-                        ClipEncoder(t2, "clip2", 1, clip_skip=2, norm=False, seed=seed, stream=stream),
-                        ClipEncoder(t2, "clip2", 1, want_feat=True, seed=seed, stream=stream)]
-        else:
-            raise ValueError(model)
+        l = _proto2()
+        I32P = ctypes.POINTER(ctypes.c_int32)
+        l.mlis_amd_textcond_create.restype = vp
+        l.mlis_amd_textcond_create.argtypes = [ctypes.c_char_p, c_int, c_int, ctypes.c_uint64, vp]
+        l.mlis_amd_textcond_destroy.argtypes = [vp]
+        l.mlis_amd_textcond_dims.argtypes = [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+        l.mlis_amd_textcond_flops.argtypes = [vp]
+        l.mlis_amd_textcond_flops.restype = ctypes.c_double
+        l.mlis_amd_textcond_encode.argtypes = [vp, I32P, c_int, FP, FP]
+        l.mlis_amd_textcond_encode_pair.argtypes = [vp, I32P, c_int, I32P, c_int, FP, FP, FP, FP]
+        self._l, self.model = l, model
+        h = l.mlis_amd_textcond_create(model.encode(), width, height, seed, vp(stream))
+        if not h:
+            check1(-1, "mlis_amd_textcond_create")
+        self.h = vp(h)
+        a, b = c_int(), c_int()
+        l.mlis_amd_textcond_dims(self.h, ctypes.byref(a), ctypes.byref(b))
+        self.n_ctx, self.n_label = a.value, b.value
+
+    @staticmethod
+    def _toks(t):
+        t = np.ascontiguousarray(np.asarray(t, np.int32).reshape(-1))
+        return t, t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if t.size else None
 
     def encode(self, toks):
-        """-> (cond [77][n_ctx], label [adm] or None)"""
-        toks = np.asarray(toks, np.int32).reshape(1, -1)
-        if len(self.enc) == 1:
-            return self.enc[0].run(toks)[0][0], None
-        e1 = self.enc[0].run(toks)[0][0]
-        e2 = self.enc[1].run(toks)[0][0]
-        feat = self.enc[2].run(toks)[1][0]
-        cond = np.concatenate([e1, e2], axis=1)                 # mlimgsynth.c:1530-1539
-        if self.model == "tinyxl":                              # tinyxl: n_ctx=128=64+64, adm=96=64+32 (shrunken size embedding)
-            return cond, np.concatenate([feat, np.zeros(32, np.float32)])
-        return cond, sdxl_label(feat, self.w, self.h)
-
-    def flops(self):
-        return sum(e.flops() for e in self.enc)
+        """-> (cond [77][n_ctx], label [n_label] or None)"""
+        t, tp = self._toks(toks)
+        cond = np.empty((77, self.n_ctx), np.float32)
+        label = np.empty(self.n_label, np.float32) if self.n_label else None
+        check1(self._l.mlis_amd_textcond_encode(self.h, tp, t.size, fptr(cond), fptr(label)), "mlis_amd_textcond_encode")
+        return cond, label
 
     def encode_pair(self, toks, neg_toks=()):
         """cond/label for the prompt and the (usually empty) negative prompt, with the SDXL zeroing rule."""
-        cond, label = self.encode(toks)
-        ncond, nlabel = self.encode(np.asarray(neg_toks, np.int32))
-        if self.model in ("sdxl", "tinyxl") and len(neg_toks) == 0:
-            ncond = np.zeros_like(ncond)
+        t, tp = self._toks(toks)
+        n, np_ = self._toks(neg_toks)
+        cond, ncond = np.empty((77, self.n_ctx), np.float32), np.empty((77, self.n_ctx), np.float32)
+        label = np.empty(self.n_label, np.float32) if self.n_label else None
+        nlabel = np.empty(self.n_label, np.float32) if self.n_label else None
+        check1(self._l.mlis_amd_textcond_encode_pair(self.h, tp, t.size, np_, n.size, fptr(cond), fptr(label), fptr(ncond), fptr(nlabel)),
+               "mlis_amd_textcond_encode_pair")
         return cond, label, ncond, nlabel
+
+    def flops(self):
+        return self._l.mlis_amd_textcond_flops(self.h)
+
+    def destroy(self):
+        if self.h:
+            self._l.mlis_amd_textcond_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class ClipTokenizer:

@@ -90,6 +90,44 @@ def test_clip_text_encode_parity(model, prefix, skip, norm, feat):
         assert err < 4e-3
 
 
+@pytest.mark.parametrize("model", ["tiny", "tinyxl"])
+def test_text_cond_assembly_vs_oracle(model):
+    """mlis_text_cond_encode assembly (src/mlimgsynth.c:1501-1563) of the C object MLIS_AmdTextCond: SD1 = one tower;
+    SDXL = [CLIP-L skip 2 no norm || bigG skip 2 no norm], label = pooled feature || size block; empty negative
+    prompt zeroes the SDXL uncond but not its label."""
+    from mlimgsynth_amd import text
+    K = O.clip_params("tiny")
+    toks = np.random.default_rng(8).integers(0, K.n_vocab - 3, 7).astype(np.int32)
+    tc = text.TextConditioner(model, 64, 64, seed=1234)
+    cond, label, ncond, nlabel = tc.encode_pair(toks, ())
+    P = O.Params(1234)
+
+    def oracle(prefix, tk, skip, norm, feat):
+        full = np.full(K.n_token, K.tok_pad, np.int32)
+        full[0] = K.tok_start
+        full[1:1 + len(tk)] = tk
+        full[1 + len(tk)] = K.tok_end
+        ptr = full.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        r = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, skip, int(norm), int(feat), len(tk) + 1 if feat else 0))
+        return r.reshape(K.d_embed) if feat else r.reshape(K.n_token, K.d_embed)
+    if model == "tiny":
+        assert cond.shape == (77, 64) and label is None and nlabel is None
+        assert rel(cond, oracle("clip", toks, 1, True, False)) < 4e-3
+        assert rel(ncond, oracle("clip", toks[:0], 1, True, False)) < 4e-3     # SD1: the empty prompt is encoded, not zeroed
+    else:
+        assert cond.shape == (77, 128) and label.shape == (96,)
+        assert rel(cond[:, :64], oracle("clip", toks, 2, False, False)) < 4e-3
+        assert rel(cond[:, 64:], oracle("clip2", toks, 2, False, False)) < 4e-3
+        assert rel(label[:64], oracle("clip2", toks, -1, True, True)) < 4e-3
+        assert not label[64:].any()
+        assert not ncond.any()                                                 # uncond_empty_zero
+        assert rel(nlabel[:64], oracle("clip2", toks[:0], -1, True, True)) < 4e-3
+        c2, l2, nc2, nl2 = tc.encode_pair(toks, toks[:3])                      # a non-empty negative prompt is encoded
+        assert nc2.any() and rel(nc2[:, :64], oracle("clip", toks[:3], 2, False, False)) < 4e-3
+        assert np.array_equal(c2, cond)
+    tc.destroy()
+
+
 def test_clip_prompt_too_long_is_an_error():
     from mlimgsynth_amd import engine, _lib
     with pytest.raises(_lib.MlsdError):
