@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 #include "common.hpp"
 #include "mlsd_kernels.h"
 
@@ -503,6 +504,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
+#include "gemm_pp.hpp"
+
 // ---- split-K second pass: sum the slices in fixed order (deterministic), then the same epilogue as above.
 // One thread per 4 consecutive columns; only launched when the wide-epilogue alignment conditions hold.
 __global__ __launch_bounds__(256) void splitk_reduce(const GemmP p, const float* __restrict__ ws, int nsplit)
@@ -610,6 +613,37 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
+// launcher of the 256x256x64 ping-pong kernel (gemm_pp.hpp): same argument handling as launch<>
+int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
+{
+    constexpr int BM = 256, BN = 256, BK = 64;
+    GemmP p;
+    p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_;
+    p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
+    p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample;
+    p.bias = a->bias; p.biasm = a->bias_m; p.act_post = a->act_after_resid; p.rowbias = a->rowbias; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+    p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
+    p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
+    p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
+    {
+        const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
+        p.vec = !(nout & 3) && !(a->N & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) &&
+                (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
+                (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+    }
+    p.dbg = 0; p.gw = g_gemm_panel;
+    p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on this tile
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;  // 128 KiB ring (>= the epilogue's 8 x 8 KiB)
+    const dim3 grid(p.nbm * p.nbn), block(512);
+    auto go = [&](auto kfn) -> int {
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+        return mlsd_check_launch("gemm_pp_kernel");
+    };
+    return a->conv ? go(gemm_pp_kernel<true>) : go(gemm_pp_kernel<false>);
+}
+
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
 
 struct Variant { const char* name; int bm, bn, slots; };
@@ -631,6 +665,7 @@ const Variant kVariants[] = {
     {"128x128x64r2", 128, 128, 512},    // 14: as 0 but register-staged
     {"256x128x64r2", 256, 128, 256},    // 15: as 3 but register-staged
     {"128x320x64s2", 128, 320, 256},    // 16: 8 waves (4x2, wave tile 32x160): N = 1280 / 640 outputs in exactly 4 / 2 tile columns
+    {"256x256x64pp", 256, 256, 256},    // 17: 8 waves in two ping-pong groups, 16x16x32 MFMA, 4 phases per K tile (gemm_pp.hpp)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -675,6 +710,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 17: return launch_pp(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
@@ -709,7 +745,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     static thread_local char buf[64];
     const int v = pick_variant(a);
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
-    const int ns = splitk_slices(a, bk, nullptr);
+    const int ns = v == 17 ? 1 : splitk_slices(a, bk, nullptr);
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

@@ -153,7 +153,7 @@ def test_gemm_rejects_bad_args(K):
         kernels.gemm(a)
 
 
-BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16]   # kVariants[] indices instantiated by the default build (gemm_conv.hip)
+BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16, 17]   # kVariants[] indices instantiated by the default build (gemm_conv.hip)
 
 
 @pytest.mark.parametrize("variant", BUILT_TILE_VARIANTS)
@@ -200,6 +200,29 @@ def test_conv2d_every_tile_variant(K, variant):
                          tile_variant=variant + 1)
     kernels.gemm(a)
     assert rel(dC.download((n, h, w, cout), np.float32).transpose(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (777, 520, 1992), (256, 256, 64), (8192, 1280, 1280)])
+def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
+    """The two-group ping-pong kernel (gemm_pp.hpp) against the 16-wave 256x256 kernel on long K and many tiles,
+    repeated: its RAW/WAR ordering rests on counted waits and barrier parity, so a race would show as rare
+    wrong tiles."""
+    kernels, _lib = K
+    rng = np.random.default_rng(M + Kd)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    d9, d17 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    mk = lambda dst, v: kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dst.ptr, ldc32=N, tile_variant=v + 1)
+    kernels.gemm(mk(d9, 9))
+    ref = d9.download((M, N), np.float32)
+    exact = A.astype(np.float32) @ W.astype(np.float32).T
+    assert rel(ref, exact) < 2e-5
+    for rep in range(6):
+        kernels.gemm(mk(d17, 17))
+        got = d17.download((M, N), np.float32)
+        assert rel(got, exact) < 2e-5, rep
+        assert np.abs(got - ref).max() < 1e-3, rep
 
 
 def test_gemm_geglu_rejected_on_odd_slab_tile(K):
