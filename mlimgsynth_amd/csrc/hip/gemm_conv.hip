@@ -613,6 +613,17 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
+// problems the ping-pong kernel takes (gemm_pp.hpp); everything else asked of variant 17 runs on the 16-wave 256x256 tile
+bool pp_eligible(const mlsd_gemm_args* a)
+{
+    if (a->conv || (a->K & 63) || a->K < 192 || (a->M & 255) || (a->N & 255)) return false;
+    if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) & 255)) return false;
+    const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
+    return !(nout & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&
+           (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) && (!a->bias || !((uintptr_t)a->bias & 15)) &&
+           (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+}
+
 // launcher of the 256x256x64 ping-pong kernel (gemm_pp.hpp): same argument handling as launch<>
 int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 {
@@ -632,16 +643,17 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
-    p.dbg = 0; p.gw = g_gemm_panel;
+    p.dbg = g_gemm_dbg; p.gw = g_gemm_panel;
     p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on this tile
-    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;  // 128 KiB ring (>= the epilogue's 8 x 8 KiB)
-    const dim3 grid(p.nbm * p.nbn), block(512);
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;   // 128 KiB ring; the epilogue needs no LDS
+    const int ntiles = p.nbm * p.nbn;
+    const dim3 grid(ntiles < 256 ? ntiles : 256), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
     auto go = [&](auto kfn) -> int {
         MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_pp_kernel");
     };
-    return a->conv ? go(gemm_pp_kernel<true>) : go(gemm_pp_kernel<false>);
+    return go(gemm_pp_kernel);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
@@ -710,7 +722,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
-    case 17: return launch_pp(a, st);
+    case 17: return pp_eligible(a) ? launch_pp(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
@@ -743,7 +755,8 @@ MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit) { return ksp
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
-    const int v = pick_variant(a);
+    int v = pick_variant(a);
+    if (v == 17 && !pp_eligible(a)) v = 9;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = v == 17 ? 1 : splitk_slices(a, bk, nullptr);
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);

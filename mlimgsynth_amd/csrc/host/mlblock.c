@@ -473,7 +473,11 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	/* candidates: (tile variant, K slices) */
 	int cv[16], cs[16], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
-	else { cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
+	else {
+		/* persistent ping-pong 256x256 tile: 256-aligned linear problems (anything else it would hand to variant 9 anyway) */
+		if (!g->conv && !(g->M & 255) && !(g->N & 255) && !(g->K & 63) && g->K >= 192) { cv[nc]=17; cs[nc++]=1; }
+		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
+	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
 	if (g->M > 64 && t128 < 512) { cv[nc]=1; cs[nc++]=1; }
 	/* 128x320: outputs whose width is a multiple of 320 (N = 1280, 640) in whole tile columns, e.g. 8192x1280 =

@@ -159,6 +159,8 @@ BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16, 17]   # kVariants[] indices instantiat
 @pytest.mark.parametrize("variant", BUILT_TILE_VARIANTS)
 @pytest.mark.parametrize("M,N,Kd", [(300, 200, 136), (1000, 640, 320), (257, 1284, 72)])
 def test_gemm_every_tile_variant(K, variant, M, N, Kd):
+    # (variant 17, the ping-pong tile, only takes 256-aligned linear problems and hands these shapes to the 16-wave tile:
+    #  its own tests are test_gemm_pingpong_*)
     """Each built tile (incl. the 128x320 one whose waves own an odd number of 32-column slabs) against the oracle
     linear, with every epilogue term on; ragged M/N/K edges."""
     kernels, _lib = K
@@ -202,7 +204,8 @@ def test_conv2d_every_tile_variant(K, variant):
     assert rel(dC.download((n, h, w, cout), np.float32).transpose(0, 3, 1, 2), ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (777, 520, 1992), (256, 256, 64), (8192, 1280, 1280)])
+@pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320),
+                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256)])
 def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
     """The two-group ping-pong kernel (gemm_pp.hpp) against the 16-wave 256x256 kernel on long K and many tiles,
     repeated: its RAW/WAR ordering rests on counted waits and barrier parity, so a race would show as rare
@@ -223,6 +226,61 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
         got = d17.download((M, N), np.float32)
         assert rel(got, exact) < 2e-5, rep
         assert np.abs(got - ref).max() < 1e-3, rep
+
+
+@pytest.mark.parametrize("mode", ["bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm"])
+def test_gemm_pingpong_epilogues(K, mode):
+    """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
+    oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
+    here -- the multi-tile stream is covered by test_gemm_pingpong_tile_matches_plain_tile."""
+    kernels, _lib = K
+    M, N, Kd = 1536, 768, 448
+    rng = np.random.default_rng(len(mode))
+    A = f16r(rng.standard_normal((M, Kd)))
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
+    bias = rng.standard_normal(N).astype(np.float32)
+    P = O.Params()
+    y = O.from_ot(O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias))).reshape(M, N)
+    gelu = lambda v: 0.5 * v * (1 + np.tanh(0.7978845608028654 * v * (1 + 0.044715 * v * v)))
+    dA, dB = dev(_lib, A.astype(np.float16)), dev(_lib, bias)
+    kw = dict(A=dA.ptr, lda=Kd, conv=0, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=18)
+    nout, keep = N, []
+    if mode == "geglu_f16":
+        d = N // 2
+        ref = y[:, :d] * gelu(y[:, d:])
+        Wi, bi = geglu_interleave(W, d), geglu_interleave(bias[:, None], d)[:, 0]
+        dW, dBi = dev(_lib, Wi.astype(np.float16)), dev(_lib, bi)
+        keep += [dBi]
+        kw.update(W_=dW.ptr, bias=dBi.ptr, act=kernels.ACT_GEGLU)
+        nout = d
+    else:
+        dW = dev(_lib, W.astype(np.float16))
+        kw.update(W_=dW.ptr)
+        res = rng.standard_normal((M, N)).astype(np.float32)
+        dR = dev(_lib, res); keep += [dR]
+        if mode == "bias_res_silu_both":
+            ref = y / (1 + np.exp(-y)) + res
+            kw.update(act=1, resid=dR.ptr, ldr=N)
+        elif mode == "rowbias_gelu":
+            rb = rng.standard_normal((M // 512, N)).astype(np.float32)
+            dRB = dev(_lib, rb); keep += [dRB]
+            ref = gelu(y + np.repeat(rb, 512, axis=0))
+            kw.update(act=2, rowbias=dRB.ptr, rows_per_batch=512, ldrb=N)
+        elif mode == "relu_post":
+            ref = np.maximum(y + res, 0)
+            kw.update(act=4, resid=dR.ptr, ldr=N, act_after_resid=1)
+        else:
+            bm = rng.standard_normal(M).astype(np.float32)
+            dBM = dev(_lib, bm); keep += [dBM]
+            z = y + bm[:, None]
+            ref = z / (1 + np.exp(-1.702 * z))
+            kw.update(act=3, bias_m=dBM.ptr)
+    dC32, dC16 = _lib.DeviceBuffer(M * nout * 4), _lib.DeviceBuffer(M * nout * 2)
+    a = kernels.GemmArgs(C32=dC32.ptr, ldc32=nout, C16=dC16.ptr, ldc16=nout, **kw)
+    assert "pp" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    assert rel(dC32.download((M, nout), np.float32), ref) < 2e-5
+    assert rel(dC16.download((M, nout), np.float16).astype(np.float32), ref) < 1e-3
 
 
 def test_gemm_geglu_rejected_on_odd_slab_tile(K):
