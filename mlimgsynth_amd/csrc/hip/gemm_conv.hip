@@ -616,7 +616,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
 // problems the ping-pong kernel takes (gemm_pp.hpp); everything else asked of variant 17 runs on the 16-wave 256x256 tile
 bool pp_eligible(const mlsd_gemm_args* a)
 {
-    if (a->conv || (a->K & 63) || a->K < 192 || (a->M & 255) || (a->N & 255)) return false;
+    if (a->conv || (a->K & 63) || a->K < 192 || (a->M & 127) || (a->N & 63)) return false;
     if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) & 255)) return false;
     const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
     return !(nout & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&

@@ -51,7 +51,7 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
     return PPTile{bm * 256, bn * 256};
 }
 
-// Linear only (plain row-major A), M and N multiples of 256, K a multiple of 64 and >= 192 (3 K tiles: U1, two tiles ahead, must enter output
+// Linear only (plain row-major A), M a multiple of 128, N of 64, K a multiple of 64 and >= 192 (3 K tiles: U1, two tiles ahead, must enter output
 // tile ti+1 while the MFMAs are in tile ti): the per-phase staging code is two LDS-DMA
 // instructions on running row pointers and nothing else (out-of-range rows are CLAMPED to the last valid row
 // instead of zero-filled: their products land in output rows/columns that are never stored).
@@ -192,8 +192,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         }
         return v;
     };
-    // Launcher guarantees (else the LDS-transposing tiles run): M, N multiples of 256 (no edge guards), 16-byte
-    // aligned rows, and rows_per_batch a multiple of 256 (one row-bias vector per output tile).
+    // Launcher guarantees (else the LDS-transposing tiles run): M a multiple of 128 and N of 64 (a wave's 128x64 block is
+    // entirely inside or outside: one wave-uniform test, no per-lane guards), 16-byte aligned rows, and rows_per_batch a
+    // multiple of 256 (one row-bias vector per output tile).
     // one 16-row block (qa, i) of the wave's tile; called with compile-time indices (a pragma-unrolled loop over the
     // whole epilogue exceeds the unroller's size limit and would push the accumulators to scratch)
     f32x4 cb[2][2];       // bias (+ row bias) of the lane's 4 column groups, loaded once per output tile
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     };
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int wrow0 = tcur.m0 + wr * 128, wcol0 = tcur.n0 + wc * 64;
+        if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % 128 == 0, N % 64 == 0: a wave's 128x64 is all in or all out
         const float* rbias = p.rowbias ? p.rowbias + (long)(tcur.m0 / p.rows_per_batch) * p.ldrb : nullptr;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)

@@ -474,8 +474,8 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	int cv[16], cs[16], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
-		/* persistent ping-pong 256x256 tile: 256-aligned linear problems (anything else it would hand to variant 9 anyway) */
-		if (!g->conv && !(g->M & 255) && !(g->N & 255) && !(g->K & 63) && g->K >= 192) { cv[nc]=17; cs[nc++]=1; }
+		/* persistent ping-pong 256x256 tile: linear problems made of whole 128x64 wave blocks (anything else it would hand to variant 9) */
+		if (!g->conv && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63) && !(g->K & 63) && g->K >= 192) { cv[nc]=17; cs[nc++]=1; }
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);

@@ -205,7 +205,7 @@ def test_conv2d_every_tile_variant(K, variant):
 
 
 @pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320),
-                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256)])
+                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448)])
 def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
     """The two-group ping-pong kernel (gemm_pp.hpp) against the 16-wave 256x256 kernel on long K and many tiles,
     repeated: its RAW/WAR ordering rests on counted waits and barrier parity, so a race would show as rare
