@@ -613,21 +613,24 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
-// problems the ping-pong kernel takes (gemm_pp.hpp); everything else asked of variant 17 runs on the 16-wave 256x256 tile
-bool pp_eligible(const mlsd_gemm_args* a)
+// problems the ping-pong kernels take (gemm_pp.hpp); everything else asked of variants 17 / 18 runs on the LDS-transposing
+// tile of the same shape (9 / 16)
+bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
-    if (a->conv || (a->K & 63) || a->K < 192 || (a->M & 127) || (a->N & 63)) return false;
-    if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) & 255)) return false;
+    if (a->conv || (a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
+    if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) % BM)) return false;
+    if (a->act == MLSD_ACT_GEGLU && BN != 256) return false;
     const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
     return !(nout & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&
            (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) && (!a->bias || !((uintptr_t)a->bias & 15)) &&
            (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
 }
 
-// launcher of the 256x256x64 ping-pong kernel (gemm_pp.hpp): same argument handling as launch<>
+// launcher of the ping-pong kernels (gemm_pp.hpp): same argument handling as launch<>
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH>
 int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 {
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BK = 64;
     GemmP p;
     p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_;
     p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
@@ -637,23 +640,16 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
-    {
-        const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
-        p.vec = !(nout & 3) && !(a->N & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) &&
-                (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
-                (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
-    }
+    p.vec = 1;                                             // pp_eligible() checked the alignment
     p.dbg = g_gemm_dbg; p.gw = g_gemm_panel;
-    p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on this tile
-    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2;   // 128 KiB ring; the epilogue needs no LDS
+    p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on these tiles
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
     const dim3 grid(ntiles < 256 ? ntiles : 256), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
-    auto go = [&](auto kfn) -> int {
-        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
-        return mlsd_check_launch("gemm_pp_kernel");
-    };
-    return go(gemm_pp_kernel);
+    auto kfn = gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH>;
+    MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+    return mlsd_check_launch("gemm_pp_kernel");
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
@@ -678,6 +674,7 @@ const Variant kVariants[] = {
     {"256x128x64r2", 256, 128, 256},    // 15: as 3 but register-staged
     {"128x320x64s2", 128, 320, 256},    // 16: 8 waves (4x2, wave tile 32x160): N = 1280 / 640 outputs in exactly 4 / 2 tile columns
     {"256x256x64pp", 256, 256, 256},    // 17: 8 waves in two ping-pong groups, 16x16x32 MFMA, 4 phases per K tile (gemm_pp.hpp)
+    {"128x320x64pp", 128, 320, 256},    // 18: the same structure on the 128x320 tile (wave 64x80)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -722,7 +719,11 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
-    case 17: return pp_eligible(a) ? launch_pp(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 17: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 18:
+        if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
@@ -756,9 +757,10 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
     int v = pick_variant(a);
-    if (v == 17 && !pp_eligible(a)) v = 9;
+    if (v == 17 && !pp_eligible(a, 256, 256)) v = 9;
+    if (v == 18 && !pp_eligible(a, 128, 320)) v = 16;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
-    const int ns = v == 17 ? 1 : splitk_slices(a, bk, nullptr);
+    const int ns = v >= 17 ? 1 : splitk_slices(a, bk, nullptr);
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

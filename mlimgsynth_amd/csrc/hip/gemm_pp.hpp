@@ -1,4 +1,4 @@
-// 256x256x64 persistent "ping-pong" GEMM / implicit-GEMM conv for gfx950 — included by gemm_conv.hip (inside
+// Persistent "ping-pong" GEMM tiles (256x256x64 and 128x320x64) for gfx950 — included by gemm_conv.hip (inside
 // its anonymous namespace; uses GemmP, wait_vmcnt, g_zero_page and the activation helpers).
 //
 // 8 waves = 2 groups (wave rows wr = 0,1) x 4 wave columns; a wave owns a 128x64 output = 4 quadrants of
@@ -31,6 +31,7 @@
 // the tile time.  Units past the end of the stream are staged from the zero page (uniform counts).
 struct PPTile { int m0, n0; };
 
+template <int BM, int BN>
 __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
 {
     // XCD-aware bijective remap of the virtual block index + column panels (as gemm_kernel)
@@ -48,18 +49,33 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
     } else {
         bm = bid / p.nbn; bn = bid - bm * p.nbn;
     }
-    return PPTile{bm * 256, bn * 256};
+    return PPTile{bm * BM, bn * BN};
 }
 
-// Linear only (plain row-major A), M a multiple of 128, N of 64, K a multiple of 64 and >= 192 (3 K tiles: U1, two tiles ahead, must enter output
-// tile ti+1 while the MFMAs are in tile ti): the per-phase staging code is two LDS-DMA
-// instructions on running row pointers and nothing else (out-of-range rows are CLAMPED to the last valid row
-// instead of zero-filled: their products land in output rows/columns that are never stored).
+// Geometry (template): the block tile is BM x BN, waves 2 x 4, a wave owns WM x WN = (BM/2) x (BN/4):
+//   256 x 256: wave 128 x 64, quadrants 64 x 32 (CB0 = CB1 = 2 column blocks of 16)   -- the description above
+//   128 x 320: wave  64 x 80, quadrants 32 x 48 | 32 x 32 (CB0 = 3, CB1 = 2): N = 1280 / 640 / 320 outputs in whole tile
+//              columns and 8192 x 1280 = exactly 256 tiles; residual rows are fetched in ONE batch at the start of the
+//              epilogue (80 spare registers) so their latency is paid once per output tile, not once per row block
+// Units are cut the same way (U1/U4 = the a0/a1 rows of both wave rows, U2/U3 = the b0/b1 rows of all four wave
+// columns); a unit of R rows is R/64 LDS-DMA instructions per thread, and the counted waits follow:
+//   P4: NU3 + NU4 + NU1 younger instructions,  P1: NU4 + NU1 + NU2,  P2: NU1 + NU2 + NU3     (6/6/6 and 4/5/6)
+// Linear only (plain row-major A), M a multiple of BM/2, N of BN/4, K a multiple of 64 and >= 192 (3 K tiles: U1, two
+// tiles ahead, must enter output tile ti+1 while the MFMAs are in tile ti): the per-phase staging code is LDS-DMA
+// instructions on running row pointers and nothing else (out-of-range rows are CLAMPED to the last valid row instead of
+// zero-filled: their products land in output rows/columns that are never stored).
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
-    constexpr int BK = 64;
-    constexpr int STAGE = 512 * BK * 2;            // 64 KiB: A 256 rows | B 256 rows
-    constexpr int BOFF = 256 * BK * 2;             // B tile offset inside a stage
+    constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
+    constexpr int WM = BM / 2, WN = BN / 4;
+    constexpr int RA = WM / 32;                    // 16-row blocks per A half (a0 / a1)
+    constexpr int NCB = CB0 + CB1;                 // 16-column blocks per wave
+    static_assert(NCB * 16 == WN && RA * 32 == WM, "wave tile");
+    constexpr int STAGE = (BM + BN) * RB;
+    constexpr int BOFF = BM * RB;                  // B tile offset inside a stage
+    constexpr int NU1 = BM / 128, NU2 = CB0, NU3 = CB1;      // LDS-DMA instructions per thread per unit (NU4 = NU1)
+    constexpr int W4 = NU3 + 2 * NU1, W1 = 2 * NU1 + NU2, W2 = NU1 + NU2 + NU3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,42 +88,61 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     const int nkt = p.K / BK;
     const int S = ntile * nkt;                                   // K tiles in this block's stream
 
-    // ---- staging assignment.  A unit = 128 tile rows = 2 x (8 waves x 8 rows); this thread stages, for every
-    // 64-row block it touches, row srow of the block and the LOGICAL chunk whose swizzled slot is lane&7.
-    const int srow = wave * 8 + (lane >> 3);                 // 0..63
-    const int sc = (lane & 7) ^ ((srow >> 1) & 7);           // every row this thread stages is = srow mod 16
+    // ---- staging.  A wave-instruction fills 8 consecutive tile rows (lane l -> row l>>3, slot l&7); instruction
+    // g = it*8 + wave of a unit covers the g-th group of 8 rows of the unit's row list.  The thread fetches the LOGICAL
+    // chunk whose swizzled slot is lane&7 in ITS row (baked into the running pointer).
+    auto a_row0 = [&](int it, int second) __attribute__((always_inline)) {        // U1 (second = 0) / U4 (1)
+        const int g = it * 8 + wave;
+        return (g / (WM / 16)) * WM + (g % (WM / 16)) * 8 + second * (WM / 2);
+    };
+    auto b_row0 = [&](int it, int second) __attribute__((always_inline)) {        // U2 (second = 0) / U3 (1)
+        const int per = (second ? CB1 : CB0) * 2;
+        const int g = it * 8 + wave;
+        return (g / per) * WN + (g % per) * 8 + second * (CB0 * 16);
+    };
+    auto chunk_of = [&](int row) __attribute__((always_inline)) { return ((lane & 7) ^ ((row >> 1) & 7)) * 8; };
 
-    // One iterator per unit sequence: U1 runs two K tiles ahead of the MFMAs, U2..U4 one.  Each holds two running
-    // row pointers (this thread's chunk of the current K tile) for the output tile it is staging for; all of them
-    // enter output tile ti+1 while the MFMAs are still in tile ti, so "the next tile" is one shared coordinate pair.
-    struct Seq { int kt, par; const _Float16* ptr[2]; };
-    Seq sa[2];    // [0] = U1 (tile rows srow + {0,128}), [1] = U4 (rows srow + {64,192})
-    Seq sb[2];    // [0] = U2, [1] = U3
-    PPTile tnext = pp_tile_coords(p, (int)blockIdx.x);       // coordinates the sequences use at their next tile entry
-    PPTile tcur = tnext;                                     // tile of the MFMAs / next epilogue
+    // One iterator per unit sequence: U1 runs two K tiles ahead of the MFMAs, U2..U4 one.  Each holds running row
+    // pointers (this thread's chunk of the current K tile) for the output tile it is staging for; all of them enter
+    // output tile ti+1 while the MFMAs are still in tile ti, so "the next tile" is one shared coordinate pair.
+    struct SeqA { int kt, par; const _Float16* ptr[NU1]; };
+    struct SeqB2 { int kt, par; const _Float16* ptr[NU2]; };
+    struct SeqB3 { int kt, par; const _Float16* ptr[NU3]; };
+    SeqA sa[2];    // [0] = U1, [1] = U4
+    SeqB2 sb2;     // U2
+    SeqB3 sb3;     // U3
+    PPTile tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x);   // coordinates the sequences use at their next tile entry
+    PPTile tcur = tnext;                                         // tile of the MFMAs / next epilogue
 
-    auto enter_A = [&](Seq& s, int second) __attribute__((always_inline)) {
+    auto enter_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
         s.kt = 0;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int m = min(tnext.m0 + srow + 64 * (it * 2 + second), p.M - 1);
-            s.ptr[it] = p.A + (long)m * p.lda + sc * 8;
+        for (int it = 0; it < NU1; ++it) {
+            const int r = a_row0(it, second) + (lane >> 3);
+            s.ptr[it] = p.A + (long)min(tnext.m0 + r, p.M - 1) * p.lda + chunk_of(r);
         }
     };
-    auto enter_B = [&](Seq& s, int second) __attribute__((always_inline)) {
+    auto enter_B2 = [&](SeqB2& s) __attribute__((always_inline)) {
         s.kt = 0;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int u = it * 64 + srow;
-            const int n = min(tnext.n0 + (u >> 5) * 64 + (u & 31) + second * 32, p.N - 1);   // unit row u -> tile row
-            s.ptr[it] = p.B + (long)n * p.ldb + sc * 8;
+        for (int it = 0; it < NU2; ++it) {
+            const int r = b_row0(it, 0) + (lane >> 3);
+            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r);
         }
     };
-    auto issue_A = [&](Seq& s, int second) __attribute__((always_inline)) {
+    auto enter_B3 = [&](SeqB3& s) __attribute__((always_inline)) {
+        s.kt = 0;
+#pragma unroll
+        for (int it = 0; it < NU3; ++it) {
+            const int r = b_row0(it, 1) + (lane >> 3);
+            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r);
+        }
+    };
+    auto issue_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
         unsigned char* stage = smem + s.par * STAGE;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            unsigned char* dst = stage + ((it * 2 + second) * 64 + wave * 8) * (BK * 2);   // wave-uniform: 8 rows, lane-linear
+        for (int it = 0; it < NU1; ++it) {
+            unsigned char* dst = stage + a_row0(it, second) * RB;                  // wave-uniform: 8 rows, lane-linear
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s.ptr[it],
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             s.ptr[it] += BK;
@@ -115,68 +150,77 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         s.par ^= 1;
         if (++s.kt == nkt) enter_A(s, second);
     };
-    auto issue_B = [&](Seq& s, int second) __attribute__((always_inline)) {
-        unsigned char* stage = smem + s.par * STAGE + BOFF;
+    auto issue_B2 = [&]() __attribute__((always_inline)) {
+        unsigned char* stage = smem + sb2.par * STAGE + BOFF;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int r0 = (it * 2 + (wave >> 2)) * 64 + (wave & 3) * 8 + second * 32;    // first of the wave-instruction's 8 rows
-            unsigned char* dst = stage + r0 * (BK * 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s.ptr[it],
+        for (int it = 0; it < NU2; ++it) {
+            unsigned char* dst = stage + b_row0(it, 0) * RB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb2.ptr[it],
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            s.ptr[it] += BK;
+            sb2.ptr[it] += BK;
         }
-        s.par ^= 1;
-        if (++s.kt == nkt) enter_B(s, second);
+        sb2.par ^= 1;
+        if (++sb2.kt == nkt) enter_B2(sb2);
+    };
+    auto issue_B3 = [&]() __attribute__((always_inline)) {
+        unsigned char* stage = smem + sb3.par * STAGE + BOFF;
+#pragma unroll
+        for (int it = 0; it < NU3; ++it) {
+            unsigned char* dst = stage + b_row0(it, 1) * RB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb3.ptr[it],
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            sb3.ptr[it] += BK;
+        }
+        sb3.par ^= 1;
+        if (++sb3.kt == nkt) enter_B3(sb3);
     };
 
     // ---- fragment addressing (16x16x32: lane = (row l15, k group lg)); rows are = l15 mod 16, so the swizzle
     // term is lane-constant: slot(ks) = ((4*ks + lg) ^ (l15 >> 1)) = c0 ^ (4*ks)
     const int c0 = lg ^ (l15 >> 1);
-    const int fa = (wr * 128 + l15) * (BK * 2);                // + (qa*64 + i*16) rows
-    const int fb = BOFF + (wc * 64 + l15) * (BK * 2);          // + (qb*32 + j*16) rows
+    const int fa = (wr * WM + l15) * RB;                       // + (qa*WM/2 + i*16) rows
+    const int fb = BOFF + (wc * WN + l15) * RB;                // + cbi*16 rows
     const int fk0 = c0 << 4, fk1 = (c0 ^ 4) << 4;
 
-    f32x4 acc[2][2][4][2];
+    f32x4 acc[2][RA][NCB];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int i = 0; i < RA; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < NCB; ++c) acc[a][i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    f16x8 af[4][2], bf[2][2][2];
+    f16x8 af[RA][2], bf[NCB][2];
 
     auto read_A = [&](const unsigned char* stage, int qa) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned char* r = stage + fa + (qa * 64 + i * 16) * (BK * 2);
+        for (int i = 0; i < RA; ++i) {
+            const unsigned char* r = stage + fa + (qa * (WM / 2) + i * 16) * RB;
             af[i][0] = *reinterpret_cast<const f16x8*>(r + fk0);
             af[i][1] = *reinterpret_cast<const f16x8*>(r + fk1);
         }
     };
     auto read_B = [&](const unsigned char* stage, int qb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned char* r = stage + fb + (qb * 32 + j * 16) * (BK * 2);
-            bf[qb][j][0] = *reinterpret_cast<const f16x8*>(r + fk0);
-            bf[qb][j][1] = *reinterpret_cast<const f16x8*>(r + fk1);
+        for (int c = (qb ? CB0 : 0); c < (qb ? NCB : CB0); ++c) {
+            const unsigned char* r = stage + fb + c * 16 * RB;
+            bf[c][0] = *reinterpret_cast<const f16x8*>(r + fk0);
+            bf[c][1] = *reinterpret_cast<const f16x8*>(r + fk1);
         }
     };
 
     // ---- epilogue of one output tile, straight from the accumulators.  The MFMAs compute the TRANSPOSED product
-    // (B fragment as the first operand), so acc[qa][qb][i][j][e] = C[row qa*64 + i*16 + l15][col qb*32 + j*16 + 4*lg + e]
-    // inside the wave's 128x64: a lane holds 4 CONSECUTIVE COLUMNS of one row -> 16-byte fp32 / 8-byte fp16 accesses with
-    // no LDS transposition (the LDS pass of the other tiles costs ~9 instructions per element; here ~1), and GEGLU's
-    // value (qb = 0) and gate (qb = 1) of one output element sit in the same lane.
-    // The epilogue is straight-line code instantiated for 32 accumulator tiles, executed once per output tile: it must
-    // stay SMALL (a first version with a per-element activation switch and scalar fallbacks was 100 KB of code and
-    // cost 12 us per tile in instruction fetch).  Hence: 16-byte-aligned layouts only (the launcher sends anything else
-    // to the LDS-transposing tiles) and ONE activation formula  y = x * sigmoid(x * (c1 + c3 x^2))  for SiLU (1, 0),
-    // quick-GELU (1.702, 0) and tanh-GELU (2c, 2c*0.044715), or  y = max(x, lo)  for none (lo = -inf) / ReLU (lo = 0).
+    // (B fragment as the first operand), so acc[qa][i][c][e] = C[row qa*WM/2 + i*16 + l15][col c*16 + 4*lg + e] inside the
+    // wave's WM x WN: a lane holds 4 CONSECUTIVE COLUMNS of one row -> 16-byte fp32 / 8-byte fp16 accesses with no LDS
+    // transposition (the LDS pass of the other tiles costs ~9 instructions per element; here ~1), and GEGLU's value
+    // (column blocks 0,1) and gate (blocks 2,3 of the 256-wide tile) of one output element sit in the same lane.
+    // The epilogue is straight-line code instantiated per accumulator tile, executed once per output tile: it must stay
+    // SMALL (a first version with a per-element activation switch and scalar fallbacks was 100 KB of code and cost
+    // 12 us per tile in instruction fetch).  Hence: whole wave blocks and 16-byte-aligned layouts only (the launcher sends
+    // anything else to the LDS-transposing tiles) and ONE activation formula  y = x * sigmoid(x * (c1 + c3 x^2))  for SiLU
+    // (1, 0), quick-GELU (1.702, 0) and tanh-GELU (2c, 2c*0.044715), or  y = max(x, lo)  for none (lo = -inf) / ReLU (0).
     const bool geglu = p.act == MLSD_ACT_GEGLU;
     const bool act_sig = p.act == MLSD_ACT_SILU || p.act == MLSD_ACT_GELU || p.act == MLSD_ACT_GELU_QUICK;
     const float act_c1 = p.act == MLSD_ACT_SILU ? 1.0f : (p.act == MLSD_ACT_GELU_QUICK ? 1.702f : 2.0f * 0.7978845608028654f);
@@ -192,15 +236,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         }
         return v;
     };
-    // Launcher guarantees (else the LDS-transposing tiles run): M a multiple of 128 and N of 64 (a wave's 128x64 block is
-    // entirely inside or outside: one wave-uniform test, no per-lane guards), 16-byte aligned rows, and rows_per_batch a
-    // multiple of 256 (one row-bias vector per output tile).
-    // one 16-row block (qa, i) of the wave's tile; called with compile-time indices (a pragma-unrolled loop over the
-    // whole epilogue exceeds the unroller's size limit and would push the accumulators to scratch)
-    f32x4 cb[2][2];       // bias (+ row bias) of the lane's 4 column groups, loaded once per output tile
+    f32x4 cb[NCB];                                 // bias (+ row bias) of the lane's column groups, loaded once per output tile
+    f32x4 rpre[RESBATCH ? 2 * RA * NCB : 1];       // RESBATCH: the whole residual tile of the lane, fetched in one batch
     auto epi_rows = [&](auto QA, auto I, int wrow0, int wcol0) __attribute__((always_inline)) {
         constexpr int qa = decltype(QA)::value, i = decltype(I)::value;
-        const int m = wrow0 + qa * 64 + i * 16 + l15;
+        const int m = wrow0 + qa * (WM / 2) + i * 16 + l15;
         const float bm = p.biasm ? p.biasm[m] : 0.f;
         if (!geglu) {
             const long col = wcol0 + 4 * lg;
@@ -208,94 +248,104 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             float* c32 = p.C32 ? p.C32 + (long)m * p.ldc32 + col : nullptr;
             _Float16* c16 = p.C16 ? p.C16 + (long)m * p.ldc16 + col : nullptr;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int o = qb * 32 + j * 16;          // column offset inside the wave's 64 (an immediate)
-                    f32x4 v = acc[qa][qb][i][j] + cb[qb][j];
-                    v += bm;
-                    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
-                    if (rrow) rs = *reinterpret_cast<const f32x4*>(rrow + o);
-                    if (p.act_post) v += rs;
-                    v = act4(v);
-                    if (!p.act_post) v += rs;
-                    if (c32) *reinterpret_cast<f32x4*>(c32 + o) = v;
-                    if (c16) {
-                        f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *reinterpret_cast<f16x4*>(c16 + o) = h;
-                    }
+            for (int c = 0; c < NCB; ++c) {
+                f32x4 v = acc[qa][i][c] + cb[c];
+                v += bm;
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RESBATCH) { if (p.resid) rs = rpre[(qa * RA + i) * NCB + c]; }
+                else { if (rrow) rs = *reinterpret_cast<const f32x4*>(rrow + c * 16); }
+                if (p.act_post) v += rs;
+                v = act4(v);
+                if (!p.act_post) v += rs;
+                if (c32) *reinterpret_cast<f32x4*>(c32 + c * 16) = v;
+                if (c16) {
+                    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<f16x4*>(c16 + c * 16) = h;
                 }
             }
-        } else {
+        } else if constexpr (CB0 == 2 && CB1 == 2) {
             const long col = (wcol0 >> 6) * 32 + 4 * lg;     // value | gate column blocks of 32 are interleaved
             const float* rrow = p.resid ? p.resid + (long)m * p.ldr + col : nullptr;
             float* c32 = p.C32 ? p.C32 + (long)m * p.ldc32 + col : nullptr;
             _Float16* c16 = p.C16 ? p.C16 + (long)m * p.ldc16 + col : nullptr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int o = j * 16;
-                const f32x4 a4 = acc[qa][0][i][j] + cb[0][j], g4 = acc[qa][1][i][j] + cb[1][j];
+                const f32x4 a4 = acc[qa][i][j] + cb[j], g4 = acc[qa][i][2 + j] + cb[2 + j];
                 f32x4 v;
                 v[0] = a4[0] * gelu_tanh_f(g4[0]); v[1] = a4[1] * gelu_tanh_f(g4[1]);
                 v[2] = a4[2] * gelu_tanh_f(g4[2]); v[3] = a4[3] * gelu_tanh_f(g4[3]);
-                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + o);
-                if (c32) *reinterpret_cast<f32x4*>(c32 + o) = v;
+                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + j * 16);
+                if (c32) *reinterpret_cast<f32x4*>(c32 + j * 16) = v;
                 if (c16) {
                     f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *reinterpret_cast<f16x4*>(c16 + o) = h;
+                    *reinterpret_cast<f16x4*>(c16 + j * 16) = h;
                 }
             }
         }
     };
     auto epilogue = [&]() __attribute__((always_inline)) {
-        const int wrow0 = tcur.m0 + wr * 128, wcol0 = tcur.n0 + wc * 64;
-        if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % 128 == 0, N % 64 == 0: a wave's 128x64 is all in or all out
+        const int wrow0 = tcur.m0 + wr * WM, wcol0 = tcur.n0 + wc * WN;
+        if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % WM == 0, N % WN == 0: a wave's block is all in or all out
+        if constexpr (RESBATCH) {
+            if (p.resid) {
+#pragma unroll
+                for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                    for (int i = 0; i < RA; ++i)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c)
+                            rpre[(qa * RA + i) * NCB + c] = *reinterpret_cast<const f32x4*>(
+                                p.resid + (long)(wrow0 + qa * (WM / 2) + i * 16 + l15) * p.ldr + wcol0 + c * 16 + 4 * lg);
+            }
+        }
         const float* rbias = p.rowbias ? p.rowbias + (long)(tcur.m0 / p.rows_per_batch) * p.ldrb : nullptr;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = wcol0 + qb * 32 + j * 16 + 4 * lg;
-                f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) c = *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (rbias) c += *reinterpret_cast<const f32x4*>(rbias + n);
-                cb[qb][j] = c;
-            }
+        for (int c = 0; c < NCB; ++c) {
+            const int n = wcol0 + c * 16 + 4 * lg;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (rbias) v += *reinterpret_cast<const f32x4*>(rbias + n);
+            cb[c] = v;
+        }
         using std::integral_constant;
         epi_rows(integral_constant<int, 0>{}, integral_constant<int, 0>{}, wrow0, wcol0);
         epi_rows(integral_constant<int, 0>{}, integral_constant<int, 1>{}, wrow0, wcol0);
-        epi_rows(integral_constant<int, 0>{}, integral_constant<int, 2>{}, wrow0, wcol0);
-        epi_rows(integral_constant<int, 0>{}, integral_constant<int, 3>{}, wrow0, wcol0);
+        if constexpr (RA > 2) {
+            epi_rows(integral_constant<int, 0>{}, integral_constant<int, 2>{}, wrow0, wcol0);
+            epi_rows(integral_constant<int, 0>{}, integral_constant<int, 3>{}, wrow0, wcol0);
+        }
         epi_rows(integral_constant<int, 1>{}, integral_constant<int, 0>{}, wrow0, wcol0);
         epi_rows(integral_constant<int, 1>{}, integral_constant<int, 1>{}, wrow0, wcol0);
-        epi_rows(integral_constant<int, 1>{}, integral_constant<int, 2>{}, wrow0, wcol0);
-        epi_rows(integral_constant<int, 1>{}, integral_constant<int, 3>{}, wrow0, wcol0);
+        if constexpr (RA > 2) {
+            epi_rows(integral_constant<int, 1>{}, integral_constant<int, 2>{}, wrow0, wcol0);
+            epi_rows(integral_constant<int, 1>{}, integral_constant<int, 3>{}, wrow0, wcol0);
+        }
     };
 
     // ---- prologue: U1..U4 of stream position 0 and U1 of position 1 in flight; U1(0), U2(0) retired and visible
-    sa[0].par = sa[1].par = sb[0].par = sb[1].par = 0;
-    enter_A(sa[0], 0); enter_A(sa[1], 1); enter_B(sb[0], 0); enter_B(sb[1], 1);
+    sa[0].par = sa[1].par = sb2.par = sb3.par = 0;
+    enter_A(sa[0], 0); enter_A(sa[1], 1); enter_B2(sb2); enter_B3(sb3);
     tcur = tnext;
-    tnext = pp_tile_coords(p, (int)blockIdx.x + (ntile > 1 ? G : 0));   // past the end: any valid tile (staged, never read)
-    issue_A(sa[0], 0); issue_B(sb[0], 0); issue_B(sb[1], 1); issue_A(sa[1], 1); issue_A(sa[0], 0);
-    wait_vmcnt<6>();
+    tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x + (ntile > 1 ? G : 0));   // past the end: any valid tile (staged, never read)
+    issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1); issue_A(sa[0], 0);
+    wait_vmcnt<W4>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0 from here on
 
-#define MLSD_PP_PHASE(QA, QB, LOAD_A, LOAD_B, ISSUE, WAIT)                                                   \
+#define MLSD_PP_PHASE(QA, QB, LOAD_A, LOAD_B, ISSUE, WAITN)                                                  \
     {                                                                                                        \
         if (LOAD_B) read_B(stage, QB);                                                                       \
         if (LOAD_A) read_A(stage, QA);                                                                       \
         ISSUE;                                                                                               \
-        if (WAIT) wait_vmcnt<6>();                                                                           \
+        if (WAITN >= 0) wait_vmcnt<(WAITN >= 0 ? WAITN : 0)>();                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
-                    acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[QB][j][ks], af[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
+                _Pragma("unroll") for (int c = (QB ? CB0 : 0); c < (QB ? NCB : CB0); ++c)                    \
+                    acc[QA][i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[c][ks], af[i][ks], acc[QA][i][c], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
@@ -305,10 +355,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     int kt = 0, ti = 0;
     for (int s = 0; s < S; ++s) {
         const unsigned char* stage = smem + (s & 1) * STAGE;
-        MLSD_PP_PHASE(0, 0, true, true, issue_B(sb[0], 0), true)
-        MLSD_PP_PHASE(0, 1, false, true, issue_B(sb[1], 1), true)
-        MLSD_PP_PHASE(1, 1, true, false, issue_A(sa[1], 1), false)
-        MLSD_PP_PHASE(1, 0, false, false, issue_A(sa[0], 0), true)
+        MLSD_PP_PHASE(0, 0, true, true, issue_B2(), W1)
+        MLSD_PP_PHASE(0, 1, false, true, issue_B3(), W2)
+        MLSD_PP_PHASE(1, 1, true, false, issue_A(sa[1], 1), -1)
+        MLSD_PP_PHASE(1, 0, false, false, issue_A(sa[0], 0), W4)
         if (++kt == nkt) {
             // seam: the next output tile's first units are in flight / landed; nothing is drained.  The groups
             // rejoin (group 0's extra barrier pairs with group 1's last one) so that all 8 waves run their
@@ -318,10 +368,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             zero_acc();
             kt = 0; ++ti;
             tcur = tnext;                                  // every sequence has entered tile ti by now (K >= 3 K tiles)
-            tnext = pp_tile_coords(p, (int)blockIdx.x + (ti + 1 < ntile ? ti + 1 : 0) * G);
+            tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x + (ti + 1 < ntile ? ti + 1 : 0) * G);
             if (s + 1 < S && wr == 1) __builtin_amdgcn_s_barrier();
         }
     }
 #undef MLSD_PP_PHASE
-    wait_vmcnt<0>();                               // the zero-page tail stages still target this block's LDS
+    wait_vmcnt<0>();                               // the tail stages (clamped rows) still target this block's LDS
 }

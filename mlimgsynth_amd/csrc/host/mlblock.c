@@ -471,11 +471,12 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		}
 	}
 	/* candidates: (tile variant, K slices) */
-	int cv[16], cs[16], nc = 0;
+	int cv[24], cs[24], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
 		/* persistent ping-pong 256x256 tile: linear problems made of whole 128x64 wave blocks (anything else it would hand to variant 9) */
 		if (!g->conv && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63) && !(g->K & 63) && g->K >= 192) { cv[nc]=17; cs[nc++]=1; }
+		if (!g->conv && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && !(g->K & 63) && g->K >= 192 && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; }
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
@@ -496,7 +497,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 				int s = (int)((targets[ti] + tiles / 2) / tiles);
 				if (s > nkt / 2) s = nkt / 2;               /* >= 2 K tiles per slice */
 				while (s > 1 && (size_t)s * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) --s;
-				if (s <= last || nc >= 16) continue;
+				if (s <= last || nc >= 24) continue;
 				cv[nc] = v; cs[nc++] = s; last = s;
 			}
 		}

@@ -153,7 +153,7 @@ def test_gemm_rejects_bad_args(K):
         kernels.gemm(a)
 
 
-BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16, 17]   # kVariants[] indices instantiated by the default build (gemm_conv.hip)
+BUILT_TILE_VARIANTS = [0, 1, 3, 4, 9, 16, 17, 18]   # kVariants[] indices instantiated by the default build (gemm_conv.hip)
 
 
 @pytest.mark.parametrize("variant", BUILT_TILE_VARIANTS)
@@ -205,8 +205,10 @@ def test_conv2d_every_tile_variant(K, variant):
 
 
 @pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320),
-                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448)])
-def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
+                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640),
+                                    (131072, 320, 320), (192, 960, 1280)])
+@pytest.mark.parametrize("pp", [17, 18])
+def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
     """The two-group ping-pong kernel (gemm_pp.hpp) against the 16-wave 256x256 kernel on long K and many tiles,
     repeated: its RAW/WAR ordering rests on counted waits and barrier parity, so a race would show as rare
     wrong tiles."""
@@ -221,20 +223,26 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd):
     ref = d9.download((M, N), np.float32)
     exact = A.astype(np.float32) @ W.astype(np.float32).T
     assert rel(ref, exact) < 2e-5
+    if (pp == 18 and (N % 80 or M % 64)) or (pp == 17 and (N % 64 or M % 128)):
+        pytest.skip("the ping-pong tiles take whole wave blocks (128x64 / 64x80)")
+    assert "pp" in kernels.gemm_variant(mk(d17, pp))
     for rep in range(6):
-        kernels.gemm(mk(d17, 17))
+        kernels.gemm(mk(d17, pp))
         got = d17.download((M, N), np.float32)
         assert rel(got, exact) < 2e-5, rep
         assert np.abs(got - ref).max() < 1e-3, rep
 
 
+@pytest.mark.parametrize("pp", [17, 18])
 @pytest.mark.parametrize("mode", ["bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm"])
-def test_gemm_pingpong_epilogues(K, mode):
+def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
     here -- the multi-tile stream is covered by test_gemm_pingpong_tile_matches_plain_tile."""
     kernels, _lib = K
-    M, N, Kd = 1536, 768, 448
+    if pp == 18 and mode == "geglu_f16":
+        pytest.skip("GEGLU pairs 32-column blocks: 256-wide tile only")
+    M, N, Kd = (1536, 768, 448) if pp == 17 else (1536, 960, 448)
     rng = np.random.default_rng(len(mode))
     A = f16r(rng.standard_normal((M, Kd)))
     W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
@@ -243,7 +251,7 @@ def test_gemm_pingpong_epilogues(K, mode):
     y = O.from_ot(O.L().orc_linear(O.to_ot(A.reshape(1, 1, M, Kd)), P.set("w", W, f16=True), P.set("b", bias))).reshape(M, N)
     gelu = lambda v: 0.5 * v * (1 + np.tanh(0.7978845608028654 * v * (1 + 0.044715 * v * v)))
     dA, dB = dev(_lib, A.astype(np.float16)), dev(_lib, bias)
-    kw = dict(A=dA.ptr, lda=Kd, conv=0, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=18)
+    kw = dict(A=dA.ptr, lda=Kd, conv=0, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=pp + 1)
     nout, keep = N, []
     if mode == "geglu_f16":
         d = N // 2
