@@ -617,7 +617,8 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
 // tile of the same shape (9 / 16)
 bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
-    if (a->conv || (a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
+    if ((a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
+    if (a->conv && (a->upsample || (a->Cin & 63) || a->KH * a->KW > 9)) return false;   // a K tile must lie inside one filter tap
     if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) % BM)) return false;
     if (a->act == MLSD_ACT_GEGLU && BN != 256) return false;
     const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
@@ -646,10 +647,12 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
     const dim3 grid(ntiles < 256 ? ntiles : 256), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
-    auto kfn = gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH>;
-    MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
-    return mlsd_check_launch("gemm_pp_kernel");
+    auto go = [&](auto kfn) -> int {
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+        return mlsd_check_launch("gemm_pp_kernel");
+    };
+    return a->conv ? go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true>) : go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false>);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)

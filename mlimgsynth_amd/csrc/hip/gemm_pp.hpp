@@ -64,7 +64,7 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
 // tiles ahead, must enter output tile ti+1 while the MFMAs are in tile ti): the per-phase staging code is LDS-DMA
 // instructions on running row pointers and nothing else (out-of-range rows are CLAMPED to the last valid row instead of
 // zero-filled: their products land in output rows/columns that are never stored).
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH>
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     // One iterator per unit sequence: U1 runs two K tiles ahead of the MFMAs, U2..U4 one.  Each holds running row
     // pointers (this thread's chunk of the current K tile) for the output tile it is staging for; all of them enter
     // output tile ti+1 while the MFMAs are still in tile ti, so "the next tile" is one shared coordinate pair.
-    struct SeqA { int kt, par; const _Float16* ptr[NU1]; };
+    // CONV (3x3 / 1x1, stride 1 / 2, no upsample, Cin % 64 == 0): a K tile lies inside ONE filter tap, so the tap and the
+    // channel offset are block-uniform (scalar); a row keeps the address of its output pixel's top-left input pixel
+    // and a 9-bit mask of the taps that fall inside the image; padded taps read the zero page.
+    struct SeqA { int kt, par; const _Float16* ptr[NU1]; int mask[CONV ? NU1 : 1]; int kh, kw, cin; };
     struct SeqB2 { int kt, par; const _Float16* ptr[NU2]; };
     struct SeqB3 { int kt, par; const _Float16* ptr[NU3]; };
     SeqA sa[2];    // [0] = U1, [1] = U4
@@ -113,13 +116,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     SeqB3 sb3;     // U3
     PPTile tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x);   // coordinates the sequences use at their next tile entry
     PPTile tcur = tnext;                                         // tile of the MFMAs / next epilogue
+    const _Float16* zsrc = reinterpret_cast<const _Float16*>(g_zero_page);
 
     auto enter_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
-        s.kt = 0;
+        s.kt = 0; s.kh = 0; s.kw = 0; s.cin = 0;
 #pragma unroll
         for (int it = 0; it < NU1; ++it) {
             const int r = a_row0(it, second) + (lane >> 3);
-            s.ptr[it] = p.A + (long)min(tnext.m0 + r, p.M - 1) * p.lda + chunk_of(r);
+            const int m = min(tnext.m0 + r, p.M - 1);
+            if constexpr (CONV) {
+                const int ohw = p.OH * p.OW;
+                const int img = m / ohw, rem = m - img * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+                int mk = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= 1 << (kh * p.KW + kw);
+                s.mask[it] = mk;
+                s.ptr[it] = p.A + ((long)img * p.H * p.W + (long)ih0 * p.W + iw0) * p.lda + chunk_of(r);
+            } else {
+                s.ptr[it] = p.A + (long)m * p.lda + chunk_of(r);
+            }
         }
     };
     auto enter_B2 = [&](SeqB2& s) __attribute__((always_inline)) {
@@ -140,14 +158,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     };
     auto issue_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
         unsigned char* stage = smem + s.par * STAGE;
+        const long toff = CONV ? ((long)s.kh * p.W + s.kw) * p.lda + s.cin : 0;      // scalar: tap + channel offset of this K tile
+        const int tbit = CONV ? 1 << (s.kh * p.KW + s.kw) : 0;
 #pragma unroll
         for (int it = 0; it < NU1; ++it) {
             unsigned char* dst = stage + a_row0(it, second) * RB;                  // wave-uniform: 8 rows, lane-linear
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s.ptr[it],
+            const _Float16* src = s.ptr[it];
+            if constexpr (CONV) src = (s.mask[it] & tbit) ? s.ptr[it] + toff : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            s.ptr[it] += BK;
+            if constexpr (!CONV) s.ptr[it] += BK;
         }
         s.par ^= 1;
+        if constexpr (CONV) { s.cin += BK; if (s.cin == p.Cin) { s.cin = 0; if (++s.kw == p.KW) { s.kw = 0; ++s.kh; } } }
         if (++s.kt == nkt) enter_A(s, second);
     };
     auto issue_B2 = [&]() __attribute__((always_inline)) {

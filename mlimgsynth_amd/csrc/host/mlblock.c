@@ -474,9 +474,11 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	int cv[24], cs[24], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
-		/* persistent ping-pong 256x256 tile: linear problems made of whole 128x64 wave blocks (anything else it would hand to variant 9) */
-		if (!g->conv && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63) && !(g->K & 63) && g->K >= 192) { cv[nc]=17; cs[nc++]=1; }
-		if (!g->conv && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && !(g->K & 63) && g->K >= 192 && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; }
+		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
+		 * one filter tap (anything else they would hand to the LDS-transposing tile of the same shape anyway) */
+		const int pp_ok = !(g->K & 63) && g->K >= 192 && (!g->conv || (!g->upsample && !(g->Cin & 63)));
+		if (pp_ok && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63)) { cv[nc]=17; cs[nc++]=1; }
+		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; }
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);

@@ -291,6 +291,42 @@ def test_gemm_pingpong_epilogues(K, mode, pp):
     assert rel(dC16.download((M, nout), np.float16).astype(np.float32), ref) < 1e-3
 
 
+@pytest.mark.parametrize("pp", [17, 18])
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 16, 16, 64, 320, 3, 1), (1, 32, 32, 128, 640, 3, 2), (2, 16, 8, 192, 320, 1, 1),
+                                                 (4, 32, 32, 64, 1280, 3, 1)])
+def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
+    """Implicit-GEMM conv on the ping-pong tiles (tap-uniform K tiles, per-row tap masks, zero page for padding) vs the
+    oracle conv; time-embedding row bias and fp32 residual on."""
+    kernels, _lib = K
+    rng = np.random.default_rng(cin + cout + k)
+    pad = k // 2
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    P = O.Params()
+    pw, pb = P.set("w", wt, f16=True), P.set("b", bias)
+    ref = np.stack([O.from_ot(O.L().orc_conv2d(O.to_ot(x[i:i + 1]), pw, pb, s, pad))[0] for i in range(n)])
+    oh, ow = ref.shape[2], ref.shape[3]
+    M = n * oh * ow
+    rowb = rng.standard_normal((n, cout)).astype(np.float32)
+    res = rng.standard_normal((M, cout)).astype(np.float32)
+    use_rb = (oh * ow) % (256 if pp == 17 else 128) == 0
+    ref = ref + (rowb[:, :, None, None] if use_rb else 0) + res.reshape(n, oh, ow, cout).transpose(0, 3, 1, 2)
+    dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    dW, dB, dRB, dR = dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias), dev(_lib, rowb), dev(_lib, res)
+    dC = _lib.DeviceBuffer(M * cout * 4)
+    a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=oh, OW=ow, KH=k, KW=k, stride=s, pad=pad,
+                         W_=dW.ptr, ldb=k * k * cin, M=M, N=cout, K=k * k * cin, bias=dB.ptr, rowbias=dRB.ptr if use_rb else None,
+                         rows_per_batch=oh * ow, ldrb=cout, resid=dR.ptr, ldr=cout, C32=dC.ptr, ldc32=cout, tile_variant=pp + 1)
+    if (M % (128 if pp == 17 else 64)) or (cout % (64 if pp == 17 else 80)) or k * k * cin < 192:
+        pytest.skip("not made of whole wave blocks for this tile")
+    assert "pp" in kernels.gemm_variant(a)
+    for rep in range(3):
+        kernels.gemm(a)
+        got = dC.download((n, oh, ow, cout), np.float32).transpose(0, 3, 1, 2)
+        assert rel(got, ref) < 2e-5, rep
+
+
 def test_gemm_geglu_rejected_on_odd_slab_tile(K):
     kernels, _lib = K
     a = kernels.GemmArgs(A=16, lda=64, W_=16, ldb=64, M=128, N=128, K=64, C32=16, ldc32=64, act=kernels.ACT_GEGLU, tile_variant=17)
