@@ -5,7 +5,7 @@
 // permutes around it (src/mlblock_nn.c:204-227).  Here the scores never leave the CU:
 //
 //   block = 4 wavefronts = 128 query rows of one (batch, head); each wave owns 32 query rows.
-//   per 64-key tile (K and V staged global -> registers -> LDS, shared by the 4 waves):
+//   per 64-key tile (K and V staged global -> registers -> LDS, double-buffered, one barrier per tile, shared by the 4 waves):
 //     S^T[key][q] = K . Q^T          v_mfma_f32_32x32x16_f16, A = K rows from LDS (ds_read_b128),
 //                                    B = Q fragments kept in registers for the whole kernel.
 //                                    Swapped product: the key index lands in the 16 accumulator
@@ -38,7 +38,9 @@ struct AttnP {
 };
 
 template <int DH>
-__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const AttnP p)
+// waves_per_eu caps the occupancy the register allocator aims for: left free it chose 4 waves/SIMD (128 VGPRs) and
+// spilled the K/V staging registers to scratch inside the loop
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, (DH <= 80 ? 3 : 1)))) void attn_kernel(const AttnP p)
 {
     constexpr int DQK = (DH + 15) / 16 * 16;       // QK^T reduction length (zero padded)
     constexpr int NKS = DQK / 16;
@@ -49,8 +51,10 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
     constexpr int IT = (64 * CH + 255) / 256;
     static_assert(DH % 8 == 0, "d_head must be a multiple of 8");
 
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KSTR];
-    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * VSTR];
+    // two K/V tile buffers: tile t+1 is written (registers -> LDS) into the buffer tile t-1 vacated, so ONE barrier per
+    // tile orders both the reads of tile t and the writes of tile t+1
+    __shared__ __attribute__((aligned(16))) unsigned char Ks2[2][64 * KSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs2[2][64 * VSTR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -63,8 +67,8 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
     const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
 
     // zero the LDS once: padding columns stay zero for the whole kernel
-    for (int i = tid * 16; i < 64 * KSTR; i += 256 * 16) *reinterpret_cast<uint4*>(Ks + i) = make_uint4(0, 0, 0, 0);
-    for (int i = tid * 16; i < 64 * VSTR; i += 256 * 16) *reinterpret_cast<uint4*>(Vs + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid * 16; i < 2 * 64 * KSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Ks2[0][0] + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid * 16; i < 2 * 64 * VSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Vs2[0][0] + i) = make_uint4(0, 0, 0, 0);
 
     // Q fragments (B operand of S^T = K.Q^T): lane (lr = query, lh) holds Q[q][16*ks + 8*lh + j]
     f16x8 qf[NKS];
@@ -87,21 +91,43 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
     if (p.causal) { const int lim = (min(q0 + 128, p.Tq) + 63) / 64; nt = min(nt, lim); }
 
     uint4 rk[IT], rv[IT];
+    // K/V rows past Tk are CLAMPED to the last key instead of zero-filled: their scores are masked to -1e30 (P = 0), so
+    // finite duplicate data is as good as zeros and the loop carries no predication, zero fills or exec-mask branches.
+    // Full tiles are fetched through running pointers (one 64-bit add per load); only a ragged last tile recomputes
+    // clamped addresses.  (Threads past the tile's last chunk re-load the last chunk; loads go through temporaries:
+    // assigned directly, the staging arrays were demoted to scratch/LDS by the compiler.)
+    const _Float16* kp[IT];
+    const _Float16* vp[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = (IT * 256 > 64 * CH) ? min(tid + it * 256, 64 * CH - 1) : tid + it * 256;
+        kp[it] = Kg + (long)(idx / CH) * p.ldk + (idx % CH) * 8;
+        vp[it] = Vg + (long)(idx / CH) * p.ldv + (idx % CH) * 8;
+    }
     auto load_kv = [&](int t) {
         const int kv0 = t * 64;
+        if (kv0 + 64 <= p.Tk) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int idx = tid + it * 256;
-            const int row = idx / CH, ch = idx % CH;
-            uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
-            if (idx < 64 * CH && kv0 + row < p.Tk) {
-                a = *reinterpret_cast<const uint4*>(Kg + (long)(kv0 + row) * p.ldk + ch * 8);
-                c = *reinterpret_cast<const uint4*>(Vg + (long)(kv0 + row) * p.ldv + ch * 8);
+            for (int it = 0; it < IT; ++it) {
+                const uint4 a = *reinterpret_cast<const uint4*>(kp[it] + (long)kv0 * p.ldk);
+                const uint4 c = *reinterpret_cast<const uint4*>(vp[it] + (long)kv0 * p.ldv);
+                rk[it] = a; rv[it] = c;
             }
-            rk[it] = a; rv[it] = c;
+        } else {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = (IT * 256 > 64 * CH) ? min(tid + it * 256, 64 * CH - 1) : tid + it * 256;
+                const int row = idx / CH, ch = idx % CH;
+                const long r = min(kv0 + row, p.Tk - 1);
+                const uint4 a = *reinterpret_cast<const uint4*>(Kg + r * p.ldk + ch * 8);
+                const uint4 c = *reinterpret_cast<const uint4*>(Vg + r * p.ldv + ch * 8);
+                rk[it] = a; rv[it] = c;
+            }
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
+        unsigned char* Ks = Ks2[buf];
+        unsigned char* Vs = Vs2[buf];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = tid + it * 256;
@@ -115,7 +141,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
 
     load_kv(0);
     __syncthreads();   // LDS zero-fill complete
-    store_kv();
+    store_kv(0);
     __syncthreads();
 
     // transposed-read lane address pattern (probe-verified): group g = lane>>4, idx = lane&15
@@ -125,22 +151,30 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
 
     for (int t = 0; t < nt; ++t) {
         const int kv0 = t * 64;
+        const unsigned char* Ks = Ks2[t & 1];
+        const unsigned char* Vs = Vs2[t & 1];
         if (t + 1 < nt) load_kv(t + 1);
 
-        // ---- S^T = K . Q^T  (two 32-key sub-tiles; the second is skipped when it holds no key at all,
-        //      e.g. keys 64..76 of the 77-token cross attention live in sub-tile 0 of tile 1)
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles; sub1: the second holds at least one key -- when not, e.g. keys
+        //      64..76 of the 77-token cross attention live in sub-tile 0 of tile 1, its P.V products are skipped)
         const bool sub1 = kv0 + 32 < p.Tk;                                   // wave-uniform
+        // The two accumulators are separate SSA values whose MFMA chains start from an inline zero: as an array
+        // initialised to zero ahead of a conditional chain the compiler materialised 32 zeros and copied 32 result
+        // registers per tile (a quarter of the loop's VALU instructions).
         f32x16 sacc[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
-            if (kt == 1 && !sub1) continue;
+        {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 r0 = zero, r1 = zero;
+            // both sub-tiles, also when the second holds no key (rows >= Tk are clamped duplicates; masked below): no
+            // branch, no fill; the two accumulation chains alternate so that no MFMA waits for its predecessor's result
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (32 * kt + lr) * KSTR + (16 * ks + 8 * lh) * 2);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kt], 0, 0, 0);
+                const f16x8 k0 = *reinterpret_cast<const f16x8*>(Ks + lr * KSTR + (16 * ks + 8 * lh) * 2);
+                const f16x8 k1 = *reinterpret_cast<const f16x8*>(Ks + (32 + lr) * KSTR + (16 * ks + 8 * lh) * 2);
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], r1, 0, 0, 0);
             }
+            sacc[0] = r0; sacc[1] = r1;
         }
         // ---- online softmax over the key axis (registers + one cross-half exchange).
         // Raw scores stay unscaled: p = exp2(s*sc - m*sc) is ONE fma + v_exp per element.  Masking only in
@@ -207,11 +241,11 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_kernel(const Att
                 }
             }
         }
-        __syncthreads();   // every wave is done reading this tile
-        if (t + 1 < nt) {
-            store_kv();
-            __syncthreads();
-        }
+        // keep the registers -> LDS copy HERE (a full tile of MFMA/softmax work after the loads were issued): left free,
+        // the scheduler hoists it up to the loads and waits for them on the spot
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) store_kv((t + 1) & 1);   // the buffer tile t-1 used: every wave passed the previous barrier after reading it
+        __syncthreads();                         // tile t+1 visible; every wave is done reading tile t
     }
 
     // ---- epilogue: O = O^T / l, heads merged.  oacc[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
