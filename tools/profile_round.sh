@@ -13,12 +13,14 @@ for f in $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1); do cp $f $OUT/
 find $OUT/kt_$WL -name "*kernel_trace.csv" -delete
 # HBM-side counters: one pass each, with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 # Target: tools/unet_eval.py = the same UNet plan (same shapes, same tuned kernels) evaluated 10x on the NULL stream;
+# (a WRITE_SIZE pass occasionally hangs at start-up on this pool: hence the short timeout -- re-run the pass, the summary
+# is only written when both passes produced counters)
 # rocprofv3's counter service segfaults at the first launch on the engine's own HIP stream when bench.py itself is
 # the target (ROCm 7.2), and bench.py's roofline is per launch of a UNet evaluation anyway.
 case $WL in sdxl) UARGS="sdxl 128 $((2*B)) 10";; sd15) UARGS="sd1 64 $((2*B)) 10";; *) UARGS="$WL 8 $((2*B)) 10";; esac
 if [ "${SKIP_KT:-0}" = "1" ]; then :; fi
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${C}_$WL -- python3 $R/tools/unet_eval.py $UARGS > $OUT/pmc_${C}_$WL.log 2>&1 < /dev/null
+  timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${C}_$WL -- python3 $R/tools/unet_eval.py $UARGS > $OUT/pmc_${C}_$WL.log 2>&1 < /dev/null
 done
 F=$(find $OUT/pmc_FETCH_SIZE_$WL -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE_$WL -name "*counter_collection.csv" | head -1)
 if [ -n "$F" ] && [ -n "$W" ]; then python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_b${B}_pmc_traffic.json "$F" "$W"; fi
