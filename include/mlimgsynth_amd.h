@@ -72,11 +72,14 @@ MLTensor* mlb_sdvae_decoder(MLCtx* C, MLTensor* x, const VaeParams* P);
 int sdvae_decode_init(MLCtx* C, const VaeParams* P, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent);
 /* host-boundary decode incl. the (x+1)/2 post (src/vae.h:43-47): latent NCHW [n][4][lh][lw] -> img [n][3][8lh][8lw] */
 int sdvae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img);
+/* graph build + prep only (the driver binds the resident latent and calls mlctx_compute itself) */
+int sdvae_decode_build(MLCtx* C, const VaeParams* P, MLTensor* t_latent);
 
 typedef struct { int ch_x, ch_inner, ch_z, n_blk; } SdTaeParams;
 MLTensor* mlb_sdtae_decoder(MLCtx* C, MLTensor* x, const SdTaeParams* P);
 int sdtae_decode_init(MLCtx* C, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent);
 int sdtae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img);
+int sdtae_decode_build(MLCtx* C, MLTensor* t_latent);
 
 /* ---------------------------------------------------------------- CLIP text encoder (src/clip.h) */
 typedef struct {

@@ -108,7 +108,8 @@ int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
 /* tile order inside an XCD's range: column panels `mode` tiles wide (default 8; 0 = row-major).  A/B timing knob. */
-void mlsd_gemm_set_mode(int mode);
+void mlsd_gemm_set_panel(int width);
+void mlsd_gemm_set_mode(int mode);     /* older name of mlsd_gemm_set_panel */
 /* diagnostics: force a tile variant (-1 = automatic choice) / the scalar epilogue (1) instead of the wide one (0) */
 void mlsd_gemm_force_variant(int v);
 int mlsd_gemm_num_variants(void);

@@ -8,7 +8,13 @@
 // :105-126).  K is ordered (kh, kw, cin) with cin fastest so a 16-byte chunk of A is 8
 // consecutive channels of one input pixel: coalesced NHWC loads, no im2col buffer in HBM.
 //
-// Structure (one block = WAVES_M x WAVES_N wavefronts of 64 lanes):
+// Two kernel families share this file's launcher, argument struct and tile-variant table:
+//   gemm_pp_kernel (gemm_pp.hpp)  persistent two-group "ping-pong" tiles, register-direct epilogue: the default for
+//                                 every problem made of whole wave blocks (linear, and conv with Cin % 64 == 0);
+//   gemm_kernel (below)           general tiles: ragged M/N/K, padded channels, upsampled conv sources, split-K, GEGLU
+//                                 on narrow outputs, unaligned layouts.
+//
+// Structure of gemm_kernel (one block = WAVES_M x WAVES_N wavefronts of 64 lanes):
 //   * A and B tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no
 //     ds_write); padded / out-of-range chunks read a 16-byte zero page.  The LDS image is lane-linear
 //     per wave-instruction, so the bank-conflict XOR swizzle is applied to the SOURCE chunk index
@@ -747,7 +753,8 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     }
 }
 
-MLSD_API void mlsd_gemm_set_mode(int mode) { g_gemm_panel = mode < 0 ? 0 : mode; }   /* tile-order panel width (A/B timing) */
+MLSD_API void mlsd_gemm_set_panel(int width) { g_gemm_panel = width < 0 ? 0 : width; }   /* tile-order panel width (A/B timing) */
+MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }

@@ -17,8 +17,6 @@
 #include <math.h>
 
 int unet_denoise_build(UnetState* S);
-int sdvae_decode_build(MLCtx* C, const VaeParams* P, MLTensor* t_latent);
-int sdtae_decode_build(MLCtx* C, MLTensor* t_latent);
 
 #define MAX_STEPS 256
 

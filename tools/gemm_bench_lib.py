@@ -14,7 +14,7 @@ vp = _lib.vp
 def time_gemm(M, N, K, variant, mode=0, reps=20, check=False, conv=None):
     rng = np.random.default_rng(0)
     L.mlsd_gemm_force_variant(variant)
-    L.mlsd_gemm_set_mode(mode)
+    L.mlsd_gemm_set_panel(mode)
     if conv:
         n, h, w, cin, cout, k = conv
         A = rng.standard_normal((n, h, w, cin)).astype(np.float16)

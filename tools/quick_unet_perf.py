@@ -7,7 +7,7 @@ from mlimgsynth_amd import engine, _lib
 model, lat, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 import os
-_lib.lib().mlsd_gemm_set_mode(int(os.environ.get('GEMM_MODE', '8')))
+_lib.lib().mlsd_gemm_set_panel(int(os.environ.get('GEMM_MODE', '8')))
 t0 = time.time()
 un = engine.Unet(model, lat, lat, n, flags=flags)
 info = un.ctx.info()
