@@ -327,6 +327,29 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
         assert rel(got, ref) < 2e-5, rep
 
 
+@pytest.mark.parametrize("pp,M,N,Kd", [(17, 4096, 2560, 1280), (18, 8192, 1280, 1280), (17, 8192, 5120, 320), (18, 32768, 640, 640)])
+def test_gemm_pingpong_is_bit_repeatable(K, pp, M, N, Kd):
+    """Race screen: the ping-pong kernels order LDS-DMA writes, fragment reads and restaging only through counted waits
+    and barrier parity, and have no atomics -- so 40 launches on the same operands must give bit-identical outputs
+    (a RAW/WAR race shows up as rare differing tiles; cdna_hip_programming.md: place reads by the count, never by clean runs)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(pp + M)
+    dA = dev(_lib, rng.standard_normal((M, Kd)).astype(np.float16))
+    dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+    dR = dev(_lib, rng.standard_normal((M, N)).astype(np.float32))
+    dC = _lib.DeviceBuffer(M * N * 2)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, resid=dR.ptr, ldr=N, act=1, C16=dC.ptr, ldc16=N,
+                         tile_variant=pp + 1)
+    assert "pp" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    first = dC.download((M, N), np.float16).view(np.uint16).copy()
+    for rep in range(40):
+        kernels.gemm(a)
+        if rep % 8 == 7:
+            assert np.array_equal(dC.download((M, N), np.float16).view(np.uint16), first), rep
+    assert np.array_equal(dC.download((M, N), np.float16).view(np.uint16), first)
+
+
 def test_gemm_geglu_rejected_on_odd_slab_tile(K):
     kernels, _lib = K
     a = kernels.GemmArgs(A=16, lda=64, W_=16, ldb=64, M=128, N=128, K=64, C32=16, ldc32=64, act=kernels.ACT_GEGLU, tile_variant=17)

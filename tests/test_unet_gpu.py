@@ -91,3 +91,24 @@ def test_unet_sd15_real_config_small_latent():
     err = [rel(got[i], ref[i]) for i in range(n)]
     print("sd1 16x16 per-image rel-L2:", err)
     assert max(err) < TOL
+
+
+def test_unet_sdxl_eval_is_bit_repeatable_and_finite():
+    """The full-size SDXL plan (batch 2, 32x32 latent: every tuned tile, split-K, ping-pong kernels, attention shapes of
+    the real model) evaluated 4 times on the same inputs: no atomics anywhere on the path, so the outputs must be
+    bit-identical (race screen for the whole plan) and finite."""
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(3)
+    n, lat = 2, 32
+    un = engine.Unet("sdxl", lat, lat, n)
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.array([7.0, 0.5], np.float32)
+    un.run(x, cond, label, sigma)                 # first evaluation autotunes
+    first = un.run(x, cond, label, sigma)
+    assert np.isfinite(first).all() and np.abs(first).max() > 0
+    for _ in range(3):
+        again = un.run(x, cond, label, sigma)
+        assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
