@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     const _Float16* Kg = p.k + (long)b * p.bsk + (long)head * DH;
     const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
 
-    // zero the LDS once: padding columns stay zero for the whole kernel
-    for (int i = tid * 16; i < 2 * 64 * KSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Ks2[0][0] + i) = make_uint4(0, 0, 0, 0);
-    for (int i = tid * 16; i < 2 * 64 * VSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Vs2[0][0] + i) = make_uint4(0, 0, 0, 0);
+    // zero the LDS once: padding columns (d_head not a multiple of 16 / 32) stay zero for the whole kernel; at d_head 32, 64,
+    // 160 every column the MFMAs read is data and the fill (a fixed cost per block that dominates 77-key cross attention) is skipped
+    if constexpr (DQK != DH || NDV * 32 != DH) {
+        for (int i = tid * 16; i < 2 * 64 * KSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Ks2[0][0] + i) = make_uint4(0, 0, 0, 0);
+        for (int i = tid * 16; i < 2 * 64 * VSTR; i += 256 * 16) *reinterpret_cast<uint4*>(&Vs2[0][0] + i) = make_uint4(0, 0, 0, 0);
+    }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (lr = query, lh) holds Q[q][16*ks + 8*lh + j]
     f16x8 qf[NKS];
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     };
 
     load_kv(0);
-    __syncthreads();   // LDS zero-fill complete
+    if constexpr (DQK != DH || NDV * 32 != DH) __syncthreads();   // LDS zero-fill complete
     store_kv(0);
     __syncthreads();
 
