@@ -112,3 +112,29 @@ def test_unet_sdxl_eval_is_bit_repeatable_and_finite():
     for _ in range(3):
         again = un.run(x, cond, label, sigma)
         assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
+
+
+@pytest.mark.skipif(__import__("os").environ.get("MLSD_FULL_SIZE") != "1",
+                    reason="2+ minutes of host time for the CPU oracle: run with MLSD_FULL_SIZE=1 (measured 1.21e-3, DESIGN.md section 5)")
+def test_unet_sdxl_headline_size_parity():
+    """BASELINE.json's headline shape itself: ONE SDXL UNet evaluation at the 128x128 latent of a 1024x1024 image (2567.5 M
+    synthetic parameters, 6.76 TFLOP) against the oracle's CPU restatement (about half a minute of host time on the
+    GPU box).  Same stated tolerance as the small cases."""
+    import os
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(11)
+    lat = 128
+    O.L().orc_set_threads(min(os.cpu_count() or 8, 128))
+    un = engine.Unet("sdxl", lat, lat, 1)
+    P = un.P
+    x = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 4
+    cond = rng.standard_normal((1, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((1, P.ch_adm_in)).astype(np.float32)
+    sigma = np.array([3.0], np.float32)
+    un.run(x, cond, label, sigma)                 # first evaluation autotunes (timing launches run on live operands)
+    got = un.run(x, cond, label, sigma)
+    ref, _ = oracle_eval("sdxl", x, cond, label, sigma)
+    err = rel(got[0], ref[0])
+    print("sdxl 128x128 rel-L2:", err)
+    assert np.isfinite(got).all()
+    assert err < TOL
