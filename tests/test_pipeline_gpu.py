@@ -47,6 +47,26 @@ def test_vae_decode_sd_real_config():
     assert err < 4e-3
 
 
+@pytest.mark.skipif(__import__("os").environ.get("MLSD_FULL_SIZE") != "1",
+                    reason="about a minute of host time for the CPU oracle: run with MLSD_FULL_SIZE=1 (result in DESIGN.md section 5)")
+def test_vae_decode_512_parity():
+    """configs[1]'s decode at full size: the real SD1.5 KL decoder, 64x64 latent -> 512x512 image (2.5 TFLOP), vs the oracle."""
+    import os
+    from mlimgsynth_amd import engine
+    O.L().orc_set_threads(min(os.cpu_count() or 8, 128))
+    rng = np.random.default_rng(5)
+    lat = 64
+    z = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 0.5
+    dec = engine.Decoder("sd1", lat, lat, 1)
+    dec.run(z)
+    got = dec.run(z)
+    V, P = O.vae_params("sd1"), O.Params(1234)
+    ref = O.from_ot(O.L().orc_vae_decode(P.h, b"vae", V, O.to_ot(z)))
+    err = rel(got - 0.5, ref - 0.5)
+    print("vae sd1 512x512 rel-L2", err)
+    assert np.isfinite(got).all() and err < 4e-3
+
+
 def test_tae_decode_parity():
     from mlimgsynth_amd import engine
     rng = np.random.default_rng(5)
