@@ -190,9 +190,20 @@ def main():
                 traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
         except Exception:
             pass
+    # matrix-pipe utilisation of that kernel from a SQ counter pass (tools/pmc_mfma_summary.py), same provenance
+    mfma_busy = None
+    pmc2 = os.path.join(ROOT, "profiles", f"r1_{a.workload}_b{B}_pmc_mfma.json")
+    if os.path.exists(pmc2):
+        try:
+            with open(pmc2) as fh:
+                k2 = json.load(fh)["kernels"].get(lab)
+            if k2:
+                mfma_busy = k2["mfma_busy_frac"]
+        except Exception:
+            pass
     out["roofline"] = {**roof, "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
                        "algorithmic_gb_per_eval": round(nb / 1e9, 3), "algorithmic_tflop_per_eval": round(fl / 1e12, 3),
-                       "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src,
+                       "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_frac_pmc": mfma_busy,
                        "share_of_eval_time": round(tms / float(ms.sum()), 3)}
     if a.kernel_table:
         with open(a.kernel_table, "w") as f:

@@ -24,6 +24,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find $OUT/pmc_FETCH_SIZE_$WL -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE_$WL -name "*counter_collection.csv" | head -1)
 if [ -n "$F" ] && [ -n "$W" ]; then python3 $R/tools/pmc_summary.py $OUT/${TAG}_${WL}_b${B}_pmc_traffic.json "$F" "$W"; fi
+# matrix-pipe utilisation (one SQ pass)
+timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace --output-format csv -d $OUT/pmc_mfma_$WL -- python3 $R/tools/unet_eval.py $UARGS > $OUT/pmc_mfma_$WL.log 2>&1 < /dev/null
+for f in $(find $OUT/pmc_mfma_$WL -name "*counter_collection.csv" | head -1); do python3 $R/tools/pmc_mfma_summary.py $OUT/${TAG}_${WL}_b${B}_pmc_mfma.json "$f"; done
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 cd $R
 timeout 600 python3 bench.py --workload $WL --batch-per-gpu $B --kernel-table $OUT/${TAG}_${WL}_b${B}_unet_eval_kernel_table.txt > $OUT/${TAG}_${WL}_b${B}_bench.json 2> $OUT/bench_$WL.log < /dev/null
