@@ -143,8 +143,16 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
         const int g = tid & 31, st = tid >> 5;
         double t1 = 0, t2 = 0;
         if (g < p.G) {
-            const float* w = p.ws + ((long)img * p.nchunk * p.G + g) * 2;
-            for (int c = st; c < p.nchunk; c += 8) { t1 += w[(long)c * p.G * 2]; t2 += w[(long)c * p.G * 2 + 1]; }
+            // 4 independent 8-byte loads in flight per trip: a one-load-per-trip loop pays an L2 round trip per chunk
+            // (up to 32 of them per thread: most of this kernel's time on small maps)
+            const float2* w = reinterpret_cast<const float2*>(p.ws) + (long)img * p.nchunk * p.G + g;
+            int c = st;
+            for (; c + 24 < p.nchunk; c += 32) {
+                const float2 a = w[(long)c * p.G], b = w[(long)(c + 8) * p.G], d = w[(long)(c + 16) * p.G], e = w[(long)(c + 24) * p.G];
+                t1 += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
+                t2 += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
+            }
+            for (; c < p.nchunk; c += 8) { const float2 a = w[(long)c * p.G]; t1 += a.x; t2 += a.y; }
         }
         r1[st][g] = t1; r2[st][g] = t2;
     }
@@ -220,14 +228,15 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
     }
 }
 
-// pixel chunks per image: >= 16 pixels each, and enough blocks (n_img * chunks ~ 1024) to occupy 256 CUs at batch 1
+// pixel chunks per image: enough blocks (n_img * chunks ~ 1024) to occupy 256 CUs at batch 1, down to ONE pixel per block
+// on the 8x8 / 16x16 maps of the UNet's inner levels (a block walks its pixels serially, one memory round trip per
+// 4-pixel trip: with 16-pixel chunks those maps ran 8 blocks x 4 dependent trips)
 int gn_chunks(int HW, int n_img)
 {
     int cap = 1024 / (n_img > 0 ? n_img : 1);
     if (cap < 64) cap = 64;
     if (cap > 256) cap = 256;
-    int c = HW / 16;
-    if (c > cap) c = cap;
+    int c = HW < cap ? HW : cap;
     if (c < 1) c = 1;
     return c;
 }
