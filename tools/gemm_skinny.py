@@ -1,0 +1,27 @@
+"""Small-M / long-K (weight-streaming) GEMM timing: tile variants x split-K counts in one process."""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, ".")
+from mlimgsynth_amd import _lib, kernels
+L = _lib.lib(); vp = _lib.vp
+ev = [vp(), vp()]
+for e in ev: L.mlsd_event_create(ctypes.byref(e))
+rng = np.random.default_rng(0)
+ws = _lib.DeviceBuffer(512 << 20)
+for (M, N, K) in [(128, 1280, 11520), (512, 1280, 11520), (512, 1280, 5120), (2048, 640, 5760)]:
+    A = rng.standard_normal((M, K)).astype(np.float16); W = rng.standard_normal((N, K)).astype(np.float16)
+    dA, dW = _lib.from_numpy(A), _lib.from_numpy(W)
+    dC = _lib.DeviceBuffer(M * N * 4)
+    row = f"{M}x{N}x{K}".ljust(18)
+    for v in (1, 0):
+        for ks in (1, 6, 13, 26, 45):
+            a = kernels.GemmArgs(A=dA.ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K, C32=dC.ptr, ldc32=N, tile_variant=v + 1,
+                                 ksplit=ks, ws=ws.ptr, ws_bytes=512 << 20)
+            for _ in range(3): kernels.gemm(a)
+            L.mlsd_event_record(ev[0], None)
+            for _ in range(20): kernels.gemm(a)
+            L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
+            ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
+            row += f" v{v}/k{ks}:{ms.value/20*1e3:5.1f}"
+    print(row)
+print("(us per launch incl. the reduce kernel; weights", "29.5 MB -> 6 us at 5 TB/s for N=1280,K=11520)")
