@@ -45,8 +45,12 @@ void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
-/* GEMM tile autotuning on the first mlctx_compute of a plan (default on; results cached per shape) */
+/* GEMM tile selection is a pure function of the shape (compiled-in table, csrc/host/tune_table.inc), so every process
+ * runs the same kernels in the same summation order.  mlctx_set_autotune(1) (or MLSD_AUTOTUNE=1) turns on the OFFLINE
+ * timing mode used by tools/tune_all.py to produce that table; mlsd_tune_dump writes the shapes timed in this process. */
 void   mlctx_set_autotune(int on);
+int    mlctx_tune_misses(void);           /* GEMM shapes prepared so far that the table does not list (static choice used) */
+int    mlsd_tune_dump(const char* path);
 
 /* ---- graph definition (src/mlblock.h:115-160) */
 void      mlctx_block_begin(MLCtx* C);

@@ -59,7 +59,7 @@ static void ctx_reset(MLCtx* C)
 	if (C->splitk_ws) { mlsd_free(C->splitk_ws); C->splitk_ws = NULL; C->splitk_ws_bytes = 0; }
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
-	C->err = 0; C->prepared = 0; C->tuned = 0;
+	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->info, 0, sizeof(C->info));
 }
@@ -137,7 +137,7 @@ void mlctx_drelease(MLCtx* C, void* p, size_t nbytes)
 MLTensor* mlt_new(MLCtx* C, int n, int h, int w, int c)
 {
 	MLTensor *t = (MLTensor*)calloc(1, sizeof(MLTensor));
-	t->n = n; t->h = h; t->w = w; t->c = c; t->prod = -1;
+	t->n = n; t->h = h; t->w = w; t->c = c; t->prod = -1; t->def_op = C->n_ops;
 	if (h > 1 || 0) { t->ne[0]=w; t->ne[1]=h; t->ne[2]=c; t->ne[3]=n; }
 	else { t->ne[0]=c; t->ne[1]=w; t->ne[2]=n; t->ne[3]=1; }
 	*VEC_PUSH(C, C->tensors, C->n_tensors, C->cap_tensors, MLTensor*) = t;
@@ -314,7 +314,7 @@ static int resolve_names(MLCtx* C)
 /* ------------------------------------------------------------------ inputs */
 static MLTensor* input_finish(MLCtx* C, MLTensor* t, const char* name, int dtype)
 {
-	t->is_input = 1; t->in_type = dtype; t->in_scale0 = 1.0f;
+	t->is_input = 1; t->in_type = dtype; t->in_scale0 = 1.0f; t->def_op = -1;
 	snprintf(t->name, sizeof(t->name), "%s", name);
 	t->in_bytes = (size_t)(t->ne[0]*t->ne[1]*t->ne[2]*t->ne[3]) * 4;
 	t->in_stage = mlctx_dalloc(C, t->in_bytes, 0);
@@ -416,17 +416,80 @@ static int run_op(MLCtx* C, MLOp* op)
 	return mlsd_set_error(-1, "unknown op kind %d", (int)op->kind);
 }
 
-/* ------------------------------------------------------------------ GEMM tile autotuner
- * "Measure, don't guess": the best tile variant depends on how the grid of a given (M,N,K) quantises over
- * the 256 CUs and on the reduction length, so every distinct GEMM/conv shape of a plan is timed once per
- * candidate variant (HIP events on the plan's stream, min of 3) and the winner is stored in the op.  Results
- * are cached process-wide by shape.  Outputs written during tuning are overwritten by the first real run. */
-typedef struct { int conv, M, N, K, act, OH, stride, ups, out; int best, ksplit; } TuneKey;
-static TuneKey g_tune[512];
+/* ------------------------------------------------------------------ GEMM tile selection
+ * The best tile variant of a GEMM/conv depends on how its (M,N,K) grid quantises over the 256 CUs and on the reduction
+ * length.  Selection is a PURE FUNCTION OF THE SHAPE: mlctx_prep looks every GEMM up in the table compiled in from
+ * tune_table.inc (keyed by shape + epilogue form); a shape that is not listed takes the launcher's static choice with no
+ * K split.  Two processes - or the ranks of a multi-GPU job - therefore always run the same kernels in the same fp32
+ * summation order and produce bit-identical results (tests/test_determinism_gpu.py).
+ * The table is produced OFFLINE by tools/tune_all.py: with MLSD_AUTOTUNE=1 (or mlctx_set_autotune(1)) the first
+ * mlctx_compute of a plan times the candidate variants of every shape the table does not hold (HIP events on the plan's
+ * stream, min of 3, on the op's real operands) and mlsd_tune_dump() writes the winners as table lines. */
+typedef struct { int conv, M, N, K, act, OH, stride, ups, out, Cin, KH, rb; int best, ksplit; } TuneKey;
+static const TuneKey k_tune_builtin[] = {
+#include "tune_table.inc"
+	{ -1, 0,0,0,0,0,0,0,0,0,0,0, 0,0 }
+};
+static TuneKey g_tune[1024];
 static int g_ntune = 0;
-static int g_autotune = 1;
+static int g_autotune = -1;          /* -1: not decided yet (environment), 0: table only, 1: time unknown shapes */
+static int g_tune_miss = 0;
+#include <pthread.h>
+static pthread_mutex_t g_tune_mu = PTHREAD_MUTEX_INITIALIZER;
 
-MLB_API void mlctx_set_autotune(int on) { g_autotune = on; }
+static int autotune_on(void)
+{
+	if (g_autotune < 0) { const char *e = getenv("MLSD_AUTOTUNE"); g_autotune = (e && *e && *e != '0') ? 1 : 0; }
+	return g_autotune;
+}
+
+MLB_API void mlctx_set_autotune(int on) { g_autotune = on ? 1 : 0; }
+MLB_API int mlctx_tune_misses(void) { return g_tune_miss; }
+
+static TuneKey tune_key(const mlsd_gemm_args* g)
+{
+	TuneKey k = { g->conv, g->M, g->N, g->K, g->act, g->conv ? g->OH : 0, g->conv ? g->stride : 0, g->conv ? g->upsample : 0,
+		(g->C32 ? 1 : 0) | (g->C16 ? 2 : 0) | (g->resid ? 4 : 0) | (g->bias_m ? 8 : 0) | (g->act_after_resid ? 16 : 0),
+		g->conv ? g->Cin : 0, g->conv ? g->KH : 0, g->rowbias ? 1 : 0, 0, 0 };
+	return k;
+}
+
+static int tune_eq(const TuneKey* t, const TuneKey* k)
+{
+	return t->conv==k->conv && t->M==k->M && t->N==k->N && t->K==k->K && t->act==k->act && t->OH==k->OH && t->stride==k->stride &&
+	       t->ups==k->ups && t->out==k->out && t->Cin==k->Cin && t->KH==k->KH && t->rb==k->rb;
+}
+
+/* table lookup: the process cache (filled by the timing mode) first, then the compiled-in table */
+static int tune_lookup(const TuneKey* k, int* best, int* ksplit)
+{
+	int found = 0;
+	pthread_mutex_lock(&g_tune_mu);
+	for (int i=0; i<g_ntune && !found; ++i) if (tune_eq(&g_tune[i], k)) { *best = g_tune[i].best; *ksplit = g_tune[i].ksplit; found = 1; }
+	pthread_mutex_unlock(&g_tune_mu);
+	static int ignore_builtin = -1;     /* tools/tune_all.py --fresh: re-time every shape */
+	if (ignore_builtin < 0) { const char *e = getenv("MLSD_TUNE_IGNORE_TABLE"); ignore_builtin = (e && *e && *e != '0') ? 1 : 0; }
+	for (const TuneKey *t = k_tune_builtin; !found && !ignore_builtin && t->conv >= 0; ++t)
+		if (tune_eq(t, k)) { *best = t->best; *ksplit = t->ksplit; found = 1; }
+	return found;
+}
+
+/* writes the process cache (shapes timed in this process) as lines of tune_table.inc; returns the number written */
+MLB_API int mlsd_tune_dump(const char* path)
+{
+	FILE *f = fopen(path, "w");
+	if (!f) return mlsd_set_error(-1, "mlsd_tune_dump: cannot open %s", path);
+	pthread_mutex_lock(&g_tune_mu);
+	for (int i=0;i<g_ntune;++i) {
+		const TuneKey *t = &g_tune[i];
+		fprintf(f, "\t{ %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d },\n", t->conv, t->M, t->N, t->K, t->act, t->OH, t->stride,
+			t->ups, t->out, t->Cin, t->KH, t->rb, t->best, t->ksplit);
+	}
+	const int n = g_ntune;
+	pthread_mutex_unlock(&g_tune_mu);
+	fclose(f);
+	return n;
+}
 
 #define SPLITK_WS_BYTES ((size_t)128 << 20)
 
@@ -438,6 +501,22 @@ static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
 		C->mem_compute += SPLITK_WS_BYTES;
 	}
 	g->ws = C->splitk_ws; g->ws_bytes = C->splitk_ws_bytes;
+	return 0;
+}
+
+/* prep-time selection: table hit -> its variant / K split; miss -> the launcher's static choice (tile_variant 0) */
+static int select_gemm(MLCtx* C, MLOp* op)
+{
+	mlsd_gemm_args *g = &op->u.gemm;
+	const TuneKey k = tune_key(g);
+	int best = 0, ks = 1;
+	if (tune_lookup(&k, &best, &ks)) {
+		g->tile_variant = best; g->ksplit = ks;
+		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
+		if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+		return 1;
+	}
+	g->tile_variant = 0; g->ksplit = 1;
 	return 0;
 }
 
@@ -457,15 +536,15 @@ static int time_gemm(MLCtx* C, mlsd_gemm_args* g, void* e0, void* e1, float* ms_
 	return 0;
 }
 
+/* offline timing mode (tools/tune_all.py): called for shapes the table does not hold */
 static int tune_gemm(MLCtx* C, MLOp* op)
 {
 	mlsd_gemm_args *g = &op->u.gemm;
-	TuneKey k = { g->conv, g->M, g->N, g->K, g->act, g->OH, g->stride, g->upsample, (g->C32 ? 1 : 0) | (g->C16 ? 2 : 0) | (g->resid ? 4 : 0), 0, 0 };
-	for (int i=0;i<g_ntune;++i) {
-		TuneKey *t = &g_tune[i];
-		if (t->conv==k.conv && t->M==k.M && t->N==k.N && t->K==k.K && t->act==k.act && t->OH==k.OH && t->stride==k.stride &&
-		    t->ups==k.ups && t->out==k.out) {
-			g->tile_variant = t->best; g->ksplit = t->ksplit;
+	TuneKey k = tune_key(g);
+	{
+		int best = 0, ks = 1;
+		if (tune_lookup(&k, &best, &ks)) {
+			g->tile_variant = best; g->ksplit = ks;
 			if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
 			return 1;
 		}
@@ -518,9 +597,12 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	mlsd_event_destroy(e0); mlsd_event_destroy(e1);
 	g->tile_variant = best; g->ksplit = best_s;
 	k.best = best; k.ksplit = best_s;
-	if (g_ntune < 512) g_tune[g_ntune++] = k;
+	pthread_mutex_lock(&g_tune_mu);
+	if (g_ntune < 1024) g_tune[g_ntune++] = k;
+	pthread_mutex_unlock(&g_tune_mu);
 	return 1;
 }
+
 
 MLB_API int mlctx_prep(MLCtx* C)
 {
@@ -534,6 +616,8 @@ MLB_API int mlctx_prep(MLCtx* C)
 		if (op->kind == OP_GEMM) {
 			if (!op->u.gemm.C32 && !op->u.gemm.C16) return mlctx_fail(C, "op %d (%s): output never consumed", i, op->label);
 			if (op->u.gemm.conv) nconv++;
+			/* tile selection: a pure function of the shape (table), unless the offline timing mode is on */
+			if (!autotune_on()) { int r = select_gemm(C, op); if (r < 0) return -1; if (!r) { C->n_tune_miss++; g_tune_miss++; } }
 		}
 		fl += op->flops;
 	}
@@ -550,7 +634,7 @@ MLB_API int mlctx_compute(MLCtx* C)
 	for (int i=0;i<C->n_params;++i) if (!C->params[i].loaded)
 		return mlctx_fail(C, "parameter '%s' was never loaded", C->params[i].key);
 	double t0 = now_s();
-	if (!C->tuned && g_autotune && !mlsd_runtime_is_dry()) {
+	if (!C->tuned && autotune_on() && !mlsd_runtime_is_dry()) {
 		/* first evaluation: run eagerly, timing the tile variants of every not-yet-seen GEMM shape on its real
 		 * operands (the ops before it have already produced them) */
 		for (int i=0;i<C->n_ops;++i) {

@@ -41,6 +41,7 @@ struct MLTensor {
 	void*  d16;  int64_t ld16;
 	size_t sz32, sz16;      /* arena sizes (0 = not arena owned) */
 	int prod;               /* index of the producing GEMM op, or -1 */
+	int def_op;             /* ops recorded when the tensor was created: its data is final after op def_op (inputs: -1) */
 	MLTensor *cat_a, *cat_b;/* virtual channel concat (both fp32) */
 	void* silu16;           /* cached fp16 silu(x) (embedding) */
 	size_t sz_silu;
@@ -90,7 +91,7 @@ struct MLCtx {
 	void* graph_exec;
 	/* batched cross-attention K/V projection of the (step-constant) context: one GEMM for all layers */
 	struct { MLTensor* ctx; char* wbase; char* out16; int n_in, n_total, n_used; } kvb;
-	int prepared, tuned;
+	int prepared, tuned, n_tune_miss;
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */
 	MLCtxInfo info;
 };

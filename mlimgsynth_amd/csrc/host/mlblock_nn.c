@@ -454,6 +454,13 @@ MLB_API MLTensor* mlb_add(MLCtx* C, MLTensor* a, MLTensor* b)
 	MLOp *op = &C->ops[a->prod];
 	if (op->u.gemm.resid) { mlctx_fail(C, "mlb_add: producer already has a residual"); return NULL; }
 	if (rows_of(a) != rows_of(b) || a->c != b->c) { mlctx_fail(C, "mlb_add: shape mismatch"); return NULL; }
+	/* the residual is READ by a's producer (op a->prod): b must be complete before that op runs.  A b recorded later
+	 * (e.g. the reference's mlb_resnet order conv2 -> skip_conv -> add, src/mlblock_nn.c:147-154) would be read stale:
+	 * refuse it, the caller has to record b first (mlb_resnet_ex does). */
+	if (!b->is_input && (b->cat_a || b->def_op >= a->prod)) {
+		mlctx_fail(C, "mlb_add: second operand '%s' is produced after the first operand's GEMM (record it earlier)", b->name);
+		return NULL;
+	}
 	const float *bd = mlt_need32(C, b);
 	if (!bd) return NULL;
 	op = &C->ops[a->prod];

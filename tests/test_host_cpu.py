@@ -160,3 +160,44 @@ def test_sdxl_label_layout(dry):
     e = lambda v: np.concatenate([np.cos(v * freq), np.sin(v * freq)])
     exp = np.concatenate([e(768), e(1024), e(0), e(0), e(768), e(1024)])
     assert np.abs(lab[1280:] - exp).max() < 5e-4
+
+
+def test_mlb_add_refuses_late_second_operand(dry):
+    """mlb_add folds b into the epilogue of a's GEMM; a b recorded AFTER that GEMM (the reference's
+    conv2 -> skip_conv -> add order, src/mlblock_nn.c:147-154) would be read before it is written.  It must fail
+    loudly; b recorded first is accepted."""
+    from mlimgsynth_amd import _lib
+    L = dry.L()
+    vp, c_int, c_bool = ctypes.c_void_p, ctypes.c_int, ctypes.c_bool
+    L.mlctx_begin.argtypes = [vp, ctypes.c_char_p]
+    L.mlctx_input_new.restype = vp
+    L.mlctx_input_new.argtypes = [vp, ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int]
+    L.mlb_nn_conv2d.restype = vp
+    L.mlb_nn_conv2d.argtypes = [vp, vp, c_int] + [c_int] * 8 + [c_bool]
+    L.mlb_add.restype = vp
+    L.mlb_add.argtypes = [vp, vp, vp]
+    L.mlctx_tensor_add.restype = vp
+    L.mlctx_tensor_add.argtypes = [vp, ctypes.c_char_p, vp]
+    L.mlctx_prep.argtypes = [vp]
+
+    def build(order):
+        C = dry.MLCtx()
+        L.mlctx_begin(C.h, b"addtest")
+        x = L.mlctx_input_new(C.h, b"x", 0, 8, 8, 8, 1)
+        if order == "late":
+            a = L.mlctx_tensor_add(C.h, b"conv2", L.mlb_nn_conv2d(C.h, x, 16, 3, 3, 1, 1, 1, 1, 1, 1, True))
+            b = L.mlctx_tensor_add(C.h, b"skip", L.mlb_nn_conv2d(C.h, x, 16, 1, 1, 1, 1, 0, 0, 1, 1, True))
+        else:
+            b = L.mlctx_tensor_add(C.h, b"skip", L.mlb_nn_conv2d(C.h, x, 16, 1, 1, 1, 1, 0, 0, 1, 1, True))
+            a = L.mlctx_tensor_add(C.h, b"conv2", L.mlb_nn_conv2d(C.h, x, 16, 3, 3, 1, 1, 1, 1, 1, 1, True))
+        y = L.mlb_add(C.h, a, b)
+        if y:
+            L.mlctx_tensor_add(C.h, b"out", y)
+        return C, y, L.mlctx_prep(C.h)
+
+    C, y, rc = build("late")
+    assert not y and rc < 0 and "produced after" in _lib.last_error()
+    C.destroy()
+    C, y, rc = build("early")
+    assert y and rc >= 1
+    C.destroy()

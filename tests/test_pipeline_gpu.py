@@ -47,8 +47,6 @@ def test_vae_decode_sd_real_config():
     assert err < 4e-3
 
 
-@pytest.mark.skipif(__import__("os").environ.get("MLSD_FULL_SIZE") != "1",
-                    reason="about a minute of host time for the CPU oracle: run with MLSD_FULL_SIZE=1 (result in DESIGN.md section 5)")
 def test_vae_decode_512_parity():
     """configs[1]'s decode at full size: the real SD1.5 KL decoder, 64x64 latent -> 512x512 image (2.5 TFLOP), vs the oracle."""
     import os

@@ -114,8 +114,6 @@ def test_unet_sdxl_eval_is_bit_repeatable_and_finite():
         assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
 
 
-@pytest.mark.skipif(__import__("os").environ.get("MLSD_FULL_SIZE") != "1",
-                    reason="2+ minutes of host time for the CPU oracle: run with MLSD_FULL_SIZE=1 (measured 1.21e-3, DESIGN.md section 5)")
 def test_unet_sdxl_headline_size_parity():
     """BASELINE.json's headline shape itself: ONE SDXL UNet evaluation at the 128x128 latent of a 1024x1024 image (2567.5 M
     synthetic parameters, 6.76 TFLOP) against the oracle's CPU restatement (about half a minute of host time on the
