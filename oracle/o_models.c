@@ -78,6 +78,11 @@ static void push(Ctx* C, const char* name)
 }
 static void pop(Ctx* C) { C->path[C->len[--C->depth]] = 0; }
 
+/* optional trace of named layer outputs (debugging aid for tools/make_torch_golden.py --trace) */
+static void (*g_trace_cb)(const char* path, const OT* t) = NULL;
+ORACLE_API void orc_set_trace(void (*cb)(const char*, const OT*)) { g_trace_cb = cb; }
+#define TRACE(C, y) do { if (g_trace_cb) g_trace_cb((C)->path, (y)); } while (0)
+
 static const OParam* par(Ctx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3)
 {
 	char key[640];
@@ -94,6 +99,7 @@ static OT* nn_linear(Ctx* C, const char* name, const OT* x, int n_out, int bias)
 	const OParam *w = par(C, "weight", C->wtype, x->ne[0], n_out, 1, 1);
 	const OParam *b = bias ? par(C, "bias", ORC_F32, n_out, 1, 1, 1) : NULL;
 	OT *y = orc_linear(x, w, b);
+	TRACE(C, y);
 	pop(C);
 	return y;
 }
@@ -104,6 +110,7 @@ static OT* nn_conv2d(Ctx* C, const char* name, const OT* x, int ch_out, int k, i
 	const OParam *w = par(C, "weight", ORC_F16, k, k, x->ne[2], ch_out);
 	const OParam *b = bias ? par(C, "bias", ORC_F32, ch_out, 1, 1, 1) : NULL;
 	OT *y = orc_conv2d(x, w, b, s, p);
+	TRACE(C, y);
 	pop(C);
 	return y;
 }
@@ -114,6 +121,7 @@ static OT* nn_layer_norm(Ctx* C, const char* name, const OT* x)
 	const OParam *w = par(C, "weight", ORC_F32, x->ne[0], 1,1,1);
 	const OParam *b = par(C, "bias", ORC_F32, x->ne[0], 1,1,1);
 	OT *y = orc_layer_norm(x, 1e-5f, w, b);
+	TRACE(C, y);
 	pop(C);
 	return y;
 }
@@ -124,6 +132,7 @@ static OT* nn_groupnorm32(Ctx* C, const char* name, const OT* x)
 	const OParam *w = par(C, "weight", ORC_F32, x->ne[2], 1,1,1);
 	const OParam *b = par(C, "bias", ORC_F32, x->ne[2], 1,1,1);
 	OT *y = orc_group_norm(x, 32, 1e-6f, w, b);
+	TRACE(C, y);
 	pop(C);
 	return y;
 }

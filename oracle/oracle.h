@@ -36,6 +36,7 @@ extern "C" {
 #define ORACLE_API __attribute__((visibility("default")))
 
 /* ------------------------------------------------------------------ tensors */
+struct OT;
 typedef struct OT {
 	int64_t ne[4];
 	float *d;
@@ -49,6 +50,9 @@ ORACLE_API int64_t ot_nel(const OT* t);
 /* round-to-nearest-even through IEEE binary16 and back (ggml_fp32_to_fp16_row) */
 ORACLE_API void orc_round_f16(float* x, int64_t n);
 ORACLE_API void orc_set_threads(int n);
+/* test switch (default 1): 0 disables the F16 rounding of conv/linear activation operands (see o_ops.c) */
+ORACLE_API void orc_set_act_rounding(int on);
+ORACLE_API void orc_set_trace(void (*cb)(const char* path, const struct OT* t));
 ORACLE_API int  orc_get_threads(void);
 
 /* C[M][N] = sum_k A[M][K] * B[N][K]   (ggml_mul_mat semantics: both K-contiguous) */

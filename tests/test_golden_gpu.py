@@ -1,0 +1,75 @@
+"""The HIP engine against the INDEPENDENT golden vectors (tests/golden/torch_golden.npz: torch restatement written from the
+public model definitions, see tests/test_golden_cpu.py).  Same stated tolerance as against the oracle: 4e-3 per
+evaluation (fp16 operands like ggml's CPU backend; fp16 Q/K/V/P in the fused attention; fp32 summation order on MFMA)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "torch_golden.npz"))
+TOL = 4e-3
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("key,model,lat,n,sigmas", G.UNET_CASES, ids=[c[0] for c in G.UNET_CASES])
+def test_hip_unet_vs_independent_golden(key, model, lat, n, sigmas):
+    from mlimgsynth_amd import engine
+    x, cond, label = G.unet_inputs(key, model, lat, n)
+    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
+    got = un.run(x, cond, label, np.array(sigmas, np.float32))
+    errs = [rel(got[i], GOLD[key][i]) for i in range(n)]
+    print(key, errs)
+    assert max(errs) < TOL
+
+
+@pytest.mark.parametrize("key,model,lat", G.VAE_CASES, ids=[c[0] for c in G.VAE_CASES])
+def test_hip_vae_decode_vs_independent_golden(key, model, lat):
+    from mlimgsynth_amd import engine
+    got = engine.Decoder(model, lat, lat, 1, seed=G.WEIGHT_SEED).run(G.vae_inputs(key, lat))
+    e = rel(got - 0.5, GOLD[key] - 0.5)
+    print(key, e)
+    assert e < TOL
+
+
+@pytest.mark.parametrize("key,lat", G.TAE_CASES, ids=[c[0] for c in G.TAE_CASES])
+def test_hip_tae_decode_vs_independent_golden(key, lat):
+    from mlimgsynth_amd import engine
+    got = engine.Decoder("sd1", lat, lat, 1, tae=True, seed=G.WEIGHT_SEED).run(G.tae_inputs(key, lat))
+    e = rel(got, GOLD[key])
+    print(key, e)
+    assert e < TOL
+
+
+@pytest.mark.parametrize("key,model,prefix,skip,norm,feat,n_tok", G.CLIP_CASES, ids=[c[0] for c in G.CLIP_CASES])
+def test_hip_clip_vs_independent_golden(key, model, prefix, skip, norm, feat, n_tok):
+    from mlimgsynth_amd import engine
+    toks, _ = G.clip_tokens(key, model, n_tok)
+    emb, _ = engine.clip_text_encode(model, prefix, toks[None], want_embed=True, want_feat=False, clip_skip=skip, norm=norm, seed=G.WEIGHT_SEED)
+    e = rel(emb[0], GOLD[key])
+    print(key, "embed", e)
+    assert e < TOL
+    if feat:
+        _, ft = engine.clip_text_encode(model, prefix, toks[None], want_embed=False, want_feat=True, clip_skip=skip, norm=norm, seed=G.WEIGHT_SEED)
+        ef = rel(ft[0], GOLD[key + "_feat"])
+        print(key, "feat", ef)
+        assert ef < TOL
+
+
+@pytest.mark.parametrize("key,model,lat,steps,seed", G.GEN_CASES, ids=[c[0] for c in G.GEN_CASES])
+def test_hip_generation_vs_independent_golden(key, model, lat, steps, seed):
+    from mlimgsynth_amd import engine
+    cond, uncond, label, unlabel = G.gen_inputs(key, model)
+    g = engine.Generator(model, lat * 8, lat * 8, 1, n_step=steps, cfg_scale=7.0, s_ancestral=1.0, weight_seed=G.WEIGHT_SEED)
+    g.set_cond(cond, label, uncond, unlabel)
+    latent, _ = g.generate([seed], want_images=False)
+    e = rel(latent[0], GOLD[key])
+    print(key, e)
+    assert e < 5e-2          # final latent of a chaotic 20-step loop (per-evaluation bound is the 4e-3 above)

@@ -40,15 +40,11 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def main():
-    only = None
-    for i, a in enumerate(sys.argv):
-        if a == "--only":
-            only = sys.argv[i + 1]
-    check = "--check" in sys.argv
-    out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
-    want = lambda k: only is None or k.startswith(only)
-
+def run_mode(out, want, check, f16_mode):
+    SUF = "" if f16_mode else "__f32"      # "__f32": no F16 operand rounding on either side (graph check at 1e-5 class)
+    O.L().orc_set_act_rounding(1 if f16_mode else 0)
+    NetM = lambda: TR.Net(TR.Weights(synth), f16_ops=f16_mode)
+    print("==== mode:", "ggml F16 operand rounding" if f16_mode else "pure fp32 operands", flush=True)
     with torch.no_grad():
         for key, model, lat, n, sigmas in G.UNET_CASES:
             if not want(key):
@@ -56,7 +52,7 @@ def main():
             t0 = time.time()
             U = G.UNET[model]
             x, cond, label = G.unet_inputs(key, model, lat, n)
-            net = TR.Net(TR.Weights(synth))
+            net = NetM()
             res = []
             for i in range(n):
                 s = np.float32(sigmas[i])
@@ -76,40 +72,40 @@ def main():
             P.free()
             print(f"{key}: torch {time.time() - t0:.1f}s, oracle-vs-torch rel-L2 {errs}", flush=True)
             if check:
-                print("   stored-vs-new", rel(out[key], res))
-            out[key] = res
+                print("   stored-vs-new", rel(out[key + SUF], res))
+            out[key + SUF] = res
 
         for key, model, lat in G.VAE_CASES:
             if not want(key):
                 continue
             z = G.vae_inputs(key, lat)
-            net = TR.Net(TR.Weights(synth))
+            net = NetM()
             res = net.vae_decode(G.VAE[model], torch.from_numpy(z)).numpy()
             P = O.Params(G.WEIGHT_SEED)
             r = O.from_ot(O.L().orc_vae_decode(P.h, b"vae", O.vae_params(model), O.to_ot(z)))
             P.free()
             print(f"{key}: oracle-vs-torch rel-L2 {rel(r - 0.5, res - 0.5)}", flush=True)
-            out[key] = res
+            out[key + SUF] = res
 
         for key, lat in G.TAE_CASES:
             if not want(key):
                 continue
             z = G.tae_inputs(key, lat)
-            res = TR.Net(TR.Weights(synth)).tae_decode(torch.from_numpy(z)).numpy()
+            res = NetM().tae_decode(torch.from_numpy(z)).numpy()
             P = O.Params(G.WEIGHT_SEED)
             r = O.from_ot(O.L().orc_tae_decode(P.h, b"tae", O.to_ot(z)))
             P.free()
             print(f"{key}: oracle-vs-torch rel-L2 {rel(r, res)}", flush=True)
-            out[key] = res
+            out[key + SUF] = res
 
         for key, model, prefix, skip, norm, feat, n_tok in G.CLIP_CASES:
             if not want(key):
                 continue
             K = G.CLIP[model]
             toks, full = G.clip_tokens(key, model, n_tok)
-            net = TR.Net(TR.Weights(synth))
+            net = NetM()
             emb = net.clip_text(K, torch.from_numpy(full[None]), prefix, skip, norm)[0].numpy()
-            out[key] = emb
+            out[key + SUF] = emb
             P = O.Params(G.WEIGHT_SEED)
             KO = O.clip_params(model)
             ptr = full.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
@@ -117,10 +113,10 @@ def main():
             msg = f"{key}: oracle-vs-torch embed rel-L2 {rel(r, emb)}"
             if feat:
                 ft = net.clip_feat(K, torch.from_numpy(full[None]), prefix, n_tok + 1)[0].numpy()
-                out[key + "_feat"] = ft
+                out[key + "_feat" + SUF] = ft
                 rf = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), KO, ptr, -1, 1, 1, n_tok + 1)).reshape(K["d_embed"])
                 msg += f", feat {rel(rf, ft)}"
-                out[key + "_label"] = TR.sdxl_label(torch.from_numpy(ft), 1024, 768).numpy()
+                out[key + "_label" + SUF] = TR.sdxl_label(torch.from_numpy(ft), 1024, 768).numpy()
             P.free()
             print(msg, flush=True)
 
@@ -129,7 +125,7 @@ def main():
                 continue
             U = G.UNET[model]
             cond, uncond, label, unlabel = G.gen_inputs(key, model)
-            net = TR.Net(TR.Weights(synth))
+            net = NetM()
             sig = np.zeros(steps + 2, np.float32)
             O.L().orc_schedule(steps, 1, 1.0, 0.0, O.fptr(sig))     # pinned schedule (SURVEY row a13 golden)
             sig = sig[:steps + 1]
@@ -153,14 +149,14 @@ def main():
                                       7.0, steps, 1.0, seed, 0, O.fptr(ref), ctypes.byref(tu))
             P.free()
             print(f"{key}: oracle-vs-torch final latent rel-L2 {rel(ref, res)}", flush=True)
-            out[key] = res
+            out[key + SUF] = res
 
         for key, model, side in G.VAE_ENC_CASES:
             if not want(key):
                 continue
             img = G.image_inputs(key, side)
-            res = TR.Net(TR.Weights(synth)).vae_encode_moments(G.VAE[model], torch.from_numpy(img)).numpy()
-            out[key] = res
+            res = NetM().vae_encode_moments(G.VAE[model], torch.from_numpy(img)).numpy()
+            out[key + SUF] = res
             if hasattr(O.L(), "orc_vae_encode_moments"):
                 P = O.Params(G.WEIGHT_SEED)
                 r = O.from_ot(O.L().orc_vae_encode_moments(P.h, b"vae", O.vae_params(model), O.to_ot(img)))
@@ -168,6 +164,21 @@ def main():
                 print(f"{key}: oracle-vs-torch moments rel-L2 {rel(r, res)}", flush=True)
             else:
                 print(f"{key}: generated (no oracle encoder yet)")
+
+    O.L().orc_set_act_rounding(1)
+
+
+def main():
+    only = None
+    for i, a in enumerate(sys.argv):
+        if a == "--only":
+            only = sys.argv[i + 1]
+    check = "--check" in sys.argv
+    out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
+    want = lambda k: only is None or k.startswith(only)
+
+    for f16_mode in (True, False):
+        run_mode(out, want, check, f16_mode)
 
     if not check:
         np.savez_compressed(OUT, **{k: np.asarray(v, np.float32) for k, v in out.items()})
