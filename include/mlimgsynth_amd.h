@@ -75,11 +75,22 @@ int sdvae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* i
 /* graph build + prep only (the driver binds the resident latent and calls mlctx_compute itself) */
 int sdvae_decode_build(MLCtx* C, const VaeParams* P, MLTensor* t_latent);
 
+/* encoder (img2img / in-painting source; src/vae.c:76-128,231-316): image [n][3][h][w] in [0,1] -> moments
+ * [n][2*ch_z][h/8][w/8] = (mean | logvar); the latent sample is a separate step (mlsd_latent_sample) */
+MLTensor* mlb_sdvae_encoder(MLCtx* C, MLTensor* x, const VaeParams* P);
+int sdvae_encode_init(MLCtx* C, const VaeParams* P, unsigned w, unsigned h, unsigned n_batch, MLTensor** t_img);
+int sdvae_encode_build(MLCtx* C, const VaeParams* P, MLTensor* t_img);
+int sdvae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float* moments);
+
 typedef struct { int ch_x, ch_inner, ch_z, n_blk; } SdTaeParams;
 MLTensor* mlb_sdtae_decoder(MLCtx* C, MLTensor* x, const SdTaeParams* P);
 int sdtae_decode_init(MLCtx* C, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent);
 int sdtae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img);
 int sdtae_decode_build(MLCtx* C, MLTensor* t_latent);
+MLTensor* mlb_sdtae_encoder(MLCtx* C, MLTensor* x, const SdTaeParams* P);       /* src/tae.c:43-63 */
+int sdtae_encode_init(MLCtx* C, unsigned w, unsigned h, unsigned n_batch, MLTensor** t_img);
+int sdtae_encode_build(MLCtx* C, MLTensor* t_img);
+int sdtae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float* latent);
 
 /* ---------------------------------------------------------------- CLIP text encoder (src/clip.h) */
 typedef struct {
@@ -147,7 +158,8 @@ typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/r
 void rng_philox_randn(RngPhilox* S, unsigned n, float* out);
 
 enum { DNSAMP_SCHED_UNIFORM = 1, DNSAMP_SCHED_KARRAS = 2 };      /* src/sampling.h:11-14 */
-enum { SOLVER_METHOD_EULER = 1 };                                /* src/solvers.h:56-62 (others: next) */
+enum { SOLVER_METHOD_EULER = 1, SOLVER_METHOD_HEUN = 2, SOLVER_METHOD_TAYLOR3 = 3, SOLVER_METHOD_DPMPP2M = 4,
+       SOLVER_METHOD_DPMPP2S = 5 };                              /* src/solvers.h:56-62 == MLIS_Method */
 
 /* dnsamp_init schedule (src/sampling.c:28-96): fills sigmas[0..n_step], returns n_step */
 int  dnsamp_schedule(const UnetParams* P, int n_step, int sched, float f_t_ini, float f_t_end, float* sigmas);
@@ -167,7 +179,16 @@ typedef struct {
 	int use_tae;             /* decode with TAESD instead of the KL-VAE */
 	int use_hipgraph;        /* replay each UNet evaluation as one hipGraph launch */
 	uint64_t weight_seed;    /* synthetic weights seed (1234) */
+	/* sampler options of dnsamp_init (src/sampling.h:34-38); zero = the reference's defaults */
+	int method;              /* SOLVER_METHOD_* (0 -> euler, src/sampling.c:33); 2-NFE solvers halve the step count (:47-49) */
+	float s_noise;           /* stochastic sampling noise level (src/sampling.c:139-151) */
+	float f_t_ini, f_t_end;  /* relative initial / final time: 0,0 -> 1,0 (txt2img); f_t_ini < 1 = img2img */
+	int defer_weights;       /* 1: do not synthesise weights: the caller loads them (mlctx_param_set on the *_ctx handles) */
 } MLIS_AmdConfig;
+
+/* progress callback (MLIS_Callback, include/mlimgsynth.h:405): called after every COMPLETED step (the stream is
+ * synchronised first); a negative return aborts the generation and is returned by mlis_amd_denoise/generate */
+typedef int (*mlis_amd_progress_fn)(void* user, int step, int n_step, int nfe);
 
 MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream);
 void mlis_amd_destroy(MLIS_AmdCtx* S);
@@ -180,6 +201,19 @@ int mlis_amd_set_cond_device(MLIS_AmdCtx* S, const void* cond, const void* label
  * semantics) and decodes; everything is enqueued on the stream, the call returns after the final sync.
  * latents_out [n][4][lh][lw] and/or images_out [n][3][h][w] (host, may be NULL) */
 int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* latents_out, float* images_out);
+int mlis_amd_set_callback(MLIS_AmdCtx* S, mlis_amd_progress_fn fn, void* user);
+/* per-image Philox streams (seed_i, offset 0).  mlis_amd_denoise/generate with seeds == NULL continue the streams, like the
+ * reference's never-reset g_rng (src/ccommon/rng_philox.c:50) */
+int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds);
+/* img2img / in-painting inputs (MLIS_TUF_LATENT / MLIS_TUF_LMASK, src/mlimgsynth.c:1652-1687): initial latent host NCHW
+ * [n][4][lh][lw] (consumed by the next denoise), latent mask host [lh][lw] (1 = keep the original; NULL clears) */
+int mlis_amd_set_init_latent(MLIS_AmdCtx* S, const float* latent);
+int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask);
+/* mlis_image_encode (src/mlimgsynth.c:1301-1330): images host NCHW [n][3][h][w] in [0,1] -> resident latent (VAE: sampled
+ * when sample != 0 with one Philox call per image, else the mean; TAE: direct), marked as the next initial latent */
+int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample);
+MLCtx* mlis_amd_encoder_ctx(MLIS_AmdCtx* S);                                /* NULL before the first encode */
+int mlis_amd_last_n_step(MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */
 int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device */

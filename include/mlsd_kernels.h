@@ -171,7 +171,7 @@ int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float eps, cons
  * dst image n reads src image n % n_src (cond/uncond duplication of src/mlimgsynth.c:1578-1582);
  * value = f(src * scale[n % n_src]) with scale NULL -> scalar `scale0`
  * (c_in of src/unet.c:470-472; 1/scale_factor of src/vae.c:174);
- * mode 1: 3*tanh(x/3) clamp of src/tae.c:71-73 applied first. */
+ * mode 1: 3*tanh(x/3) clamp of src/tae.c:71-73 applied first; mode 2: x*2-1 (sdvae_encoder_pre, src/vae.h:36-40) applied first. */
 int mlsd_nchw_to_nhwc_f16(const float* src, int n_src, int C, int HW, void* dst, int n_dst, int Cpad,
                           const float* scale, float scale0, int mode, void* stream);
 /* NHWC fp32 [n][HW][ld] (first C channels) -> NCHW fp32 [n][C][HW]; out = in*mul + add
@@ -193,6 +193,29 @@ int mlsd_sampler_update(float* x, const float* eps, int64_t ld, int B, int C, in
                         const float* dt, const float* noise, const float* s_up, void* stream);
 /* dnsamp_noise_add (src/sampling.c:112-117): x[b] += noise[b] * s[b]; x, noise fp32 [B][per], s fp32 [B] on device */
 int mlsd_noise_add(float* x, const float* noise, const float* s, int B, int64_t per, void* stream);
+/* ---- general sampler (all solvers / in-painting / img2img / v-prediction): one launch per loop of the reference, same
+ * fp32/fp64 operation order (bit-identical to the host arithmetic).  x, dx, tmp vectors: NCHW fp32 [B][C][HW], n = B*C*HW.
+ * Scalars by value (they are wave-uniform kernel arguments: nothing to upload or sync). */
+/* dx = CFG mix (src/mlimgsynth.c:1565-1587) of the UNet outputs eps NHWC [2B|B][HW][ld]; vparam != 0: each branch first
+ * rescaled out*c_out + x_eval*c_skip (src/unet.c:490-494) */
+int mlsd_dxdt_cfg(const float* eps, int64_t ld, const float* x_eval, float* dx, int B, int C, int HW, float cfg,
+                  int vparam, float c_out, float c_skip, void* stream);
+/* fused Euler(-ancestral) step with the CFG mix (one launch per step; the 1-NFE eps-model path):
+ * x += (eps_c*f + eps_u*(1-f))*dt [+ noise*s_up]; same operation order as dxdt_cfg + vec_axpy + noise_add_s */
+int mlsd_euler_cfg_update(float* x, const float* eps, int64_t ld, int B, int C, int HW, float cfg, float dt,
+                          const float* noise, float s_up, void* stream);
+int mlsd_vec_axpy(float* out, const float* x, const float* d, float dt, int64_t n, void* stream);     /* out = x + d*dt (solvers.c:86,105,278) */
+int mlsd_solver_heun_corr(float* x, const float* dx, const float* d1, float dt, int64_t n, void* stream);   /* solvers.c:112-113 */
+int mlsd_solver_taylor3(float* x, const float* dx, float* dp1, float* dp2, float dt, float idtp, float f2, float f3,
+                        int64_t n, void* stream);                                                            /* solvers.c:150-165 */
+int mlsd_solver_dpmpp2m(float* x, const float* dx, float* dprev, float t_cur, float a, float c, int64_t n, void* stream);   /* :222-229 */
+int mlsd_solver_dpmpp2s(float* x, const float* x1, const float* dx1, float t1, float a, int64_t n, void* stream);           /* :281-284 */
+int mlsd_noise_add_s(float* x, const float* noise, float s, int64_t n, void* stream);                /* sampling.c:115, scalar sigma */
+int mlsd_mask_apply(float* x, const float* x0, const float* mask /*[HW]*/, int HW, int64_t n, void* stream);   /* sampling.c:98-110 */
+/* sdvae_latent_sample / sdvae_latent_mean (src/vae.c:188-229): moments NHWC fp32 [B][HW][ld] (mean | logvar) -> latent NCHW
+ * [B][cz][HW]; rnd NCHW [B][cz][HW] or NULL (mean only) */
+int mlsd_latent_sample(const float* moments, int64_t ld, const float* rnd, float* latent, int B, int cz, int HW, float scale,
+                       void* stream);
 /* finite check (ltensor_finite_check, src/unet.c:487): counts non-finite values into *count (device int32) */
 int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream);
 /* deterministic synthetic parameter fill, bit-identical to oracle/o_core.c orc_synth_fill.

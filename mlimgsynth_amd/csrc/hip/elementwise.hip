@@ -22,6 +22,7 @@ __global__ void nchw_to_nhwc_f16_kernel(const float* __restrict__ src, int n_src
             if (c < C) {
                 v = src[((long)ns * C + c) * HW + pix];
                 if (mode == 1) v = tanhf(v * (1.0f / 3.0f)) * 3.0f;
+                if (mode == 2) v = __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);        // sdvae_encoder_pre [0,1] -> [-1,1], src/vae.h:36-40
                 v *= s;
             }
             d[c] = (_Float16)v;

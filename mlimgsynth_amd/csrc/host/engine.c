@@ -1,16 +1,19 @@
-/* Generation driver — the slice of the reference's mlis_generate (src/mlimgsynth.c:1634-1773) that
- * drives the hot path: schedule, initial noise, 20 x [CFG UNet evaluation + Euler(-ancestral) update],
- * latent decode.  MI355X-first differences:
+/* Generation driver — the slice of the reference's mlis_generate (src/mlimgsynth.c:1634-1773) that drives the hot
+ * path: [image encode] -> schedule -> initial noise -> n_step x [dxdt (CFG UNet evaluation) + solver update
+ * (+ ancestral / stochastic noise, in-painting blend)] -> latent decode.  The loop is a re-creation of
+ * dnsamp_init / dnsamp_step (src/sampling.c:28-185) and of the five solvers (src/solvers.c:82-296) whose vector
+ * loops run on the device (csrc/hip/sampler.hip, same fp32/fp64 operation order) while every scalar stays on the
+ * host exactly as in the reference.  MI355X-first differences:
  *   - n_batch images per GPU; cond and uncond of all images form ONE batch-2B UNet evaluation
- *     (the reference runs two sequential batch-1 evaluations per step, mlimgsynth.c:1578-1582);
- *   - the latent never leaves the device: c_in scaling happens in the UNet's input conversion,
- *     the CFG mix + Euler step + ancestral noise are one elementwise kernel;
- *   - all per-step scalars (t, c_in, dt, sigma_up) are computed up front on the host with the
- *     reference's own formulas and uploaded once; the Philox/Box-Muller noise is generated on the host
- *     (bit-exact integer stream, fp64 Box-Muller like src/ccommon/rng_philox.c) WHILE the GPU runs the
- *     UNet evaluation of the same step, then copied asynchronously;
- *   - weights stay resident in HBM (288 GB) for the lifetime of the context instead of being
- *     re-uploaded per generate (mlblock.c:266-292) or per half-graph (--unet-split, unet.c:390-458).
+ *     (the reference runs two sequential batch-1 evaluations per dxdt, mlimgsynth.c:1578-1582);
+ *   - the latent never leaves the device: c_in scaling happens in the UNet's input conversion, the CFG mix and
+ *     the solver updates are elementwise kernels with by-value scalars; nothing in the loop synchronises
+ *     (unless a progress callback is installed);
+ *   - the Philox/Box-Muller noise is generated on the host (bit-exact integer stream, fp64 Box-Muller like
+ *     src/ccommon/rng_philox.c) WHILE the GPU runs the UNet evaluation enqueued just before, then copied
+ *     asynchronously; one independent stream per image (seed_i, offset 0: generate.sh:56-59 semantics);
+ *   - weights stay resident in HBM (288 GB) for the lifetime of the context instead of being re-uploaded per
+ *     generate (mlblock.c:266-292) or per half-graph (--unet-split, unet.c:390-458).
  */
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
@@ -19,6 +22,9 @@
 int unet_denoise_build(UnetState* S);
 
 #define MAX_STEPS 256
+#define MAX_BATCH 64
+#define MAX_DRAWS (2 * MAX_STEPS + 2)
+#define N_TMP 2
 
 struct MLIS_AmdCtx {
 	MLIS_AmdConfig c;
@@ -27,24 +33,32 @@ struct MLIS_AmdCtx {
 	UnetParams unet_p;
 	VaeParams vae_p;
 	int lw, lh, hw, B, N;
-	MLCtx *unet_ctx, *dec_ctx;
+	MLCtx *unet_ctx, *dec_ctx, *enc_ctx;
 	UnetState unet;
-	MLTensor *t_lat_dec;
+	MLTensor *t_lat_dec, *t_img_enc;
 	/* device state */
 	float *d_x;                 /* latent [B][4][hw] NCHW fp32 */
+	float *d_xin;               /* what the UNet plan reads: == d_x for 1-NFE solvers, own buffer for heun / dpmpp2s */
+	float *d_dx;                /* dxdt */
+	float *d_tmp[N_TMP];        /* solver state vectors (solver_tmp_get, solvers.c:54-76) */
+	float *d_x0, *d_lmask;      /* in-painting: original latent, latent mask [hw] */
 	float *d_img;               /* image  [B][3][H][W] fp32 */
+	float *d_img_in;            /* encoder input image (NCHW fp32 [B][3][H][W], [0,1]) */
 	float *d_cin;               /* [B] current c_in (read by the UNet input conversion) */
-	float *d_tall, *d_cinall, *d_dtall, *d_supall, *d_sig0;   /* per-step scalar tables */
-	float *d_noise;             /* [n_step+1][B][4*hw] */
+	float *d_noise;             /* [MAX draws][B][4*hw] */
 	float *h_noise;             /* pinned, same shape */
-	float *h_scal;              /* pinned staging of the scalar tables */
+	float *h_scal;              /* pinned staging ring of per-evaluation scalars (t[N] | c_in[B]) */
 	int32_t *d_nan;
-	void *ev[MAX_STEPS][2];
+	void *ev[2 * MAX_STEPS][2];
 	int n_ev;
 	float last_unet_ms;
-	int last_nfe;
-	int cond_set;
+	int last_nfe, last_n_step;
+	int cond_set, have_init_latent, have_lmask;
 	int own_stream;
+	RngPhilox rng[MAX_BATCH];
+	int n_draw_max, n_draw_gen;          /* noise draws of the current denoise call: planned / generated so far */
+	int i_eval;
+	mlis_amd_progress_fn cb; void* cb_user;
 };
 
 static int fail(const char* msg) { return mlsd_set_error(-1, "%s", msg); }
@@ -55,17 +69,26 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	mlsd_stream_sync(S->stream);
 	if (S->unet_ctx) mlctx_destroy(S->unet_ctx);
 	if (S->dec_ctx) mlctx_destroy(S->dec_ctx);
-	mlsd_free(S->d_x); mlsd_free(S->d_img); mlsd_free(S->d_cin); mlsd_free(S->d_tall); mlsd_free(S->d_cinall);
-	mlsd_free(S->d_dtall); mlsd_free(S->d_supall); mlsd_free(S->d_sig0); mlsd_free(S->d_noise); mlsd_free(S->d_nan);
+	if (S->enc_ctx) mlctx_destroy(S->enc_ctx);
+	if (S->d_xin != S->d_x) mlsd_free(S->d_xin);
+	mlsd_free(S->d_x); mlsd_free(S->d_dx); mlsd_free(S->d_x0); mlsd_free(S->d_lmask); mlsd_free(S->d_img); mlsd_free(S->d_img_in);
+	for (int i=0;i<N_TMP;++i) mlsd_free(S->d_tmp[i]);
+	mlsd_free(S->d_cin); mlsd_free(S->d_noise); mlsd_free(S->d_nan);
 	mlsd_host_free(S->h_noise); mlsd_host_free(S->h_scal);
 	for (int i=0;i<S->n_ev;++i) { mlsd_event_destroy(S->ev[i][0]); mlsd_event_destroy(S->ev[i][1]); }
 	if (S->own_stream) mlsd_stream_destroy(S->stream);
 	free(S);
 }
 
+static int solver_nfe(int method)
+{	/* SolverClass.n_fe, src/solvers.c:90-296 */
+	return (method == SOLVER_METHOD_HEUN || method == SOLVER_METHOD_DPMPP2S) ? 2 : 1;
+}
+
 MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 {
 	MLIS_AmdCtx *S = (MLIS_AmdCtx*)calloc(1, sizeof(*S));
+	if (!S) { fail("out of memory"); return NULL; }
 	S->c = *cfg; S->stream = stream;
 	if (!stream) {   /* own non-default stream: stream capture (hipGraph) is not permitted on the NULL stream */
 		if (mlsd_stream_create(&S->stream)) { free(S); return NULL; }
@@ -75,10 +98,14 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 	snprintf(S->model, sizeof(S->model), "%s", cfg->model ? cfg->model : "sd1");
 	S->c.model = S->model;
 	if (S->c.n_step < 1) S->c.n_step = 20;
-	if (S->c.n_step >= MAX_STEPS) { fail("too many steps"); goto err; }
+	if (S->c.n_step >= MAX_STEPS) { fail("too many steps (max 255)"); goto err; }
 	if (S->c.n_batch < 1) S->c.n_batch = 1;
+	if (S->c.n_batch > MAX_BATCH) { fail("n_batch > 64 not supported"); goto err; }
 	if (!(S->c.cfg_scale > 0)) S->c.cfg_scale = 7;          /* default cfg 7, src/mlimgsynth.c:474 */
 	if (!S->c.sched) S->c.sched = DNSAMP_SCHED_UNIFORM;
+	if (S->c.method <= 0) S->c.method = SOLVER_METHOD_EULER;   /* sampling.c:33 */
+	if (S->c.method > SOLVER_METHOD_DPMPP2S) { mlsd_set_error(-1, "invalid sampling method %d", S->c.method); goto err; }
+	if (!(S->c.f_t_ini > 0)) S->c.f_t_ini = 1;
 	if (!S->c.weight_seed) S->c.weight_seed = 1234;
 	if (unet_params_get(S->model, &S->unet_p) < 0) goto err;
 	if (vae_params_get(S->model, &S->vae_p) < 0) goto err;
@@ -88,28 +115,30 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 	S->N = S->c.cfg_scale > 1 ? 2*S->B : S->B;
 	const int B = S->B, N = S->N, ns = S->c.n_step;
 	const size_t lat_elems = (size_t)B * 4 * S->hw;
+	S->n_draw_max = 2 * ns + 2;
 
 	if (mlsd_malloc((void**)&S->d_x, lat_elems*4)) goto err;
+	S->d_xin = S->d_x;
+	if (solver_nfe(S->c.method) > 1 && mlsd_malloc((void**)&S->d_xin, lat_elems*4)) { S->d_xin = S->d_x; goto err; }
+	if (mlsd_malloc((void**)&S->d_dx, lat_elems*4)) goto err;
+	for (int i=0;i<N_TMP;++i) if (mlsd_malloc((void**)&S->d_tmp[i], lat_elems*4)) goto err;
+	if (mlsd_malloc((void**)&S->d_x0, lat_elems*4)) goto err;
+	if (mlsd_malloc((void**)&S->d_lmask, (size_t)S->hw*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_img, (size_t)B*3*S->c.width*S->c.height*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_cin, B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_tall, (size_t)ns*N*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_cinall, (size_t)ns*B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_dtall, (size_t)ns*B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_supall, (size_t)ns*B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_sig0, B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_noise, (size_t)(ns+1)*lat_elems*4)) goto err;
+	if (mlsd_malloc((void**)&S->d_noise, (size_t)S->n_draw_max*lat_elems*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_nan, 256)) goto err;
-	if (mlsd_host_alloc((void**)&S->h_noise, (size_t)(ns+1)*lat_elems*4)) goto err;
-	if (mlsd_host_alloc((void**)&S->h_scal, (size_t)ns*(N+3*B)*4 + B*4)) goto err;
-	for (int i=0;i<ns;++i) { if (mlsd_event_create(&S->ev[i][0]) || mlsd_event_create(&S->ev[i][1])) goto err; S->n_ev = i+1; }
+	if (mlsd_host_alloc((void**)&S->h_noise, (size_t)S->n_draw_max*lat_elems*4)) goto err;
+	if (mlsd_host_alloc((void**)&S->h_scal, (size_t)2*ns*(N+B)*4)) goto err;
+	for (int i=0;i<2*ns;++i) { if (mlsd_event_create(&S->ev[i][0]) || mlsd_event_create(&S->ev[i][1])) goto err; S->n_ev = i+1; }
 
-	/* ---- UNet plan, x bound to the resident latent (c_in scaling + cond/uncond duplication in the gather) */
+	/* ---- UNet plan, x bound to the resident evaluation point (c_in scaling + cond/uncond duplication in the gather) */
 	S->unet_ctx = mlctx_new(stream);
 	if (S->c.use_hipgraph) mlctx_set_flags(S->unet_ctx, MLB_F_HIPGRAPH);
 	if (unet_denoise_init(&S->unet, S->unet_ctx, &S->unet_p, S->lw, S->lh, N) < 0) goto err;
-	if (mlctx_input_bind(S->unet.t_x, S->d_x, B, S->d_cin, 1.0f, 0) < 0) { fail("input bind failed"); goto err; }
+	if (mlctx_input_bind(S->unet.t_x, S->d_xin, B, S->d_cin, 1.0f, 0) < 0) { fail("input bind failed"); goto err; }
 	if (unet_denoise_build(&S->unet) < 0) goto err;
-	if (mlctx_params_synth(S->unet_ctx, S->c.weight_seed) < 0) goto err;
+	if (!S->c.defer_weights && mlctx_params_synth(S->unet_ctx, S->c.weight_seed) < 0) goto err;
 
 	/* ---- decoder plan, latent input bound to the same resident latent */
 	S->dec_ctx = mlctx_new(stream);
@@ -122,11 +151,17 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 		if (mlctx_input_bind(S->t_lat_dec, S->d_x, B, NULL, 1 / S->vae_p.scale_factor, 0) < 0) goto err;
 		if (sdvae_decode_build(S->dec_ctx, &S->vae_p, S->t_lat_dec) < 0) goto err;
 	}
-	if (mlctx_params_synth(S->dec_ctx, S->c.weight_seed) < 0) goto err;
+	if (!S->c.defer_weights && mlctx_params_synth(S->dec_ctx, S->c.weight_seed) < 0) goto err;
 	return S;
 err:
 	mlis_amd_destroy(S);
 	return NULL;
+}
+
+MLB_API int mlis_amd_set_callback(MLIS_AmdCtx* S, mlis_amd_progress_fn fn, void* user)
+{
+	S->cb = fn; S->cb_user = user;
+	return 1;
 }
 
 static int fill_cond(MLIS_AmdCtx* S, MLTensor* t, const void* a, const void* b, size_t per_bytes, int kind)
@@ -160,80 +195,213 @@ MLB_API int mlis_amd_set_cond_device(MLIS_AmdCtx* S, const void* cond, const voi
 	return set_cond(S, cond, label, uncond, unlabel, 2);
 }
 
+MLB_API int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds)
+{
+	for (int b=0;b<S->B;++b) { S->rng[b].seed = seeds[b]; S->rng[b].offset = 0; }
+	return 1;
+}
+
+/* initial latent for img2img (MLIS_TUF_LATENT, src/mlimgsynth.c:1661-1666): host NCHW [B][4][lh][lw], or NULL to go back
+ * to txt2img (zero latent) */
+MLB_API int mlis_amd_set_init_latent(MLIS_AmdCtx* S, const float* latent)
+{
+	if (!latent) { S->have_init_latent = 0; return 1; }
+	if (mlsd_memcpy(S->d_x, latent, (size_t)S->B*4*S->hw*4, 0, S->stream) || mlsd_stream_sync(S->stream)) return -1;
+	S->have_init_latent = 1;
+	return 1;
+}
+
+/* latent mask for in-painting (MLIS_TUF_LMASK): host [lh][lw], 1 = keep the original latent; NULL clears it */
+MLB_API int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask)
+{
+	if (!lmask) { S->have_lmask = 0; return 1; }
+	if (mlsd_memcpy(S->d_lmask, lmask, (size_t)S->hw*4, 0, S->stream) || mlsd_stream_sync(S->stream)) return -1;
+	S->have_lmask = 1;
+	return 1;
+}
+
+/* ------------------------------------------------------------------ noise draws
+ * Every dnsamp_noise_add (src/sampling.c:112-117) is one rng_randn call of the whole latent per image.  Which draws a
+ * run makes is known from the schedule alone, so draw k is generated on the host as soon as the evaluation before it
+ * has been enqueued (the GPU is busy for tens of ms) and uploaded asynchronously. */
+static const float* noise_draw(MLIS_AmdCtx* S, int k)
+{
+	const size_t per = (size_t)4 * S->hw, lat_elems = (size_t)S->B * per;
+	if (k >= S->n_draw_max) { fail("internal: too many noise draws"); return NULL; }
+	for (; S->n_draw_gen <= k; S->n_draw_gen++) {
+		float *hn = S->h_noise + (size_t)S->n_draw_gen*lat_elems, *dn = S->d_noise + (size_t)S->n_draw_gen*lat_elems;
+		for (int b=0;b<S->B;++b) rng_philox_randn(&S->rng[b], (unsigned)per, hn + (size_t)b*per);
+		if (mlsd_memcpy(dn, hn, lat_elems*4, 0, S->stream)) return NULL;
+	}
+	return S->d_noise + (size_t)k*lat_elems;
+}
+
+/* mlis_denoise_dxdt + unet_denoise_run (src/mlimgsynth.c:1565-1587, src/unet.c:460-498): one batched evaluation at
+ * x_eval (device), sigma -> raw UNet output stays in the plan's result tensor.  `prefetch_draws`: noise draws to generate
+ * on the host while this evaluation runs. */
+static int unet_eval(MLIS_AmdCtx* S, const float* x_eval, float sigma, int prefetch_upto)
+{
+	const UnetParams *P = &S->unet_p;
+	const int B = S->B, N = S->N;
+	void *st = S->stream;
+	if (S->i_eval >= 2*S->c.n_step) return fail("internal: too many evaluations");
+	float *hs = S->h_scal + (size_t)S->i_eval*(N+B);
+	const float t = unet_sigma_to_t(P, sigma);
+	const float c_in = 1 / sqrt(sigma*sigma + 1);                /* unet.c:471 */
+	for (int n=0;n<N;++n) hs[n] = t;
+	for (int b=0;b<B;++b) hs[N+b] = c_in;
+	float *d_t_in = (float*)mlctx_input_device_ptr(S->unet.t_t);
+	if (mlsd_memcpy(d_t_in, hs, (size_t)N*4, 0, st) || mlsd_memcpy(S->d_cin, hs + N, (size_t)B*4, 0, st)) return -1;
+	if (x_eval != S->d_xin && mlsd_memcpy(S->d_xin, x_eval, (size_t)B*4*S->hw*4, 2, st)) return -1;
+	mlsd_event_record(S->ev[S->i_eval][0], st);
+	if (mlctx_compute(S->unet_ctx) < 0) return -1;               /* cond + uncond of all images: one evaluation */
+	mlsd_event_record(S->ev[S->i_eval][1], st);
+	S->i_eval++;
+	S->last_nfe += N / B;
+	int64_t ld = 0;
+	const float *eps = mlctx_tensor_device_f32(S->unet_ctx, S->unet.t_out, &ld);
+	if (mlsd_count_nonfinite(eps, (size_t)N*S->hw*ld, S->d_nan, st)) return -1;   /* ltensor_finite_check, unet.c:487 */
+	if (prefetch_upto >= 0 && !noise_draw(S, prefetch_upto)) return -1;
+	return 1;
+}
+
+/* dx = CFG mix (+ v-param rescale) of the evaluation just enqueued */
+static int dxdt_finish(MLIS_AmdCtx* S, const float* x_eval, float sigma, float* dx)
+{
+	int64_t ld = 0;
+	const float *eps = mlctx_tensor_device_f32(S->unet_ctx, S->unet.t_out, &ld);
+	const float c_skip = sigma / (sigma*sigma + 1), c_out = 1 / sqrt(sigma*sigma + 1);   /* unet.c:491-492 */
+	return mlsd_dxdt_cfg(eps, ld, x_eval, dx, S->B, 4, S->hw, S->c.cfg_scale, S->unet_p.vparam, c_out, c_skip, S->stream) ? -1 : 1;
+}
+
 MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 {
 	if (!S->cond_set) return fail("mlis_amd_denoise: conditioning not set");
 	const UnetParams *P = &S->unet_p;
-	const int B = S->B, N = S->N;
-	const size_t per = (size_t)4 * S->hw, lat_elems = (size_t)B * per;
+	const int B = S->B, method = S->c.method;
+	const int64_t nel = (int64_t)B * 4 * S->hw;
 	void *st = S->stream;
+	if (seeds) mlis_amd_seed(S, seeds);
 
-	/* ---- dnsamp_init: schedule + per-step scalars, exactly the reference's host arithmetic */
+	/* ---- dnsamp_init (src/sampling.c:28-96) */
 	float sigmas[MAX_STEPS+1];
-	const int n_step = dnsamp_schedule(P, S->c.n_step, S->c.sched, 1.0f, 0.0f, sigmas);
+	int n_req = S->c.n_step;
+	const int nfe_solver = solver_nfe(method);
+	if (nfe_solver > 1) n_req = (n_req + nfe_solver - 1) / nfe_solver;        /* keep the NFE count (:47-49) */
+	const int n_step = dnsamp_schedule(P, n_req, S->c.sched, S->c.f_t_ini, S->c.f_t_end, sigmas);
 	if (n_step < 0 || n_step > S->c.n_step) return fail("schedule failed");
-	float *h_t = S->h_scal, *h_cin = h_t + (size_t)n_step*N, *h_dt = h_cin + (size_t)n_step*B,
-	      *h_sup = h_dt + (size_t)n_step*B, *h_sig0 = h_sup + (size_t)n_step*B;
-	int need_noise[MAX_STEPS];
-	float solver_t = sigmas[0];                                   /* sampling.c:92 */
+	float solver_t = sigmas[0];                                               /* :92 */
+	unsigned i_step_solver = 0;
+	float dt_prev = 0, h_last = 0;                                            /* taylor3 / dpmpp2m scalar state */
+	S->n_draw_gen = 0; S->i_eval = 0; S->last_nfe = 0; S->last_n_step = n_step;
+	int k_draw = 0;
+	if (mlsd_memset(S->d_nan, 0, 4, st)) return -1;
+	if (!S->have_init_latent && mlsd_memset(S->d_x, 0, (size_t)nel*4, st)) return -1;   /* mlimgsynth.c:1669-1670 */
+	if (method == SOLVER_METHOD_TAYLOR3 || method == SOLVER_METHOD_DPMPP2M) {
+		/* solver tmp tensors start zeroed (ltensor_resize of an empty tensor; values unused until i_step >= 1) */
+		if (mlsd_memset(S->d_tmp[0], 0, (size_t)nel*4, st) || mlsd_memset(S->d_tmp[1], 0, (size_t)nel*4, st)) return -1;
+	}
+
 	for (int s=0; s<n_step; ++s) {
 		float s_up = 0, s_down = sigmas[s+1];
-		if (S->c.s_ancestral > 0) dnsamp_ancestral(sigmas[s], sigmas[s+1], S->c.s_ancestral, &s_down, &s_up);
-		const float sigma = solver_t;                              /* dxdt evaluated at the solver's t (solvers.c:84-85) */
-		const float t = unet_sigma_to_t(P, sigma);
-		const float c_in = 1 / sqrt(sigma*sigma + 1);              /* unet.c:471 */
-		const float dt = s_down - sigma;                           /* solvers.c:84 */
-		for (int n=0;n<N;++n) h_t[(size_t)s*N + n] = t;
-		for (int b=0;b<B;++b) { h_cin[(size_t)s*B+b] = c_in; h_dt[(size_t)s*B+b] = dt; h_sup[(size_t)s*B+b] = s_up; }
-		solver_t = s_down;
-		need_noise[s] = (s_up > 0 && s+1 != n_step);
-		if (need_noise[s]) solver_t = sigmas[s+1];                 /* sampling.c:173 */
-	}
-	for (int b=0;b<B;++b) h_sig0[b] = sigmas[0];
-	if (mlsd_memcpy(S->d_tall, h_t, (size_t)n_step*N*4, 0, st) || mlsd_memcpy(S->d_cinall, h_cin, (size_t)n_step*B*4, 0, st) ||
-	    mlsd_memcpy(S->d_dtall, h_dt, (size_t)n_step*B*4, 0, st) || mlsd_memcpy(S->d_supall, h_sup, (size_t)n_step*B*4, 0, st) ||
-	    mlsd_memcpy(S->d_sig0, h_sig0, B*4, 0, st)) return -1;
-
-	/* ---- initial latent: zeros + N(0,1)*sigma_0 (mlimgsynth.c:1669-1670, sampling.c:133) */
-	RngPhilox rng[64];
-	if (B > 64) return fail("n_batch > 64 not supported");
-	for (int b=0;b<B;++b) { rng[b].seed = seeds[b]; rng[b].offset = 0; }
-	for (int b=0;b<B;++b) rng_philox_randn(&rng[b], (unsigned)per, S->h_noise + (size_t)b*per);
-	if (mlsd_memset(S->d_x, 0, lat_elems*4, st) || mlsd_memset(S->d_nan, 0, 4, st)) return -1;
-	if (mlsd_memcpy(S->d_noise, S->h_noise, lat_elems*4, 0, st)) return -1;
-	if (mlsd_noise_add(S->d_x, S->d_noise, S->d_sig0, B, (int64_t)per, st)) return -1;
-
-	int64_t ld_eps = 0;
-	const float *eps = mlctx_tensor_device_f32(S->unet_ctx, S->unet.t_out, &ld_eps);
-	float *d_t_in = (float*)mlctx_input_device_ptr(S->unet.t_t);
-	int nfe = 0;
-	for (int s=0; s<n_step; ++s) {
-		/* this step's scalars into the plan's fixed input slots */
-		if (mlsd_memcpy(d_t_in, S->d_tall + (size_t)s*N, (size_t)N*4, 2, st) ||
-		    mlsd_memcpy(S->d_cin, S->d_cinall + (size_t)s*B, (size_t)B*4, 2, st)) return -1;
-		mlsd_event_record(S->ev[s][0], st);
-		if (mlctx_compute(S->unet_ctx) < 0) return -1;           /* cond + uncond of all images: one evaluation */
-		mlsd_event_record(S->ev[s][1], st);
-		nfe += N / B;
-		if (mlsd_count_nonfinite(eps, (size_t)N*S->hw*4, S->d_nan, st)) return -1;   /* ltensor_finite_check, unet.c:487 */
-		const float *noise = NULL;
-		if (need_noise[s]) {
-			/* host Philox for THIS step while the GPU is busy with the evaluation just enqueued */
-			float *hn = S->h_noise + (size_t)(s+1)*lat_elems, *dn = S->d_noise + (size_t)(s+1)*lat_elems;
-			for (int b=0;b<B;++b) rng_philox_randn(&rng[b], (unsigned)per, hn + (size_t)b*per);
-			if (mlsd_memcpy(dn, hn, lat_elems*4, 0, st)) return -1;
-			noise = dn;
+		if (s == 0) {                                                         /* sampling.c:129-137 */
+			if (S->have_lmask && mlsd_memcpy(S->d_x0, S->d_x, (size_t)nel*4, 2, st)) return -1;
+			const float *nz = noise_draw(S, k_draw++);
+			if (!nz || mlsd_noise_add_s(S->d_x, nz, sigmas[0], nel, st)) return -1;
+			if (S->have_lmask && mlsd_mask_apply(S->d_x, S->d_x0, S->d_lmask, S->hw, nel, st)) return -1;
 		}
-		if (mlsd_sampler_update(S->d_x, eps, ld_eps, B, 4, S->hw, S->c.cfg_scale, S->d_dtall + (size_t)s*B, noise,
-				S->d_supall + (size_t)s*B, st)) return -1;
+		if (S->c.s_noise > 0 && s > 0) {                                      /* :139-151 */
+			float s_curr = sigmas[s], s_hat = s_curr * sqrt(2) * S->c.s_noise, s_n = sqrt(s_hat*s_hat - s_curr*s_curr);
+			const float *nz = noise_draw(S, k_draw++);
+			if (!nz || mlsd_noise_add_s(S->d_x, nz, s_n, nel, st)) return -1;
+			if (S->have_lmask && mlsd_mask_apply(S->d_x, S->d_x0, S->d_lmask, S->hw, nel, st)) return -1;
+			solver_t = s_hat;
+		}
+		if (S->c.s_ancestral > 0) dnsamp_ancestral(sigmas[s], sigmas[s+1], S->c.s_ancestral, &s_down, &s_up);   /* :153-166 */
+		const int anc_noise = (s_up > 0 && s+1 != n_step);
+		/* draws to have ready by the end of this step's first evaluation: the ancestral one and the next step's s_noise one */
+		const int k_prefetch = k_draw - 1 + anc_noise + ((S->c.s_noise > 0 && s+1 < n_step) ? 1 : 0);
+
+		/* ---- solver_step(&S->solver, s_down, x)  (src/solvers.c:43-52) */
+		const float t0 = solver_t, t1 = s_down;
+		if (!(t0 >= 0)) return fail("negative solver time");
+		switch (method) {
+		case SOLVER_METHOD_EULER: {                                           /* :82-88 */
+			if (unet_eval(S, S->d_x, t0, k_prefetch) < 0) return -1;
+			if (!P->vparam) {   /* fused: CFG mix, x += dx*dt and the ancestral noise of sampling.c:170-172 in one launch */
+				int64_t ld = 0;
+				const float *eps = mlctx_tensor_device_f32(S->unet_ctx, S->unet.t_out, &ld);
+				const float *nz = anc_noise ? noise_draw(S, k_draw) : NULL;
+				if (anc_noise && !nz) return -1;
+				if (mlsd_euler_cfg_update(S->d_x, eps, ld, B, 4, S->hw, S->c.cfg_scale, t1 - t0, nz, s_up, st)) return -1;
+				if (nz) { k_draw++; s_up = -1; }                               /* noise already added */
+			} else {
+				if (dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
+				if (mlsd_vec_axpy(S->d_x, S->d_x, S->d_dx, t1 - t0, nel, st)) return -1;
+			}
+		} break;
+		case SOLVER_METHOD_HEUN: {                                            /* :96-117 */
+			const float dt = t1 - t0;
+			float *x1 = S->d_tmp[0], *d1 = S->d_tmp[1];
+			if (unet_eval(S, S->d_x, t0, k_prefetch) < 0 || dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
+			if (mlsd_vec_axpy(x1, S->d_x, S->d_dx, dt, nel, st)) return -1;
+			if (!(t1 > 0)) { if (mlsd_memcpy(S->d_x, x1, (size_t)nel*4, 2, st)) return -1; }
+			else {
+				if (unet_eval(S, x1, t1, -1) < 0 || dxdt_finish(S, x1, t1, d1) < 0) return -1;
+				if (mlsd_solver_heun_corr(S->d_x, S->d_dx, d1, dt, nel, st)) return -1;
+			}
+		} break;
+		case SOLVER_METHOD_TAYLOR3: {                                         /* :137-168 */
+			const float dt = t1 - t0;
+			if (unet_eval(S, S->d_x, t0, k_prefetch) < 0 || dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
+			float idtp = i_step_solver >= 1 ? 1 / dt_prev : 0, f2 = i_step_solver >= 1 ? dt*dt/2 : 0,
+			      f3 = i_step_solver >= 2 ? dt*dt*dt/6 : 0;
+			if (mlsd_solver_taylor3(S->d_x, S->d_dx, S->d_tmp[0], S->d_tmp[1], dt, idtp, f2, f3, nel, st)) return -1;
+			dt_prev = dt;
+		} break;
+		case SOLVER_METHOD_DPMPP2M: {                                         /* :207-233 */
+			float a = t1 / t0, h = -log(a), c = h / (2*h_last);
+			if (i_step_solver == 0 || !(t1 > 0)) c = 0;
+			if (unet_eval(S, S->d_x, t0, k_prefetch) < 0 || dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
+			if (mlsd_solver_dpmpp2m(S->d_x, S->d_dx, S->d_tmp[0], t0, a, c, nel, st)) return -1;
+			h_last = h;
+		} break;
+		case SOLVER_METHOD_DPMPP2S: {                                         /* :264-289 */
+			float *x1 = S->d_tmp[0], *dx1 = S->d_tmp[1];
+			if (unet_eval(S, S->d_x, t0, k_prefetch) < 0 || dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
+			if (!(t1 > 0)) { if (mlsd_vec_axpy(S->d_x, S->d_x, S->d_dx, t1 - t0, nel, st)) return -1; }
+			else {
+				float tm = sqrt(t1 * t0), dt1 = tm - t0, a = t1 / t0;
+				if (mlsd_vec_axpy(x1, S->d_x, S->d_dx, dt1, nel, st)) return -1;
+				if (unet_eval(S, x1, tm, -1) < 0 || dxdt_finish(S, x1, tm, dx1) < 0) return -1;
+				if (mlsd_solver_dpmpp2s(S->d_x, x1, dx1, tm, a, nel, st)) return -1;
+			}
+		} break;
+		default: return fail("invalid sampling method");
+		}
+		solver_t = t1; i_step_solver++;                                       /* solvers.c:49-50 */
+
+		if (s_up > 0 && s+1 != n_step) {                                      /* sampling.c:170-174 */
+			const float *nz = noise_draw(S, k_draw++);
+			if (!nz || mlsd_noise_add_s(S->d_x, nz, s_up, nel, st)) return -1;
+		}
+		if (anc_noise) solver_t = sigmas[s+1];
+		if (S->have_lmask && mlsd_mask_apply(S->d_x, S->d_x0, S->d_lmask, S->hw, nel, st)) return -1;   /* :176-178 */
+
+		if (S->cb) {   /* mlis_callback (mlimgsynth.c:1741-1745): reports COMPLETED steps, a negative return aborts */
+			if (mlsd_stream_sync(st)) return -1;
+			int r = S->cb(S->cb_user, s + 1, n_step, S->last_nfe);
+			if (r < 0) return r;
+		}
 	}
 	int32_t nan_count = 0;
 	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;
 	float tot = 0;
-	for (int s=0; s<n_step; ++s) { float ms = 0; mlsd_event_elapsed_ms(S->ev[s][0], S->ev[s][1], &ms); tot += ms; }
-	S->last_unet_ms = tot; S->last_nfe = nfe;
-	S->unet.nfe += nfe;
-	if (nan_count) return mlsd_set_error(-1, "NaN found in UNet output (%d values)", nan_count);
+	for (int i=0; i<S->i_eval; ++i) { float ms = 0; mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &ms); tot += ms; }
+	S->last_unet_ms = tot;
+	S->unet.nfe += S->last_nfe;
+	S->have_init_latent = 0;                /* f_t_ini / latent use flags are cleared after a generation (mlimgsynth.c:700-706) */
+	if (nan_count) return mlsd_set_error(-7 /* MLIS_E_NAN */, "NaN found in UNet output (%d values)", nan_count);
 	return 1;
 }
 
@@ -250,9 +418,56 @@ MLB_API int mlis_amd_decode(MLIS_AmdCtx* S)
 	return 1;
 }
 
+/* mlis_image_encode (src/mlimgsynth.c:1301-1330): images host NCHW [B][3][H][W] in [0,1] -> the resident latent becomes
+ * the sampled (VAE: mean + std*N(0,1), one Philox call per image, src/vae.c:203-229) or direct (TAE) encoding and is
+ * marked as the initial latent of the next denoise.  The encoder plan is built on first use. */
+MLB_API int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample)
+{
+	const int B = S->B, W = S->c.width, H = S->c.height;
+	const size_t img_elems = (size_t)B*3*W*H;
+	void *st = S->stream;
+	if (!S->enc_ctx) {
+		if (!S->d_img_in && mlsd_malloc((void**)&S->d_img_in, img_elems*4)) return -1;
+		S->enc_ctx = mlctx_new(st);
+		if (S->c.use_tae) {
+			if (sdtae_encode_init(S->enc_ctx, W, H, B, &S->t_img_enc) < 0) return -1;
+			if (mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 0) < 0) return -1;
+			if (sdtae_encode_build(S->enc_ctx, S->t_img_enc) < 0) return -1;
+		} else {
+			if (sdvae_encode_init(S->enc_ctx, &S->vae_p, W, H, B, &S->t_img_enc) < 0) return -1;
+			if (mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 2) < 0) return -1;   /* mode 2: x*2-1 (vae.h:36-40) */
+			if (sdvae_encode_build(S->enc_ctx, &S->vae_p, S->t_img_enc) < 0) return -1;
+		}
+		if (!S->c.defer_weights && mlctx_params_synth(S->enc_ctx, S->c.weight_seed) < 0) return -1;
+	}
+	if (mlsd_memcpy(S->d_img_in, images, img_elems*4, 0, st)) return -1;
+	if (mlctx_compute(S->enc_ctx) < 0) return -1;
+	MLTensor *r = mlctx_result(S->enc_ctx);
+	int64_t ld = 0;
+	const float *y = mlctx_tensor_device_f32(S->enc_ctx, r, &ld);
+	if (mlsd_memset(S->d_nan, 0, 4, st) || mlsd_count_nonfinite(y, (size_t)B*S->hw*ld, S->d_nan, st)) return -1;
+	if (S->c.use_tae) {
+		if (mlsd_nhwc_to_nchw_f32(y, ld, B, 4, S->hw, S->d_x, 1.0f, 0.0f, st)) return -1;
+	} else {
+		const float *rnd = NULL;
+		if (sample) {   /* sdvae_latent_sample: rng_randn(n) per image, before any denoising draw */
+			S->n_draw_gen = 0;
+			rnd = noise_draw(S, 0);
+			if (!rnd) return -1;
+		}
+		if (mlsd_latent_sample(y, ld, rnd, S->d_x, B, S->vae_p.ch_z, S->hw, S->vae_p.scale_factor, st)) return -1;
+	}
+	int32_t nan_count = 0;
+	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;
+	if (nan_count) return mlsd_set_error(-7, "NaN found in encoded latent");   /* mlimgsynth.c:1323 */
+	S->have_init_latent = 1;
+	return 1;
+}
+
 MLB_API int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* latents_out, float* images_out)
 {
-	if (mlis_amd_denoise(S, seeds) < 0) return -1;
+	int r = mlis_amd_denoise(S, seeds);
+	if (r < 0) return r;
 	if (latents_out && mlsd_memcpy(latents_out, S->d_x, (size_t)S->B*4*S->hw*4, 1, S->stream)) return -1;
 	if (mlis_amd_decode(S) < 0) return -1;
 	if (images_out && mlsd_memcpy(images_out, S->d_img, (size_t)S->B*3*S->c.width*S->c.height*4, 1, S->stream)) return -1;
@@ -264,8 +479,10 @@ MLB_API void* mlis_amd_latent_device(MLIS_AmdCtx* S) { return S->d_x; }
 MLB_API void* mlis_amd_image_device(MLIS_AmdCtx* S) { return S->d_img; }
 MLB_API MLCtx* mlis_amd_unet_ctx(MLIS_AmdCtx* S) { return S->unet_ctx; }
 MLB_API MLCtx* mlis_amd_decoder_ctx(MLIS_AmdCtx* S) { return S->dec_ctx; }
+MLB_API MLCtx* mlis_amd_encoder_ctx(MLIS_AmdCtx* S) { return S->enc_ctx; }
 MLB_API float mlis_amd_last_unet_ms(MLIS_AmdCtx* S) { return S->last_unet_ms; }
 MLB_API int mlis_amd_last_nfe(MLIS_AmdCtx* S) { return S->last_nfe; }
+MLB_API int mlis_amd_last_n_step(MLIS_AmdCtx* S) { return S->last_n_step; }
 
 MLB_API int mlis_amd_info(MLIS_AmdCtx* S, double* unet_flops, double* dec_flops, int* unet_ops, size_t* mem_params, size_t* mem_compute)
 {

@@ -122,6 +122,7 @@ typedef struct {
 } MLEpilogue;
 MLTensor* mlb_linear_ex(MLCtx* C, MLTensor* x, int n_out, bool bias, const MLEpilogue* ep, int geglu);
 MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int upsample, bool bias, const MLEpilogue* ep);
+MLTensor* mlb_conv2d_ex2(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int p_end, int upsample, bool bias, const MLEpilogue* ep);
 MLTensor* mlb_groupnorm_ex(MLCtx* C, MLTensor* x, int n_grp, float eps, int silu, int want_raw16, MLTensor** raw_out);
 MLTensor* mlb_layer_norm_ex(MLCtx* C, MLTensor* x, float eps, int out32);
 MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int d_out, int d_embed, int n_head,

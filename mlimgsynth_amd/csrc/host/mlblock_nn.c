@@ -63,6 +63,13 @@ MLB_API MLTensor* mlb_nn_linear(MLCtx* C, MLTensor* x, int n_out, bool bias)
 /* ------------------------------------------------------------------ conv2d */
 MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int upsample, bool bias, const MLEpilogue* ep)
 {
+	return mlb_conv2d_ex2(C, x, ch_out, k, s, p, p, upsample, bias, ep);
+}
+
+/* p = zero padding before the first row/column, p_end = after the last (ggml_pad(x,1,1,0,0) + conv p=0 of the VAE
+ * encoder's downsample, src/mlblock_nn.c:109-111, is p = 0, p_end = 1: the gather's bounds check supplies the zeros) */
+MLTensor* mlb_conv2d_ex2(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, int p_end, int upsample, bool bias, const MLEpilogue* ep)
+{
 	if (!x || C->err) return NULL;
 	mlctx_block_begin(C);
 	const int ch_in = x->c, cpad = (ch_in + 7) / 8 * 8;
@@ -75,7 +82,7 @@ MLTensor* mlb_conv2d_ex(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p, 
 	const float *bd = NULL;
 	if (bias) { MLParam *b = mlctx_param_new(C, "bias", MLT_F32, ch_out, 1, 1, 1, 0, 0, 0); bd = (const float*)b->dev; }
 	const int H = x->h, W = x->w, He = upsample ? 2*H : H, We = upsample ? 2*W : W;
-	const int OH = (He + 2*p - k)/s + 1, OW = (We + 2*p - k)/s + 1;
+	const int OH = (He + p + p_end - k)/s + 1, OW = (We + p + p_end - k)/s + 1;
 	MLTensor *y = mlt_new(C, x->n, OH, OW, ch_out);
 	const float *rd = NULL, *rb = NULL; int64_t ldr = 0;
 	if (ep && ep->resid) {
@@ -178,7 +185,7 @@ MLB_API MLTensor* mlb_nn_layer_norm(MLCtx* C, MLTensor* x, bool affine, bool bia
 MLB_API MLTensor* mlb_downsample(MLCtx* C, MLTensor* x, int ch_out, bool vae)
 {
 	mlctx_block_begin(C);
-	if (vae) { mlctx_fail(C, "VAE-encoder downsample (end padding) is not implemented yet"); return NULL; }
+	if (vae) return MLN("conv", mlb_conv2d_ex2(C, x, ch_out, 3, 2, 0, 1, 0, T, NULL));   /* ggml_pad(x,1,1,0,0) + conv p=0 (:109-111) */
 	return MLN("conv", mlb_conv2d_ex(C, x, ch_out, 3, 2, 1, 0, T, NULL));
 }
 

@@ -32,6 +32,10 @@ MLB_API int unet_params_get(const char* model, UnetParams* U)
 		int a[4]={2,1,0,0}, m[5]={1,2,0,0,0}, d[5]={1,1,0,0,0};
 		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));
 		U->n_ch=64; U->n_te=256; U->n_head=2; U->n_ctx=64; U->n_res_blk=1; U->clip_norm=1;
+	} else if (!strcmp(model,"tinyv")) {   /* tiny with v-prediction (SD2-style: d_head given, vparam) */
+		int a[4]={2,1,0,0}, m[5]={1,2,0,0,0}, d[5]={1,1,0,0,0};
+		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));
+		U->n_ch=64; U->n_te=256; U->d_head=32; U->n_ctx=64; U->n_res_blk=1; U->clip_norm=1; U->vparam=1;
 	} else if (!strcmp(model,"tinyxl")) {
 		int a[4]={2,0,0,0}, m[5]={1,2,0,0,0}, d[5]={1,2,0,0,0};
 		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));

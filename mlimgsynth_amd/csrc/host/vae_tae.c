@@ -20,7 +20,7 @@ MLB_API int vae_params_get(const char* model, VaeParams* V)
 	V->d_embed=4; V->f_down=8;
 	if (!strcmp(model,"sd1") || !strcmp(model,"sd2")) V->scale_factor = 0.18215f;
 	else if (!strcmp(model,"sdxl")) V->scale_factor = 0.13025f;
-	else if (!strcmp(model,"tiny") || !strcmp(model,"tinyxl")) { V->scale_factor = 0.18215f; V->ch = 64; V->n_res_blk = 1; }
+	else if (!strcmp(model,"tiny") || !strcmp(model,"tinyxl") || !strcmp(model,"tinyv")) { V->scale_factor = 0.18215f; V->ch = 64; V->n_res_blk = 1; }
 	else return mlsd_set_error(-1, "unknown VAE model '%s'", model);
 	return 1;
 }
@@ -81,6 +81,80 @@ static MLTensor* mlb_attn_2d_self(MLCtx* C, MLTensor* x)
 	MLTensor *y = MLN("proj_out", mlb_conv2d_ex(C, a, c, 1, 1, 0, 0, T, &ep));
 	mlb_release(C, a);
 	return y;
+}
+
+/* mlb_kl_encoder, src/vae.c:76-118 */
+static MLTensor* mlb_kl_encoder(MLCtx* C, MLTensor* x, int ch_out, int ch, int n_res, int n_res_blk, const int* ch_mult)
+{
+	char name[64];
+	mlctx_block_begin(C);
+	MLTensor *y;
+	x = MLN("conv_in", mlb_conv2d_ex(C, x, ch, 3, 1, 1, 0, T, NULL));
+	if (!x || !mlt_need32(C, x)) return NULL;
+	int ch_blk = ch;
+	for (int i=0; i<n_res; ++i) {
+		int ch_blk_out = ch * ch_mult[i];
+		for (int j=0; j<n_res_blk; ++j) {
+			sprintf(name, "down.%d.block.%d", i, j);
+			y = MLN(name, mlb_resnet_ex(C, x, NULL, ch_blk_out)); if (!y || !mlt_need32(C, y)) return NULL; mlb_release(C, x); x = y;
+			ch_blk = ch_blk_out;
+		}
+		if (i+1 != n_res) {
+			sprintf(name, "down.%d.downsample", i);
+			y = MLN(name, mlb_downsample(C, x, ch_blk, T)); if (!y || !mlt_need32(C, y)) return NULL; mlb_release(C, x); x = y;
+		}
+	}
+	y = MLN("mid.block_1", mlb_resnet_ex(C, x, NULL, ch_blk)); if (!y || !mlt_need32(C, y)) return NULL; mlb_release(C, x); x = y;
+	y = MLN("mid.attn_1", mlb_attn_2d_self(C, x));             if (!y || !mlt_need32(C, y)) return NULL; mlb_release(C, x); x = y;
+	y = MLN("mid.block_2", mlb_resnet_ex(C, x, NULL, ch_blk)); if (!y || !mlt_need32(C, y)) return NULL; mlb_release(C, x); x = y;
+	MLTensor *h = MLN("norm_out", mlb_groupnorm_ex(C, x, 32, 1e-6f, 1, 0, NULL));
+	mlb_release(C, x);
+	x = MLN("conv_out", mlb_conv2d_ex(C, h, ch_out, 3, 1, 1, 0, T, NULL));
+	mlb_release(C, h);
+	return x;
+}
+
+/* mlb_sdvae_encoder, src/vae.c:120-128: image [W,H,3,N] in [-1,1] -> moments [W/8,H/8,2*ch_z,N] (mean | logvar).
+ * The [0,1] -> [-1,1] map of sdvae_encoder_pre (src/vae.h:36-40) is applied by the caller's input conversion. */
+MLB_API MLTensor* mlb_sdvae_encoder(MLCtx* C, MLTensor* x, const VaeParams* P)
+{
+	if (x->c != P->ch_x) { mlctx_fail(C, "sdvae_encoder: image must have %d channels", P->ch_x); return NULL; }
+	MLTensor *y = MLN("encoder", mlb_kl_encoder(C, x, P->ch_z*2, P->ch, P->n_res, P->n_res_blk, P->ch_mult));
+	if (!y) return NULL;
+	y = MLN("quant_conv", mlb_conv2d_ex(C, y, P->ch_z*2, 1, 1, 0, 0, T, NULL));
+	if (!y || !mlt_need32(C, y)) return NULL;
+	return y;
+}
+
+MLB_API int sdvae_encode_init(MLCtx* C, const VaeParams* P, unsigned w, unsigned h, unsigned n_batch, MLTensor** t_img)
+{
+	if (w % P->f_down || h % P->f_down) return mlsd_set_error(-1, "invalid input image shape: %ux%u", w, h);   /* vae.c:241-243 */
+	mlctx_begin(C, "VAE encode");
+	mlctx_set_tprefix(C, "vae");
+	*t_img = mlctx_input_new_img(C, "img", w, h, P->ch_x, n_batch);
+	return *t_img ? 1 : -1;
+}
+
+MLB_API int sdvae_encode_build(MLCtx* C, const VaeParams* P, MLTensor* t_img)
+{
+	if (!mlb_sdvae_encoder(C, t_img, P)) return -1;
+	return mlctx_prep(C);
+}
+
+/* host-boundary encode: img NCHW [n][3][h][w] in [0,1] -> moments NCHW [n][2*ch_z][h/8][w/8] (no sampling) */
+MLB_API int sdvae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float* moments)
+{
+	const size_t n_in = t_img->in_bytes / 4;
+	float *tmp = (float*)malloc(n_in * 4);
+	for (size_t i=0;i<n_in;++i) tmp[i] = img[i]*2 - 1;                      /* sdvae_encoder_pre */
+	int R = mlctx_input_set(C, t_img, tmp, t_img->in_bytes);
+	free(tmp);
+	if (R < 0 || mlctx_compute(C) < 0) return -1;
+	MLTensor *r = mlctx_result(C);
+	const size_t n = (size_t)r->n * r->h * r->w * r->c;
+	if (mlctx_output_get(C, r, moments, n*4) < 0) return -1;
+	for (size_t i=0;i<n;++i) if (!isfinite(moments[i])) return mlsd_set_error(-1, "NaN found in encoded latent");   /* mlimgsynth.c:1323 */
+	return 1;
 }
 
 /* mlb_kl_decoder, src/vae.c:130-169 */
@@ -207,6 +281,30 @@ MLB_API MLTensor* mlb_sdtae_decoder(MLCtx* C, MLTensor* x, const SdTaeParams* P)
 	return y;
 }
 
+MLB_API MLTensor* mlb_sdtae_encoder(MLCtx* C, MLTensor* x, const SdTaeParams* P)
+{	/* src/tae.c:43-63 */
+	int iblk = 0;
+	char name[32];
+	mlctx_block_begin(C);
+	MLTensor *y;
+	x = MLN(IDX2NAME(iblk++), mlb_conv2d_ex(C, x, P->ch_inner, 3, 1, 1, 0, T, NULL));
+	if (!x || !mlt_need32(C, x)) return NULL;
+	y = MLN(IDX2NAME(iblk++), mlb_sdtae_block(C, x, P->ch_inner)); if (!y) return NULL;
+	mlb_release(C, x); x = y;
+	for (int j=0; j<3; ++j) {
+		y = MLN(IDX2NAME(iblk++), mlb_conv2d_ex(C, x, P->ch_inner, 3, 2, 1, 0, F, NULL)); if (!y || !mlt_need32(C, y)) return NULL;
+		mlb_release(C, x); x = y;
+		for (int i=0; i<P->n_blk; ++i) {
+			y = MLN(IDX2NAME(iblk++), mlb_sdtae_block(C, x, P->ch_inner)); if (!y) return NULL;
+			mlb_release(C, x); x = y;
+		}
+	}
+	y = MLN(IDX2NAME(iblk++), mlb_conv2d_ex(C, x, P->ch_z, 3, 1, 1, 0, T, NULL));
+	if (!y || !mlt_need32(C, y)) return NULL;
+	mlb_release(C, x);
+	return y;
+}
+
 static const SdTaeParams g_sdtae_sd1 = { 3, 64, 4, 3 };   /* src/tae.c:17-22 */
 
 MLB_API int sdtae_decode_init(MLCtx* C, unsigned lw, unsigned lh, unsigned n_batch, MLTensor** t_latent)
@@ -223,6 +321,31 @@ MLB_API int sdtae_decode_build(MLCtx* C, MLTensor* t_latent)
 	if (!out) return -1;
 	mlctx_tensor_add(C, "decoder.layers", out);   /* src/tae.c:128 */
 	return mlctx_prep(C);
+}
+
+MLB_API int sdtae_encode_init(MLCtx* C, unsigned w, unsigned h, unsigned n_batch, MLTensor** t_img)
+{
+	if (w % 8 || h % 8) return mlsd_set_error(-1, "invalid input image shape: %ux%u", w, h);   /* tae.c:100-103 */
+	mlctx_begin(C, "TAE encode");
+	mlctx_set_tprefix(C, "tae");
+	*t_img = mlctx_input_new_img(C, "img", w, h, 3, n_batch);
+	return *t_img ? 1 : -1;
+}
+
+MLB_API int sdtae_encode_build(MLCtx* C, MLTensor* t_img)
+{
+	MLTensor *out = mlb_sdtae_encoder(C, t_img, &g_sdtae_sd1);
+	if (!out) return -1;
+	mlctx_tensor_add(C, "encoder.layers", out);   /* src/tae.c:110 */
+	return mlctx_prep(C);
+}
+
+/* img NCHW [n][3][h][w] (used as given: the reference's sdtae_encode applies no pre-scaling) -> latent [n][4][h/8][w/8] */
+MLB_API int sdtae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float* latent)
+{
+	if (mlctx_input_set(C, t_img, img, t_img->in_bytes) < 0 || mlctx_compute(C) < 0) return -1;
+	MLTensor *r = mlctx_result(C);
+	return mlctx_output_get(C, r, latent, (size_t)r->n * r->h * r->w * r->c * 4);
 }
 
 MLB_API int sdtae_decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img)

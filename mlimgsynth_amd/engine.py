@@ -45,7 +45,8 @@ class CtxInfo(ctypes.Structure):
 class AmdConfig(ctypes.Structure):
     _fields_ = [("model", ctypes.c_char_p), ("width", c_int), ("height", c_int), ("n_batch", c_int), ("n_step", c_int),
                 ("cfg_scale", c_f), ("s_ancestral", c_f), ("sched", c_int), ("use_tae", c_int), ("use_hipgraph", c_int),
-                ("weight_seed", c_u64)]
+                ("weight_seed", c_u64), ("method", c_int), ("s_noise", c_f), ("f_t_ini", c_f), ("f_t_end", c_f),
+                ("defer_weights", c_int)]
 
 
 _proto_done = False
@@ -223,6 +224,14 @@ def _proto2():
     l.mlis_amd_last_unet_ms.restype = c_f
     l.mlis_amd_last_unet_ms.argtypes = [vp]
     l.mlis_amd_last_nfe.argtypes = [vp]
+    l.mlis_amd_last_n_step.argtypes = [vp]
+    l.mlis_amd_seed.argtypes = [vp, ctypes.POINTER(c_u64)]
+    l.mlis_amd_set_init_latent.argtypes = [vp, FP]
+    l.mlis_amd_set_lmask.argtypes = [vp, FP]
+    l.mlis_amd_encode.argtypes = [vp, FP, c_int]
+    l.mlis_amd_encoder_ctx.restype = vp
+    l.mlis_amd_encoder_ctx.argtypes = [vp]
+    l.mlis_amd_set_callback.argtypes = [vp, vp, vp]
     l._proto2_done = True
     return l
 
@@ -293,11 +302,15 @@ def clip_text_encode(model, prefix, toks, want_embed=True, want_feat=False, clip
 class Generator:
     """mlis_amd_* generation driver (mlis_generate slice, src/mlimgsynth.c:1634-1773) for one GPU."""
 
+    METHODS = {"euler": 1, "heun": 2, "taylor3": 3, "dpmpp2m": 4, "dpmpp2s": 5}
+
     def __init__(self, model, width, height, n_batch, n_step=20, cfg_scale=7.0, s_ancestral=1.0, sched=1, use_tae=False,
-                 use_hipgraph=False, weight_seed=1234, stream=None):
+                 use_hipgraph=False, weight_seed=1234, stream=None, method="euler", s_noise=0.0, f_t_ini=1.0, f_t_end=0.0,
+                 defer_weights=False):
         l = _proto2()
         self.cfg = AmdConfig(model.encode(), width, height, n_batch, n_step, cfg_scale, s_ancestral, sched, int(use_tae),
-                             int(use_hipgraph), weight_seed)
+                             int(use_hipgraph), weight_seed, self.METHODS.get(method, method), s_noise, f_t_ini, f_t_end,
+                             int(defer_weights))
         self.h = l.mlis_amd_create(ctypes.byref(self.cfg), vp(stream))
         if not self.h:
             from ._lib import MlsdError, last_error
@@ -312,8 +325,32 @@ class Generator:
     def set_cond_device(self, cond, label=None, uncond=None, unlabel=None):
         check1(_proto2().mlis_amd_set_cond_device(self.h, vp(cond), vp(label), vp(uncond), vp(unlabel)), "mlis_amd_set_cond_device")
 
+    def set_init_latent(self, latent):
+        a = np.ascontiguousarray(latent, np.float32) if latent is not None else None
+        check1(_proto2().mlis_amd_set_init_latent(self.h, fptr(a)), "mlis_amd_set_init_latent")
+
+    def set_lmask(self, lmask):
+        a = np.ascontiguousarray(lmask, np.float32) if lmask is not None else None
+        check1(_proto2().mlis_amd_set_lmask(self.h, fptr(a)), "mlis_amd_set_lmask")
+
+    def seed(self, seeds):
+        check1(_proto2().mlis_amd_seed(self.h, (c_u64 * self.B)(*[int(s) for s in seeds])), "mlis_amd_seed")
+
+    def encode(self, images, sample=True):
+        """mlis_image_encode: images [B][3][H][W] in [0,1] -> the resident latent (returned as numpy too)"""
+        a = np.ascontiguousarray(images, np.float32)
+        check1(_proto2().mlis_amd_encode(self.h, fptr(a), int(sample)), "mlis_amd_encode")
+        from ._lib import lib
+        out = np.empty((self.B, 4, self.h_px // 8, self.w // 8), np.float32)
+        lib().mlsd_memcpy(out.ctypes.data_as(vp), vp(self.latent_ptr()), ctypes.c_size_t(out.nbytes), 1, None)
+        lib().mlsd_device_sync()
+        return out
+
+    def last_n_step(self):
+        return _proto2().mlis_amd_last_n_step(self.h)
+
     def generate(self, seeds, want_latents=True, want_images=True):
-        seeds = (c_u64 * self.B)(*[int(s) for s in seeds])
+        seeds = (c_u64 * self.B)(*[int(s) for s in seeds]) if seeds is not None else None
         lat = np.empty((self.B, 4, self.h_px // 8, self.w // 8), np.float32) if want_latents else None
         img = np.empty((self.B, 3, self.h_px, self.w), np.float32) if want_images else None
         check1(_proto2().mlis_amd_generate(self.h, seeds, fptr(lat), fptr(img)), "mlis_amd_generate")

@@ -33,6 +33,10 @@ void orc_unet_params_get(const char* model, OrcUnetParams* U)
 		int a[4]={2,1,0,0}, m[5]={1,2,0,0,0}, d[5]={1,1,0,0,0};
 		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));
 		U->n_ch=64; U->n_te=256; U->n_head=2; U->n_ctx=64; U->n_res_blk=1; U->clip_norm=1;
+	} else if (!strcmp(model,"tinyv")) {   /* tiny with v-prediction (SD2-style: d_head given, vparam) */
+		int a[4]={2,1,0,0}, m[5]={1,2,0,0,0}, d[5]={1,1,0,0,0};
+		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));
+		U->n_ch=64; U->n_te=256; U->d_head=32; U->n_ctx=64; U->n_res_blk=1; U->clip_norm=1; U->vparam=1;
 	} else if (!strcmp(model,"tinyxl")) {  /* shrunken SDXL-like config (label, d_head, depth 2) */
 		int a[4]={2,0,0,0}, m[5]={1,2,0,0,0}, d[5]={1,2,0,0,0};
 		memcpy(U->attn_res,a,sizeof(a)); memcpy(U->ch_mult,m,sizeof(m)); memcpy(U->transf_depth,d,sizeof(d));
@@ -48,7 +52,7 @@ void orc_vae_params_get(const char* model, OrcVaeParams* V)
 	V->ch_x=3; V->ch_z=4; V->ch=128; V->n_res=4; V->n_res_blk=2; memcpy(V->ch_mult,m,sizeof(m));
 	V->d_embed=4; V->f_down=8;
 	V->scale_factor = !strcmp(model,"sdxl") ? 0.13025f : 0.18215f;
-	if (!strcmp(model,"tiny") || !strcmp(model,"tinyxl")) { V->ch=64; V->n_res_blk=1; }
+	if (!strcmp(model,"tiny") || !strcmp(model,"tinyxl") || !strcmp(model,"tinyv")) { V->ch=64; V->n_res_blk=1; }
 }
 
 void orc_clip_params_get(const char* model, OrcClipParams* C)
@@ -406,6 +410,87 @@ OT* orc_vae_decode(OParams* P, const char* prefix, const OrcVaeParams* V, const 
 	pop(C);
 	/* sdvae_decoder_post, src/vae.h:43-47 */
 	{ int64_t n = ot_nel(x); for (int64_t i=0;i<n;++i) x->d[i] = (x->d[i]+1)/2; }
+	return x;
+}
+
+/* sdvae_encode without tiling, src/vae.c:76-128,231-316: image [W,H,3,1] in [0,1] -> moments [W/8,H/8,2*ch_z,1]
+ * (mean | logvar) after quant_conv; no sampling (orc_latent_sample) */
+OT* orc_vae_encode_moments(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img)
+{
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx *C = &Cs;
+	push(C, prefix);
+	char name[64];
+	OT *x = ot_from(img->d, img->ne[0], img->ne[1], img->ne[2], img->ne[3]);
+	{ int64_t n = ot_nel(x); for (int64_t i=0;i<n;++i) x->d[i] = x->d[i]*2 - 1; }   /* sdvae_encoder_pre, src/vae.h:36-40 */
+	/* mlb_kl_encoder :76-118 */
+	push(C, "encoder");
+	OT *t = nn_conv2d(C, "conv_in", x, V->ch, 3, 1, 1, 1); ot_free(x); x = t;
+	int ch_blk = V->ch;
+	for (int i=0; i<V->n_res; ++i) {
+		int ch_out = V->ch * V->ch_mult[i];
+		for (int j=0; j<V->n_res_blk; ++j) {
+			snprintf(name, sizeof(name), "down.%d.block.%d", i, j);
+			t = resnet(C, name, x, NULL, ch_out); ot_free(x); x = t;
+			ch_blk = ch_out;
+		}
+		if (i+1 != V->n_res) {
+			snprintf(name, sizeof(name), "down.%d.downsample", i);
+			t = downsample(C, name, x, ch_blk, 1); ot_free(x); x = t;
+		}
+	}
+	t = resnet(C, "mid.block_1", x, NULL, ch_blk); ot_free(x); x = t;
+	t = attn_2d_self(C, "mid.attn_1", x); ot_free(x); x = t;
+	t = resnet(C, "mid.block_2", x, NULL, ch_blk); ot_free(x); x = t;
+	t = nn_groupnorm32(C, "norm_out", x); ot_free(x); x = t;
+	orc_silu(x);
+	t = nn_conv2d(C, "conv_out", x, V->ch_z*2, 3, 1, 1, 1); ot_free(x); x = t;
+	pop(C);
+	/* mlb_sdvae_encoder :120-128 */
+	t = nn_conv2d(C, "quant_conv", x, V->ch_z*2, 1, 1, 0, 1); ot_free(x); x = t;
+	return x;
+}
+
+/* sdvae_latent_sample / sdvae_latent_mean, src/vae.c:188-229: moments [W,H,2cz,1] -> latent [W,H,cz,1];
+ * rnd = n floats of N(0,1) (one rng_randn call) or NULL for the mean */
+OT* orc_latent_sample(const OT* mom, const OrcVaeParams* V, const float* rnd)
+{
+	const int64_t n = mom->ne[0]*mom->ne[1]*(mom->ne[2]/2);
+	OT *lat = ot_new(mom->ne[0], mom->ne[1], mom->ne[2]/2, 1);
+	const float *mean = mom->d, *logvar = mom->d + n;
+	for (int64_t i=0;i<n;++i) {
+		float v = mean[i];
+		if (rnd) {
+			float lv = logvar[i]; lv = lv < -30 ? -30 : (lv > 20 ? 20 : lv);
+			v = mean[i] + exp(lv * 0.5) * rnd[i];
+		}
+		lat->d[i] = v * V->scale_factor;
+	}
+	return lat;
+}
+
+/* ------------------------------------------------------------------ TAE (src/tae.c) */
+static OT* tae_block(Ctx* C, int idx, const OT* x0, int ch_out);
+
+OT* orc_tae_encode(OParams* P, const char* prefix, const OT* img)
+{	/* mlb_sdtae_encoder :43-63 (the image is used as given: sdtae_encode applies no pre-scaling, :96-115) */
+	const int ch_inner=64, ch_z=4, n_blk=3;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx *C = &Cs;
+	push(C, prefix); push(C, "encoder.layers");
+	char name[16];
+	int iblk = 0;
+	OT *x = ot_from(img->d, img->ne[0], img->ne[1], img->ne[2], img->ne[3]);
+	snprintf(name, sizeof(name), "%d", iblk++);
+	OT *t = nn_conv2d(C, name, x, ch_inner, 3, 1, 1, 1); ot_free(x); x = t;
+	t = tae_block(C, iblk++, x, ch_inner); ot_free(x); x = t;
+	for (int j=0;j<3;++j) {
+		snprintf(name, sizeof(name), "%d", iblk++);
+		t = nn_conv2d(C, name, x, ch_inner, 3, 2, 1, 0); ot_free(x); x = t;
+		for (int i=0;i<n_blk;++i) { t = tae_block(C, iblk++, x, ch_inner); ot_free(x); x = t; }
+	}
+	snprintf(name, sizeof(name), "%d", iblk++);
+	t = nn_conv2d(C, name, x, ch_z, 3, 1, 1, 1); ot_free(x); x = t;
 	return x;
 }
 

@@ -216,3 +216,144 @@ int orc_generate_latent(OParams* P, const char* prefix, const OrcUnetParams* U,
 	free(noise); ot_free(x);
 	return nfe;
 }
+
+/* ------------------------------------------------------------------ general sampler
+ * dnsamp_init / dnsamp_step (src/sampling.c:28-185) with the Solver classes of src/solvers.c:82-296 and
+ * mlis_denoise_dxdt (src/mlimgsynth.c:1565-1587), restated in the reference's own structure: a solver owns
+ * (t, i_step, tmp tensors) and calls dxdt(t, x). */
+typedef struct {
+	OParams *P; const char *prefix; const OrcUnetParams *U;
+	const OT *cond, *label, *uncond, *unlabel;
+	float cfg; int nfe; int64_t n; int lw, lh;
+} DxCtx;
+
+static void dxdt_eval(DxCtx* D, float t, const float* x, float* dx)
+{
+	OT *xt = ot_from(x, D->lw, D->lh, D->U->n_ch_in, 1);
+	OT *d = orc_unet_denoise_run(D->P, D->prefix, D->U, xt, D->cond, D->label, t); D->nfe++;
+	memcpy(dx, d->d, (size_t)D->n*sizeof(float));
+	ot_free(d);
+	float f = D->cfg;
+	if (f > 1) {
+		OT *u = orc_unet_denoise_run(D->P, D->prefix, D->U, xt, D->uncond, D->unlabel, t); D->nfe++;
+		for (int64_t i=0;i<D->n;++i) dx[i] = dx[i]*f + u->d[i]*(1-f);
+		ot_free(u);
+	}
+	ot_free(xt);
+}
+
+void orc_mask_downsize(const float* mask, int w, int h, int f, float* lmask)
+{	/* ltensor_downsize(lmask, mask, f, f, 1, 1), src/localtensor.c:161-194 (mlis_mask_encode, mlimgsynth.c:1359-1365) */
+	const int lw = w/f, lh = h/f;
+	const float fn = 1.0f/(f*f);
+	for (int i1=0;i1<lh;++i1) for (int i0=0;i0<lw;++i0) {
+		float v = 0;
+		for (int j1=0;j1<f;++j1) for (int j0=0;j0<f;++j0) v += mask[i0*f+j0 + (i1*f+j1)*w];
+		lmask[i0 + i1*lw] = v * fn;
+	}
+}
+
+int orc_sample_ex(OParams* P, const char* prefix, const OrcUnetParams* U, int lw, int lh,
+	const OT* cond, const OT* label, const OT* uncond, const OT* unlabel, const OrcSampleOpts* O,
+	uint64_t seed, uint32_t rng_offset, const float* init_latent, const float* lmask, float* latent_out)
+{
+	/* ---- dnsamp_init */
+	int method = O->method > 0 ? O->method : 1;
+	int nfe_solver = (method == 2 || method == 5) ? 2 : 1;
+	int n_req = O->n_step < 1 ? 20 : O->n_step;
+	if (nfe_solver > 1) n_req = (n_req + nfe_solver-1) / nfe_solver;
+	float sigmas[1024];
+	int n_step = orc_schedule(n_req, O->sched ? O->sched : 1, O->f_t_ini > 0 ? O->f_t_ini : 1, O->f_t_end, sigmas);
+	OrcRng rng = { seed, rng_offset };
+	const int64_t n = (int64_t)lw*lh*U->n_ch_in;
+	DxCtx D = { P, prefix, U, cond, label, uncond, unlabel, O->cfg_scale, 0, n, lw, lh };
+	float *x = (float*)calloc(n, sizeof(float)), *x0 = (float*)calloc(n, sizeof(float)), *noise = (float*)malloc(n*sizeof(float));
+	float *dx = (float*)malloc(n*sizeof(float)), *tmp0 = (float*)calloc(n, sizeof(float)), *tmp1 = (float*)calloc(n, sizeof(float));
+	if (init_latent) memcpy(x, init_latent, (size_t)n*sizeof(float));
+	float S_t = sigmas[0];
+	unsigned S_istep = 0;
+	float dt_prev = 0, h_last = 0;
+	const int hw = lw*lh;
+	#define MASK_APPLY() do { if (lmask) for (int64_t i=0;i<n;++i) { float m = lmask[i % hw]; x[i] = x0[i]*m + x[i]*(1-m); } } while (0)
+	#define NOISE_ADD(SIG) do { orc_rng_randn(&rng, (unsigned)n, noise); for (int64_t i=0;i<n;++i) x[i] += noise[i] * (SIG); } while (0)
+	for (int s=0; s<n_step; ++s) {
+		float s_up = 0, s_down = sigmas[s+1];
+		if (s == 0) {
+			if (lmask) memcpy(x0, x, (size_t)n*sizeof(float));
+			NOISE_ADD(sigmas[0]);
+			MASK_APPLY();
+		}
+		if (O->s_noise > 0 && s > 0) {
+			float s_curr = sigmas[s], s_hat = s_curr * sqrt(2) * O->s_noise, s_noise = sqrt(s_hat*s_hat - s_curr*s_curr);
+			NOISE_ADD(s_noise);
+			MASK_APPLY();
+			S_t = s_hat;
+		}
+		if (O->s_ancestral > 0) orc_ancestral(sigmas[s], sigmas[s+1], O->s_ancestral, &s_down, &s_up);
+		/* ---- solver_step(S, s_down, x) */
+		const float t = s_down;
+		switch (method) {
+		case 1: {   /* solver_euler_step :82-88 */
+			float dt = t - S_t;
+			dxdt_eval(&D, S_t, x, dx);
+			for (int64_t i=0;i<n;++i) x[i] += dx[i] * dt;
+		} break;
+		case 2: {   /* solver_heun_step :96-117 */
+			float dt = t - S_t;
+			float *x1 = tmp0, *d1 = tmp1;
+			dxdt_eval(&D, S_t, x, dx);
+			for (int64_t i=0;i<n;++i) x1[i] = x[i] + dx[i] * dt;
+			if (!(t > 0)) { for (int64_t i=0;i<n;++i) x[i] = x1[i]; }
+			else {
+				dxdt_eval(&D, t, x1, d1);
+				for (int64_t i=0;i<n;++i) x[i] += (dx[i] + d1[i]) * 0.5 * dt;
+			}
+		} break;
+		case 3: {   /* solver_taylor3_step :137-168 */
+			float dt = t - S_t;
+			float *dp1 = tmp0, *dp2 = tmp1;
+			dxdt_eval(&D, S_t, x, dx);
+			for (int64_t i=0;i<n;++i) x[i] += dx[i] * dt;
+			float idtp = S_istep >= 1 ? 1 / dt_prev : 0, f2 = S_istep >= 1 ? dt*dt/2 : 0, f3 = S_istep >= 2 ? dt*dt*dt/6 : 0;
+			for (int64_t i=0;i<n;++i) {
+				float d2 = (dx[i] - dp1[i]) * idtp, d3 = (d2 - dp2[i]) * idtp;
+				x[i] += d2 * f2 + d3 * f3;
+				dp1[i] = dx[i]; dp2[i] = d2;
+			}
+			dt_prev = dt;
+		} break;
+		case 4: {   /* solver_dpmpp2m_step :207-233 */
+			float *dprev = tmp0;
+			float a = t / S_t, h = -log(a), c = h / (2*h_last);
+			if (S_istep == 0 || !(t > 0)) c = 0;
+			dxdt_eval(&D, S_t, x, dx);
+			for (int64_t i=0;i<n;++i) {
+				float d0 = x[i] - S_t * dx[i], d1 = dprev[i], d = (1+c) * d0 - c * d1;
+				x[i] = a * x[i] + (1-a) * d;
+				dprev[i] = d0;
+			}
+			h_last = h;
+		} break;
+		case 5: {   /* solver_dpmpp2s_step :264-289 */
+			float *x1 = tmp0, *dx1 = tmp1;
+			dxdt_eval(&D, S_t, x, dx);
+			if (!(t > 0)) { float dt = t - S_t; for (int64_t i=0;i<n;++i) x[i] += dx[i] * dt; }
+			else {
+				float t1 = sqrt(t * S_t), dt1 = t1 - S_t, a = t / S_t;
+				for (int64_t i=0;i<n;++i) x1[i] = x[i] + dx[i] * dt1;
+				dxdt_eval(&D, t1, x1, dx1);
+				for (int64_t i=0;i<n;++i) { float d = x1[i] - t1 * dx1[i]; x[i] = a * x[i] + (1-a) * d; }
+			}
+		} break;
+		default: free(x); free(x0); free(noise); free(dx); free(tmp0); free(tmp1); return -1;
+		}
+		S_t = t; S_istep++;
+		if (s_up > 0 && s+1 != n_step) { NOISE_ADD(s_up); S_t = sigmas[s+1]; }
+		MASK_APPLY();
+	}
+	#undef MASK_APPLY
+	#undef NOISE_ADD
+	memcpy(latent_out, x, (size_t)n*sizeof(float));
+	free(x); free(x0); free(noise); free(dx); free(tmp0); free(tmp1);
+	return D.nfe;
+}

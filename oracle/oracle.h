@@ -174,6 +174,17 @@ ORACLE_API int orc_generate_latent(OParams* P, const char* prefix, const OrcUnet
 	float cfg_scale, int n_step, float s_ancestral, uint64_t seed, int nfe_limit,
 	float* latent_out, double* t_unet_seconds);
 
+/* ---- "next" rows: image encoders, latent sample, mask downsize, general sampler (all solvers, Karras, s_noise, img2img,
+ * in-painting).  method: 1 euler, 2 heun, 3 taylor3, 4 dpmpp2m, 5 dpmpp2s (MLIS_Method); sched: 1 uniform, 2 karras */
+ORACLE_API OT* orc_vae_encode_moments(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img);
+ORACLE_API OT* orc_latent_sample(const OT* moments, const OrcVaeParams* V, const float* rnd);
+ORACLE_API OT* orc_tae_encode(OParams* P, const char* prefix, const OT* img);
+ORACLE_API void orc_mask_downsize(const float* mask, int w, int h, int f, float* lmask);
+typedef struct { int method, sched, n_step; float cfg_scale, s_ancestral, s_noise, f_t_ini, f_t_end; } OrcSampleOpts;
+ORACLE_API int orc_sample_ex(OParams* P, const char* prefix, const OrcUnetParams* U, int lw, int lh,
+	const OT* cond, const OT* label, const OT* uncond, const OT* unlabel, const OrcSampleOpts* O,
+	uint64_t seed, uint32_t rng_offset, const float* init_latent, const float* lmask, float* latent_out);
+
 #ifdef __cplusplus
 }
 #endif

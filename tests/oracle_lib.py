@@ -39,6 +39,11 @@ class ClipParams(ctypes.Structure):
                 ("n_head", c_int), ("n_layer", c_int), ("tok_start", c_int), ("tok_end", c_int), ("tok_pad", c_int)]
 
 
+class SampleOpts(ctypes.Structure):
+    _fields_ = [("method", c_int), ("sched", c_int), ("n_step", c_int), ("cfg_scale", c_f), ("s_ancestral", c_f),
+                ("s_noise", c_f), ("f_t_ini", c_f), ("f_t_end", c_f)]
+
+
 class Rng(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("offset", ctypes.c_uint32)]
 
@@ -121,6 +126,16 @@ def L():
                                           OTP, OTP, OTP, OTP, c_f, c_int, c_f, ctypes.c_uint64, c_int, FP,
                                           ctypes.POINTER(ctypes.c_double)]
         l.orc_set_threads.argtypes = [c_int]
+        l.orc_set_act_rounding.argtypes = [c_int]
+        l.orc_vae_encode_moments.restype = OTP
+        l.orc_vae_encode_moments.argtypes = [c_vp, ctypes.c_char_p, ctypes.POINTER(VaeParams), OTP]
+        l.orc_latent_sample.restype = OTP
+        l.orc_latent_sample.argtypes = [OTP, ctypes.POINTER(VaeParams), FP]
+        l.orc_tae_encode.restype = OTP
+        l.orc_tae_encode.argtypes = [c_vp, ctypes.c_char_p, OTP]
+        l.orc_mask_downsize.argtypes = [FP, c_int, c_int, c_int, FP]
+        l.orc_sample_ex.argtypes = [c_vp, ctypes.c_char_p, ctypes.POINTER(UnetParams), c_int, c_int, OTP, OTP, OTP, OTP,
+                                    ctypes.POINTER(SampleOpts), ctypes.c_uint64, ctypes.c_uint32, FP, FP, FP]
         _L = l
     return _L
 

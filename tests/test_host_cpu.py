@@ -35,6 +35,7 @@ def declared_symbols():
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"static inline[^{]*\{[^}]*\}", "", src)
+        src = re.sub(r"typedef[^;{]*\(\s*\*[^;]*;", "", src)          # function-pointer typedefs are not symbols
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src):
             name = m.group(1)
             if name not in ("defined", "sizeof"):
