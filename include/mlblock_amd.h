@@ -24,7 +24,7 @@ extern "C" {
 typedef struct MLCtx MLCtx;
 typedef struct MLTensor MLTensor;
 
-enum { MLT_F32 = 0, MLT_F16 = 1, MLT_I32 = 26 };  /* ggml_type numbering (mlimgsynth.h:336-339) */
+enum { MLT_F32 = 0, MLT_F16 = 1, MLT_I32 = 26, MLT_I64 = 27, MLT_F64 = 28, MLT_BF16 = 30 };  /* ggml_type numbering (mlimgsynth.h:336-339) */
 
 enum MLCtxFlags {           /* src/mlblock.h:29-36 */
 	MLB_F_MULTI_COMPUTE = 1,
@@ -41,7 +41,8 @@ void   mlctx_begin(MLCtx* C, const char* name);
 void   mlctx_end(MLCtx* C);
 void   mlctx_set_tprefix(MLCtx* C, const char* prefix);   /* C->c.tprefix */
 void   mlctx_set_flags(MLCtx* C, int flags);
-void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type; only MLT_F16 is implemented */
+void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type of the CHECKPOINT (MLT_F16 | MLT_F32 | MLT_BF16, src/mlimgsynth.c:1242);
+                                                              * device storage and MFMA operands are always F16 */
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
@@ -80,7 +81,7 @@ int mlctx_param_count(const MLCtx* C);
 /* key = full dotted name as the reference derives it (src/mlblock.c:67-105) */
 int mlctx_param_info(const MLCtx* C, int i, const char** key, int* type, int64_t ne[4]);
 /* load one parameter from host memory in the REFERENCE layout/shape (element count is what is checked,
- * src/mlblock.c:243); src_type MLT_F32 or MLT_F16; converted/repacked to the engine's device layout */
+ * src/mlblock.c:243); src_type MLT_F32 | MLT_F16 | MLT_BF16 | MLT_F64; converted/repacked to the engine's device layout */
 int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void* host_data, int64_t n_elem);
 /* deterministic synthetic weights (bench/tests: no checkpoints exist): same generator as oracle/o_core.c */
 int mlctx_params_synth(MLCtx* C, uint64_t seed);

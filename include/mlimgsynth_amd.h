@@ -153,6 +153,26 @@ int clip_tokenize(const ClipTokenizer* T, const char* text, int64_t len, int32_t
 /* bytes a byte/merge token stands for; returns the byte count (may exceed max: nothing is written past it) */
 int clip_token_decode(const ClipTokenizer* T, int32_t token, char* out, int max, int* end_of_word);
 
+/* ---------------------------------------------------------------- checkpoint loading
+ * tensor-name conversion: tnconv_sd, src/tensor_name_conv.c:274-324 (0 unused, 1 converted, 2 = open_clip fused in_proj) */
+enum { TNCONV_R_UNUSED = 0, TNCONV_R_GOOD = 1, TNCONV_R_QKV_PROJ = 2 };
+int tnconv_sd(const char* name, char* out, size_t out_size);
+/* tensor index over an mmap'd safetensors file (src/ccompute/tensorstore_safet.c:152-205, tensorstore.c:184-323) */
+typedef struct MLTStore MLTStore;
+typedef struct { char* name; int dtype; int n_dim; int64_t shape[4]; /* shape[0] fastest */ size_t size; const void* data; } MLTSEntry;
+/* convert_names != 0: names go through tnconv_sd, unused tensors are dropped and open_clip in_proj tensors are split into
+ * q/k/v_proj views (tensor_callback_main / open_clip_attn_conv, src/mlimgsynth.c:989-1055) */
+MLTStore* mlts_open_safetensors(const char* path, int convert_names);
+void mlts_close(MLTStore* S);
+int mlts_count(const MLTStore* S);
+const MLTSEntry* mlts_at(const MLTStore* S, int i);
+const MLTSEntry* mlts_find(const MLTStore* S, const char* name);
+int mlts_stats(const MLTStore* S, int* n_unused, int* n_split);
+/* mlis_model_identify (src/mlimgsynth.c:1206-1249): "sd1" | "sd2" | "sdxl" or NULL; *wtype = dtype of the probe tensor */
+const char* mlts_model_identify(const MLTStore* S, int* wtype);
+/* mlctx_tstore_load (src/mlblock.c:266-292): every parameter of the prepared plan by name; element count checked */
+int mlctx_tstore_load(MLCtx* C, const MLTStore* S);
+
 /* ---------------------------------------------------------------- RNG / schedule / sampler */
 typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
 void rng_philox_randn(RngPhilox* S, unsigned n, float* out);

@@ -835,8 +835,18 @@ MLB_API int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void*
 	if (n != n_elem) return mlctx_fail(C, "parameter '%s': %lld elements given, %lld expected", key, (long long)n_elem, (long long)n);
 	const size_t esz = p->type == MLT_F16 ? 2 : 4;
 	void *buf = calloc(p->dev_elems, esz);
+	if (src_type != MLT_F32 && src_type != MLT_F16 && src_type != MLT_BF16 && src_type != MLT_F64) {
+		free(buf);
+		return mlctx_fail(C, "parameter '%s': unsupported source type %d", key, src_type);
+	}
 	for (int64_t i=0;i<n;++i) {
-		float v = src_type == MLT_F16 ? f16_to_f32(((const uint16_t*)host)[i]) : ((const float*)host)[i];
+		float v;
+		switch (src_type) {
+		case MLT_F16: v = f16_to_f32(((const uint16_t*)host)[i]); break;
+		case MLT_BF16: { uint32_t u = (uint32_t)((const uint16_t*)host)[i] << 16; memcpy(&v, &u, 4); } break;   /* ggml_bf16_to_fp32_row */
+		case MLT_F64: { double d; memcpy(&d, (const char*)host + i*8, 8); v = (float)d; } break;
+		default: memcpy(&v, (const char*)host + i*4, 4); break;                                                     /* may be unaligned in an mmap'd file */
+		}
 		const int64_t o = param_dst_index(p, i);
 		if (p->type == MLT_F16) ((uint16_t*)buf)[o] = f32_to_f16_rne(v); else ((float*)buf)[o] = v;
 	}

@@ -28,7 +28,10 @@ MLTensor* mlb_linear_ex(MLCtx* C, MLTensor* x, int n_out, bool bias, const MLEpi
 	if (!x || C->err) return NULL;
 	mlctx_block_begin(C);
 	const int n_in = x->c;
-	if (C->wtype != MLT_F16) { mlctx_fail(C, "only F16 linear weights are implemented (wtype=%d)", C->wtype); return NULL; }
+	/* C->wtype is the checkpoint's linear weight type (F16 | F32 | BF16).  The device copy is always F16: weights are rounded
+	 * once at load time (mlctx_param_set), which is what ggml's F16 path does to the activations anyway; an F32 checkpoint
+	 * therefore differs from the reference's pure-fp32 mul_mat by the fp16 rounding of the weights (stated in DESIGN.md). */
+	if (C->wtype != MLT_F16 && C->wtype != MLT_F32 && C->wtype != MLT_BF16) { mlctx_fail(C, "unsupported linear weight type %d", C->wtype); return NULL; }
 	if (n_in % 8) { mlctx_fail(C, "linear: n_in=%d must be a multiple of 8", n_in); return NULL; }
 	const void *xd = mlt_need16(C, x);
 	if (!xd) return NULL;

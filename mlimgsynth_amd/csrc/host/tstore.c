@@ -1,0 +1,263 @@
+/* Checkpoint index + parameter loading — re-creation, for the hot path, of the reference's tensor store
+ * (src/ccompute/tensorstore.c:184-323, tensorstore_safet.c:152-205) and of the load callbacks of src/mlimgsynth.c:
+ *   tensor_callback_main :1033-1055  every file tensor is renamed to the engine's dotted names (name_conv.c = tnconv_sd);
+ *   open_clip_attn_conv  :989-1030   open_clip's fused attn.in_proj_{weight,bias} becomes three views q/k/v_proj;
+ *   mlis_model_identify  :1206-1249  model type + linear weight type from one cross-attention k_proj tensor;
+ *   mlctx_tstore_load    src/mlblock.c:266-292  every plan parameter is looked up by name, the element COUNT is
+ *                        checked (not the shape, :243: that is how SDXL's Linear proj_in/out load into 1x1 convs),
+ *                        converted to the parameter's type and uploaded (here: repacked to the device layout).
+ * The file is mmap'd read-only; nothing is copied until a parameter is uploaded.  safetensors only (the GGUF reader of
+ * tensorstore_gguf.c is not on this round's path).
+ */
+#include "mlblock_int.h"
+#include "mlimgsynth_amd.h"
+#include <ctype.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+struct MLTStore {
+	MLTSEntry* e; int n, cap;
+	void* map; size_t map_size;
+	int n_unused, n_split;
+};
+
+/* ------------------------------------------------------------------ tiny JSON cursor (safetensors header only) */
+typedef struct { const char *p, *end; } JCur;
+
+static void j_ws(JCur* c) { while (c->p < c->end && isspace((unsigned char)*c->p)) c->p++; }
+static int j_eat(JCur* c, char ch) { j_ws(c); if (c->p < c->end && *c->p == ch) { c->p++; return 1; } return 0; }
+
+static int j_string(JCur* c, char* out, size_t max)
+{	/* JSON string with the escapes a tensor name can contain; returns length or -1 */
+	j_ws(c);
+	if (c->p >= c->end || *c->p != '"') return -1;
+	c->p++;
+	size_t n = 0;
+	while (c->p < c->end && *c->p != '"') {
+		char ch = *c->p++;
+		if (ch == '\\' && c->p < c->end) {
+			ch = *c->p++;
+			if (ch == 'n') ch = '\n'; else if (ch == 't') ch = '\t';
+			else if (ch == 'u') { if (c->end - c->p < 4) return -1; c->p += 4; ch = '?'; }
+		}
+		if (n + 1 < max) out[n++] = ch;
+	}
+	if (c->p >= c->end) return -1;
+	c->p++;
+	out[n] = 0;
+	return (int)n;
+}
+
+static int j_uint(JCur* c, uint64_t* v)
+{
+	j_ws(c);
+	if (c->p >= c->end || !isdigit((unsigned char)*c->p)) return -1;
+	uint64_t x = 0;
+	while (c->p < c->end && isdigit((unsigned char)*c->p)) x = x*10 + (uint64_t)(*c->p++ - '0');
+	*v = x;
+	return 1;
+}
+
+static int j_skip(JCur* c)
+{	/* skip one value */
+	j_ws(c);
+	if (c->p >= c->end) return -1;
+	if (*c->p == '"') { char tmp[8]; return j_string(c, tmp, sizeof(tmp)) < 0 ? -1 : 1; }
+	if (*c->p == '{' || *c->p == '[') {
+		const char open = *c->p, close = open == '{' ? '}' : ']';
+		c->p++;
+		if (j_eat(c, close)) return 1;
+		do {
+			if (open == '{') { char tmp[8]; if (j_string(c, tmp, sizeof(tmp)) < 0 || !j_eat(c, ':')) return -1; }
+			if (j_skip(c) < 0) return -1;
+		} while (j_eat(c, ','));
+		return j_eat(c, close) ? 1 : -1;
+	}
+	while (c->p < c->end && *c->p != ',' && *c->p != '}' && *c->p != ']') c->p++;
+	return 1;
+}
+
+/* ------------------------------------------------------------------ store */
+static int dtype_from_str(const char* s)
+{
+	if (!strcmp(s, "F32")) return MLT_F32;
+	if (!strcmp(s, "F16")) return MLT_F16;
+	if (!strcmp(s, "BF16")) return MLT_BF16;
+	if (!strcmp(s, "F64")) return MLT_F64;
+	if (!strcmp(s, "I64")) return MLT_I64;
+	if (!strcmp(s, "I32")) return MLT_I32;
+	return -1;
+}
+
+static size_t dtype_size(int t)
+{
+	switch (t) { case MLT_F16: case MLT_BF16: return 2; case MLT_F32: case MLT_I32: return 4; case MLT_F64: case MLT_I64: return 8; }
+	return 0;
+}
+
+static MLTSEntry* ts_add(MLTStore* S, const char* name, const MLTSEntry* src)
+{
+	for (int i=0;i<S->n;++i) if (!strcmp(S->e[i].name, name)) {   /* tstore_tensor_add replaces an existing key */
+		char *keep = S->e[i].name; S->e[i] = *src; S->e[i].name = keep; return &S->e[i];
+	}
+	if (S->n == S->cap) { S->cap = S->cap ? S->cap*2 : 1024; S->e = (MLTSEntry*)realloc(S->e, sizeof(MLTSEntry)*S->cap); }
+	MLTSEntry *e = &S->e[S->n++];
+	*e = *src;
+	e->name = strdup(name);
+	return e;
+}
+
+MLB_API void mlts_close(MLTStore* S)
+{
+	if (!S) return;
+	for (int i=0;i<S->n;++i) free(S->e[i].name);
+	free(S->e);
+	if (S->map) munmap(S->map, S->map_size);
+	free(S);
+}
+
+/* open_clip_attn_conv (src/mlimgsynth.c:989-1030): "<...>attn.in_proj_weight" [d, 3d] -> q/k/v_proj.weight views */
+static int qkv_split(MLTStore* S, const MLTSEntry* e, const char* newname)
+{
+	const char *type;
+	size_t l = strlen(newname);
+	if (l >= 12 && !strcmp(newname + l - 12, "in_proj_bias")) { type = "bias"; l -= 12; }
+	else if (l >= 14 && !strcmp(newname + l - 14, "in_proj_weight")) { type = "weight"; l -= 14; }
+	else return 0;
+	const int idim = e->shape[1] == 1 ? 0 : 1;
+	if (e->shape[idim] % 3) return mlsd_set_error(-1, "invalid open_clip tensor '%s'", newname);
+	MLTSEntry part = *e;
+	part.shape[idim] /= 3;
+	part.size /= 3;
+	static const char* const pn[3] = {"q_proj.", "k_proj.", "v_proj."};
+	for (int i=0;i<3;++i) {
+		char nm[256];
+		snprintf(nm, sizeof(nm), "%.*s%s%s", (int)l, newname, pn[i], type);
+		ts_add(S, nm, &part);
+		part.data = (const char*)part.data + part.size;
+	}
+	S->n_split++;
+	return 1;
+}
+
+MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names)
+{
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) { mlsd_set_error(-6 /* MLIS_E_FILE_NOT_FOUND */, "could not open '%s'", path); return NULL; }
+	struct stat st;
+	if (fstat(fd, &st) < 0 || st.st_size < 10) { close(fd); mlsd_set_error(-1, "'%s': not a safetensors file", path); return NULL; }
+	void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (map == MAP_FAILED) { mlsd_set_error(-1, "mmap of '%s' failed", path); return NULL; }
+	MLTStore *S = (MLTStore*)calloc(1, sizeof(*S));
+	S->map = map; S->map_size = (size_t)st.st_size;
+	const unsigned char *b = (const unsigned char*)map;
+	uint64_t hlen = 0;
+	for (int i=7;i>=0;--i) hlen = (hlen << 8) | b[i];
+	if (hlen < 2 || hlen > 0xffffff || 8 + hlen > S->map_size || b[8] != '{') {   /* tstore_detect_safet :300-308 */
+		mlsd_set_error(-1, "'%s': invalid safetensors header", path); mlts_close(S); return NULL;
+	}
+	const char *data0 = (const char*)b + 8 + hlen;
+	const size_t data_size = S->map_size - 8 - hlen;
+	JCur c = { (const char*)b + 8, (const char*)b + 8 + hlen };
+	char name[512], key[64], val[64];
+	if (!j_eat(&c, '{')) goto bad;
+	if (!j_eat(&c, '}')) do {
+		if (j_string(&c, name, sizeof(name)) < 0 || !j_eat(&c, ':')) goto bad;
+		if (!strcmp(name, "__metadata__")) { if (j_skip(&c) < 0) goto bad; continue; }
+		MLTSEntry e; memset(&e, 0, sizeof(e));
+		uint64_t off0 = 0, off1 = 0, shp[8]; int nd = 0, have = 0;
+		if (!j_eat(&c, '{')) goto bad;
+		do {
+			if (j_string(&c, key, sizeof(key)) < 0 || !j_eat(&c, ':')) goto bad;
+			if (!strcmp(key, "dtype")) { if (j_string(&c, val, sizeof(val)) < 0) goto bad; e.dtype = dtype_from_str(val); have |= 1; }
+			else if (!strcmp(key, "shape")) {
+				if (!j_eat(&c, '[')) goto bad;
+				if (!j_eat(&c, ']')) { do { if (nd >= 8 || j_uint(&c, &shp[nd]) < 0) goto bad; nd++; } while (j_eat(&c, ',')); if (!j_eat(&c, ']')) goto bad; }
+				have |= 2;
+			}
+			else if (!strcmp(key, "data_offsets")) {
+				if (!j_eat(&c, '[') || j_uint(&c, &off0) < 0 || !j_eat(&c, ',') || j_uint(&c, &off1) < 0 || !j_eat(&c, ']')) goto bad;
+				have |= 4;
+			}
+			else { mlsd_set_error(-1, "safetensors tensor '%s': unknown key '%s'", name, key); goto fail; }
+		} while (j_eat(&c, ','));
+		if (!j_eat(&c, '}') || have != 7) goto bad;
+		if (nd > 4) { mlsd_set_error(-1, "safetensors tensor '%s': %d dimensions", name, nd); goto fail; }
+		if (off1 < off0 || off1 > data_size) { mlsd_set_error(-1, "safetensors tensor '%s': invalid offsets", name); goto fail; }
+		e.n_dim = nd;
+		for (int i=0;i<4;++i) e.shape[i] = 1;
+		for (int i=0;i<nd;++i) e.shape[i] = (int64_t)shp[nd-1-i];           /* reversed: shape[0] fastest (ggml order) */
+		e.size = off1 - off0; e.data = data0 + off0;
+		const size_t want = (size_t)(e.shape[0]*e.shape[1]*e.shape[2]*e.shape[3]) * dtype_size(e.dtype);
+		if (e.dtype < 0 || want != e.size) { mlsd_set_error(-1, "safetensors tensor '%s': invalid size %zu for dtype/shape", name, e.size); goto fail; }
+		if (!convert_names) { ts_add(S, name, &e); continue; }
+		char conv[512];
+		const int r = tnconv_sd(name, conv, sizeof(conv));                   /* tensor_callback_main :1033-1055 */
+		if (r < 0) goto fail;
+		if (r == 0) { S->n_unused++; continue; }
+		if (r == TNCONV_R_QKV_PROJ) { if (qkv_split(S, &e, conv) < 0) goto fail; continue; }
+		ts_add(S, conv, &e);
+	} while (j_eat(&c, ','));
+	if (!j_eat(&c, '}')) goto bad;
+	return S;
+bad:
+	mlsd_set_error(-1, "'%s': malformed safetensors header near byte %ld", path, (long)(c.p - (const char*)b));
+fail:
+	mlts_close(S);
+	return NULL;
+}
+
+MLB_API int mlts_count(const MLTStore* S) { return S ? S->n : 0; }
+MLB_API const MLTSEntry* mlts_at(const MLTStore* S, int i) { return (S && i >= 0 && i < S->n) ? &S->e[i] : NULL; }
+MLB_API int mlts_stats(const MLTStore* S, int* n_unused, int* n_split)
+{
+	if (n_unused) *n_unused = S->n_unused;
+	if (n_split) *n_split = S->n_split;
+	return 1;
+}
+
+MLB_API const MLTSEntry* mlts_find(const MLTStore* S, const char* name)
+{
+	for (int i=0; S && i<S->n; ++i) if (!strcmp(S->e[i].name, name)) return &S->e[i];
+	return NULL;
+}
+
+/* mlis_model_identify, src/mlimgsynth.c:1206-1249: returns the model name ("sd1" | "sd2" | "sdxl") or NULL, and the
+ * checkpoint's linear weight type */
+MLB_API const char* mlts_model_identify(const MLTStore* S, int* wtype)
+{
+	const MLTSEntry *te;
+	const char *m = NULL;
+	if ((te = mlts_find(S, "unet.in.1.1.transf.0.attn2.k_proj.weight"))) {
+		if (te->shape[0] == 768) m = "sd1"; else if (te->shape[0] == 1024) m = "sd2";
+	} else if ((te = mlts_find(S, "unet.in.4.1.transf.0.attn2.k_proj.weight"))) {
+		if (te->shape[0] == 2048) m = "sdxl";
+	}
+	if (te && wtype) *wtype = te->dtype;
+	if (!m) mlsd_set_error(-1, "could not detect the model type");
+	return m;
+}
+
+/* mlctx_tstore_load, src/mlblock.c:266-292.  `optional_prefix`: parameters under it may be absent (a checkpoint without
+ * the VAE encoder, say); everything else must be present.  Returns the number of parameters loaded. */
+MLB_API int mlctx_tstore_load(MLCtx* C, const MLTStore* S)
+{
+	int n = 0;
+	const int np = mlctx_param_count(C);
+	for (int i=0;i<np;++i) {
+		const char *key; int type; int64_t ne[4];
+		mlctx_param_info(C, i, &key, &type, ne);
+		const MLTSEntry *e = mlts_find(S, key);
+		if (!e) return mlsd_set_error(-1, "tensor '%s' not found", key);                 /* mlblock.c:276-277 */
+		const int64_t cnt = e->shape[0]*e->shape[1]*e->shape[2]*e->shape[3];
+		if (cnt != ne[0]*ne[1]*ne[2]*ne[3])                                              /* tstore_tensor_read :243 */
+			return mlsd_set_error(-1, "tensor '%s': %lld elements in the file, %lld expected", key, (long long)cnt,
+				(long long)(ne[0]*ne[1]*ne[2]*ne[3]));
+		if (mlctx_param_set(C, key, e->dtype, e->data, cnt) < 0) return -1;
+		n++;
+	}
+	return n;
+}
