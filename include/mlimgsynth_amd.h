@@ -126,6 +126,15 @@ int sdxl_label_build(const float* feat, int n_feat, int width, int height, float
  * cond [77][n_ctx]; label [n_label] (SDXL: pooled bigG feature || size embeddings; NULL for SD1). */
 typedef struct MLIS_AmdTextCond MLIS_AmdTextCond;
 MLIS_AmdTextCond* mlis_amd_textcond_create(const char* model, int width, int height, uint64_t weight_seed, void* stream);
+/* clip_skip 0 = model default; defer_weights != 0: the towers are built without weights, the caller loads them into
+ * mlis_amd_textcond_ctx(T, i) for i < mlis_amd_textcond_n_towers(T) (mlctx_tstore_load / mlctx_param_set) */
+MLIS_AmdTextCond* mlis_amd_textcond_create_ex(const char* model, int width, int height, uint64_t weight_seed, void* stream,
+	int clip_skip, int defer_weights);
+int mlis_amd_textcond_n_towers(const MLIS_AmdTextCond* T);
+MLCtx* mlis_amd_textcond_ctx(MLIS_AmdTextCond* T, int i);
+int mlis_amd_textcond_set_size(MLIS_AmdTextCond* T, int width, int height);     /* SDXL size embeddings of the label */
+/* with per-token weights (prompt emphasis, src/mlimgsynth.c:1457-1463); weights NULL = all 1 */
+int mlis_amd_textcond_encode_w(MLIS_AmdTextCond* T, const int32_t* toks, const float* weights, int n_tok, float* cond, float* label);
 void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T);
 int mlis_amd_textcond_dims(const MLIS_AmdTextCond* T, int* n_ctx, int* n_label);
 double mlis_amd_textcond_flops(const MLIS_AmdTextCond* T);
@@ -172,6 +181,20 @@ int mlts_stats(const MLTStore* S, int* n_unused, int* n_split);
 const char* mlts_model_identify(const MLTStore* S, int* wtype);
 /* mlctx_tstore_load (src/mlblock.c:266-292): every parameter of the prepared plan by name; element count checked */
 int mlctx_tstore_load(MLCtx* C, const MLTStore* S);
+
+/* ---------------------------------------------------------------- prompt pre-processing (src/prompt_preproc.h:104-209)
+ * text = the prompt with emphasis marks / options removed; chunks index into it; loras name into lora_names */
+typedef struct { int begin, len; float w; } MLISPromptChunk;
+typedef struct { int name_off, len; float w; } MLISPromptLora;
+typedef struct {
+	char* text; int n_text;
+	MLISPromptChunk* chunks; int n_chunk;
+	char* lora_names; int n_lora_chars;
+	MLISPromptLora* loras; int n_lora;
+} MLISPrompt;
+int mlis_prompt_set_raw(MLISPrompt* P, const char* text);       /* prompt_text_set_raw */
+int mlis_prompt_set_parse(MLISPrompt* P, const char* text);     /* prompt_text_set_parse; MLIS_E_PROMPT_PARSE (-5) on error */
+void mlis_prompt_free(MLISPrompt* P);
 
 /* ---------------------------------------------------------------- RNG / schedule / sampler */
 typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
@@ -222,9 +245,14 @@ int mlis_amd_set_cond_device(MLIS_AmdCtx* S, const void* cond, const void* label
  * latents_out [n][4][lh][lw] and/or images_out [n][3][h][w] (host, may be NULL) */
 int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* latents_out, float* images_out);
 int mlis_amd_set_callback(MLIS_AmdCtx* S, mlis_amd_progress_fn fn, void* user);
+/* change the sampler options between generations (plans and weights stay); 0 / negative values = the reference's defaults */
+int mlis_amd_set_sampler(MLIS_AmdCtx* S, int n_step, int method, int sched, float cfg_scale, float s_ancestral, float s_noise,
+	float f_t_ini, float f_t_end);
 /* per-image Philox streams (seed_i, offset 0).  mlis_amd_denoise/generate with seeds == NULL continue the streams, like the
  * reference's never-reset g_rng (src/ccommon/rng_philox.c:50) */
 int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds);
+int mlis_amd_seed_ex(MLIS_AmdCtx* S, const uint64_t* seeds, uint32_t offset);    /* resume streams at a Philox offset */
+uint32_t mlis_amd_rng_offset(const MLIS_AmdCtx* S);                           /* calls made so far on every stream */
 /* img2img / in-painting inputs (MLIS_TUF_LATENT / MLIS_TUF_LMASK, src/mlimgsynth.c:1652-1687): initial latent host NCHW
  * [n][4][lh][lw] (consumed by the next denoise), latent mask host [lh][lw] (1 = keep the original; NULL clears) */
 int mlis_amd_set_init_latent(MLIS_AmdCtx* S, const float* latent);
@@ -232,7 +260,8 @@ int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask);
 /* mlis_image_encode (src/mlimgsynth.c:1301-1330): images host NCHW [n][3][h][w] in [0,1] -> resident latent (VAE: sampled
  * when sample != 0 with one Philox call per image, else the mean; TAE: direct), marked as the next initial latent */
 int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample);
-MLCtx* mlis_amd_encoder_ctx(MLIS_AmdCtx* S);                                /* NULL before the first encode */
+MLCtx* mlis_amd_encoder_ctx(MLIS_AmdCtx* S);                                /* NULL before the first encode / prepare */
+MLCtx* mlis_amd_encoder_prepare(MLIS_AmdCtx* S);                            /* build the encoder plan now (weights: synth or caller-loaded) */
 int mlis_amd_last_n_step(MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */

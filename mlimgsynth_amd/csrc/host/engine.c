@@ -38,7 +38,7 @@ struct MLIS_AmdCtx {
 	MLTensor *t_lat_dec, *t_img_enc;
 	/* device state */
 	float *d_x;                 /* latent [B][4][hw] NCHW fp32 */
-	float *d_xin;               /* what the UNet plan reads: == d_x for 1-NFE solvers, own buffer for heun / dpmpp2s */
+	float *d_xin;               /* what the UNet plan reads (1 MB d2d copy per evaluation; keeps the plan independent of the solver) */
 	float *d_dx;                /* dxdt */
 	float *d_tmp[N_TMP];        /* solver state vectors (solver_tmp_get, solvers.c:54-76) */
 	float *d_x0, *d_lmask;      /* in-painting: original latent, latent mask [hw] */
@@ -56,6 +56,7 @@ struct MLIS_AmdCtx {
 	int cond_set, have_init_latent, have_lmask;
 	int own_stream;
 	RngPhilox rng[MAX_BATCH];
+	int cap_steps;
 	int n_draw_max, n_draw_gen;          /* noise draws of the current denoise call: planned / generated so far */
 	int i_eval;
 	mlis_amd_progress_fn cb; void* cb_user;
@@ -70,7 +71,7 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	if (S->unet_ctx) mlctx_destroy(S->unet_ctx);
 	if (S->dec_ctx) mlctx_destroy(S->dec_ctx);
 	if (S->enc_ctx) mlctx_destroy(S->enc_ctx);
-	if (S->d_xin != S->d_x) mlsd_free(S->d_xin);
+	mlsd_free(S->d_xin);
 	mlsd_free(S->d_x); mlsd_free(S->d_dx); mlsd_free(S->d_x0); mlsd_free(S->d_lmask); mlsd_free(S->d_img); mlsd_free(S->d_img_in);
 	for (int i=0;i<N_TMP;++i) mlsd_free(S->d_tmp[i]);
 	mlsd_free(S->d_cin); mlsd_free(S->d_noise); mlsd_free(S->d_nan);
@@ -78,6 +79,24 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	for (int i=0;i<S->n_ev;++i) { mlsd_event_destroy(S->ev[i][0]); mlsd_event_destroy(S->ev[i][1]); }
 	if (S->own_stream) mlsd_stream_destroy(S->stream);
 	free(S);
+}
+
+/* buffers whose size follows the step count: noise draws (<= 2 per step + 2), per-evaluation scalars and events (<= 2 per step) */
+static int ensure_steps(MLIS_AmdCtx* S, int ns)
+{
+	if (ns >= MAX_STEPS) return fail("too many steps (max 255)");
+	if (ns <= S->cap_steps) return 1;
+	const size_t lat_elems = (size_t)S->B * 4 * S->hw;
+	mlsd_stream_sync(S->stream);
+	mlsd_free(S->d_noise); mlsd_host_free(S->h_noise); mlsd_host_free(S->h_scal);
+	S->d_noise = NULL; S->h_noise = NULL; S->h_scal = NULL; S->cap_steps = 0;
+	S->n_draw_max = 2 * ns + 2;
+	if (mlsd_malloc((void**)&S->d_noise, (size_t)S->n_draw_max*lat_elems*4)) return -1;
+	if (mlsd_host_alloc((void**)&S->h_noise, (size_t)S->n_draw_max*lat_elems*4)) return -1;
+	if (mlsd_host_alloc((void**)&S->h_scal, (size_t)2*ns*(S->N+S->B)*4)) return -1;
+	for (int i=S->n_ev; i<2*ns; ++i) { if (mlsd_event_create(&S->ev[i][0]) || mlsd_event_create(&S->ev[i][1])) return -1; S->n_ev = i+1; }
+	S->cap_steps = ns;
+	return 1;
 }
 
 static int solver_nfe(int method)
@@ -115,22 +134,17 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 	S->N = S->c.cfg_scale > 1 ? 2*S->B : S->B;
 	const int B = S->B, N = S->N, ns = S->c.n_step;
 	const size_t lat_elems = (size_t)B * 4 * S->hw;
-	S->n_draw_max = 2 * ns + 2;
 
 	if (mlsd_malloc((void**)&S->d_x, lat_elems*4)) goto err;
-	S->d_xin = S->d_x;
-	if (solver_nfe(S->c.method) > 1 && mlsd_malloc((void**)&S->d_xin, lat_elems*4)) { S->d_xin = S->d_x; goto err; }
+	if (mlsd_malloc((void**)&S->d_xin, lat_elems*4)) goto err;   /* the UNet plan's input: the evaluation point (x, or x1 of heun / dpmpp2s) is copied in */
 	if (mlsd_malloc((void**)&S->d_dx, lat_elems*4)) goto err;
 	for (int i=0;i<N_TMP;++i) if (mlsd_malloc((void**)&S->d_tmp[i], lat_elems*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_x0, lat_elems*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_lmask, (size_t)S->hw*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_img, (size_t)B*3*S->c.width*S->c.height*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_cin, B*4)) goto err;
-	if (mlsd_malloc((void**)&S->d_noise, (size_t)S->n_draw_max*lat_elems*4)) goto err;
 	if (mlsd_malloc((void**)&S->d_nan, 256)) goto err;
-	if (mlsd_host_alloc((void**)&S->h_noise, (size_t)S->n_draw_max*lat_elems*4)) goto err;
-	if (mlsd_host_alloc((void**)&S->h_scal, (size_t)2*ns*(N+B)*4)) goto err;
-	for (int i=0;i<2*ns;++i) { if (mlsd_event_create(&S->ev[i][0]) || mlsd_event_create(&S->ev[i][1])) goto err; S->n_ev = i+1; }
+	if (ensure_steps(S, ns) < 0) goto err;
 
 	/* ---- UNet plan, x bound to the resident evaluation point (c_in scaling + cond/uncond duplication in the gather) */
 	S->unet_ctx = mlctx_new(stream);
@@ -156,6 +170,23 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 err:
 	mlis_amd_destroy(S);
 	return NULL;
+}
+
+/* sampler options may change between generations without rebuilding the plans (the reference re-reads them in dnsamp_init on
+ * every mlis_generate).  cfg_scale may change freely on its side of 1 (crossing it changes the UNet batch: new context). */
+MLB_API int mlis_amd_set_sampler(MLIS_AmdCtx* S, int n_step, int method, int sched, float cfg_scale, float s_ancestral, float s_noise,
+	float f_t_ini, float f_t_end)
+{
+	if (n_step < 1) n_step = 20;
+	if (method <= 0) method = SOLVER_METHOD_EULER;
+	if (method > SOLVER_METHOD_DPMPP2S) return mlsd_set_error(-4, "invalid sampling method %d", method);
+	if (sched && sched != DNSAMP_SCHED_UNIFORM && sched != DNSAMP_SCHED_KARRAS) return mlsd_set_error(-4, "invalid sampling scheduler %d", sched);
+	if (!(cfg_scale > 0)) cfg_scale = 7;
+	if ((cfg_scale > 1) != (S->c.cfg_scale > 1)) return fail("cfg_scale crossing 1 changes the UNet batch: create a new context");
+	if (ensure_steps(S, n_step) < 0) return -1;
+	S->c.n_step = n_step; S->c.method = method; S->c.sched = sched ? sched : DNSAMP_SCHED_UNIFORM; S->c.cfg_scale = cfg_scale;
+	S->c.s_ancestral = s_ancestral; S->c.s_noise = s_noise; S->c.f_t_ini = f_t_ini > 0 ? f_t_ini : 1; S->c.f_t_end = f_t_end;
+	return 1;
 }
 
 MLB_API int mlis_amd_set_callback(MLIS_AmdCtx* S, mlis_amd_progress_fn fn, void* user)
@@ -201,6 +232,13 @@ MLB_API int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds)
 	return 1;
 }
 
+MLB_API int mlis_amd_seed_ex(MLIS_AmdCtx* S, const uint64_t* seeds, uint32_t offset)
+{
+	for (int b=0;b<S->B;++b) { S->rng[b].seed = seeds[b]; S->rng[b].offset = offset; }
+	return 1;
+}
+MLB_API uint32_t mlis_amd_rng_offset(const MLIS_AmdCtx* S) { return S->rng[0].offset; }
+
 /* initial latent for img2img (MLIS_TUF_LATENT, src/mlimgsynth.c:1661-1666): host NCHW [B][4][lh][lw], or NULL to go back
  * to txt2img (zero latent) */
 MLB_API int mlis_amd_set_init_latent(MLIS_AmdCtx* S, const float* latent)
@@ -244,7 +282,7 @@ static int unet_eval(MLIS_AmdCtx* S, const float* x_eval, float sigma, int prefe
 	const UnetParams *P = &S->unet_p;
 	const int B = S->B, N = S->N;
 	void *st = S->stream;
-	if (S->i_eval >= 2*S->c.n_step) return fail("internal: too many evaluations");
+	if (S->i_eval >= 2*S->cap_steps) return fail("internal: too many evaluations");
 	float *hs = S->h_scal + (size_t)S->i_eval*(N+B);
 	const float t = unet_sigma_to_t(P, sigma);
 	const float c_in = 1 / sqrt(sigma*sigma + 1);                /* unet.c:471 */
@@ -418,6 +456,29 @@ MLB_API int mlis_amd_decode(MLIS_AmdCtx* S)
 	return 1;
 }
 
+/* builds the encoder plan (once) without running it; with defer_weights the caller loads its parameters before the first encode */
+MLB_API MLCtx* mlis_amd_encoder_prepare(MLIS_AmdCtx* S)
+{
+	if (S->enc_ctx) return S->enc_ctx;
+	const int B = S->B, W = S->c.width, H = S->c.height;
+	void *st = S->stream;
+	if (!S->d_img_in && mlsd_malloc((void**)&S->d_img_in, (size_t)B*3*W*H*4)) return NULL;
+	MLCtx *C = mlctx_new(st);
+	int ok = 0;
+	if (S->c.use_tae) {
+		ok = sdtae_encode_init(C, W, H, B, &S->t_img_enc) >= 0 && mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 0) >= 0 &&
+		     sdtae_encode_build(C, S->t_img_enc) >= 0;
+	} else {
+		ok = sdvae_encode_init(C, &S->vae_p, W, H, B, &S->t_img_enc) >= 0 &&
+		     mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 2) >= 0 &&       /* mode 2: x*2-1 (vae.h:36-40) */
+		     sdvae_encode_build(C, &S->vae_p, S->t_img_enc) >= 0;
+	}
+	if (ok && !S->c.defer_weights) ok = mlctx_params_synth(C, S->c.weight_seed) >= 0;
+	if (!ok) { mlctx_destroy(C); return NULL; }
+	S->enc_ctx = C;
+	return C;
+}
+
 /* mlis_image_encode (src/mlimgsynth.c:1301-1330): images host NCHW [B][3][H][W] in [0,1] -> the resident latent becomes
  * the sampled (VAE: mean + std*N(0,1), one Philox call per image, src/vae.c:203-229) or direct (TAE) encoding and is
  * marked as the initial latent of the next denoise.  The encoder plan is built on first use. */
@@ -426,20 +487,7 @@ MLB_API int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample)
 	const int B = S->B, W = S->c.width, H = S->c.height;
 	const size_t img_elems = (size_t)B*3*W*H;
 	void *st = S->stream;
-	if (!S->enc_ctx) {
-		if (!S->d_img_in && mlsd_malloc((void**)&S->d_img_in, img_elems*4)) return -1;
-		S->enc_ctx = mlctx_new(st);
-		if (S->c.use_tae) {
-			if (sdtae_encode_init(S->enc_ctx, W, H, B, &S->t_img_enc) < 0) return -1;
-			if (mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 0) < 0) return -1;
-			if (sdtae_encode_build(S->enc_ctx, S->t_img_enc) < 0) return -1;
-		} else {
-			if (sdvae_encode_init(S->enc_ctx, &S->vae_p, W, H, B, &S->t_img_enc) < 0) return -1;
-			if (mlctx_input_bind(S->t_img_enc, S->d_img_in, B, NULL, 1.0f, 2) < 0) return -1;   /* mode 2: x*2-1 (vae.h:36-40) */
-			if (sdvae_encode_build(S->enc_ctx, &S->vae_p, S->t_img_enc) < 0) return -1;
-		}
-		if (!S->c.defer_weights && mlctx_params_synth(S->enc_ctx, S->c.weight_seed) < 0) return -1;
-	}
+	if (!S->enc_ctx && !mlis_amd_encoder_prepare(S)) return -1;
 	if (mlsd_memcpy(S->d_img_in, images, img_elems*4, 0, st)) return -1;
 	if (mlctx_compute(S->enc_ctx) < 0) return -1;
 	MLTensor *r = mlctx_result(S->enc_ctx);

@@ -29,6 +29,8 @@ MLB_API void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T)
 	free(T);
 }
 
+static int g_defer = 0;   /* set around create_ex: towers are built without synthetic weights (the caller loads them) */
+
 static int tower_add(MLIS_AmdTextCond* T, const char* tower, const char* prefix, int clip_skip, bool norm, bool want_feat,
 	uint64_t seed, void* stream)
 {
@@ -39,26 +41,39 @@ static int tower_add(MLIS_AmdTextCond* T, const char* tower, const char* prefix,
 	if (!T->ctx[i]) return mlsd_set_error(-1, "textcond: mlctx_new failed");
 	T->n_enc = i + 1;
 	if (clip_encoder_init(&T->enc[i], T->ctx[i], &P, prefix, 1, clip_skip, norm, want_feat) < 0) return -1;
-	if (mlctx_params_synth(T->ctx[i], seed) < 0) return -1;
+	if (!g_defer && mlctx_params_synth(T->ctx[i], seed) < 0) return -1;
 	return 1;
 }
 
 MLB_API MLIS_AmdTextCond* mlis_amd_textcond_create(const char* model, int width, int height, uint64_t weight_seed, void* stream)
+{
+	return mlis_amd_textcond_create_ex(model, width, height, weight_seed, stream, 0, 0);
+}
+
+/* clip_skip 0 = the model's default (1 for SD1, 2 for SD2 / SDXL: src/mlimgsynth.c:757,766,776); the final norm follows
+ * UnetParams.clip_norm (SD1/SD2 true, SDXL false: src/unet.c:33,53,75; src/mlimgsynth.c:1511-1512) */
+MLB_API MLIS_AmdTextCond* mlis_amd_textcond_create_ex(const char* model, int width, int height, uint64_t weight_seed, void* stream,
+	int clip_skip, int defer_weights)
 {
 	MLIS_AmdTextCond *T = calloc(1, sizeof(*T));
 	if (!T) return NULL;
 	snprintf(T->model, sizeof(T->model), "%s", model ? model : "");
 	T->width = width; T->height = height;
 	int rc = -1;
-	if (!strcmp(T->model, "sd1") || !strcmp(T->model, "tiny")) {
-		rc = tower_add(T, T->model[0] == 's' ? "vit_l" : "tiny", "clip", 1, true, false, weight_seed, stream);
+	g_defer = defer_weights;
+	if (!strcmp(T->model, "sd1") || !strcmp(T->model, "tiny") || !strcmp(T->model, "tinyv")) {
+		rc = tower_add(T, T->model[0] == 's' ? "vit_l" : "tiny", "clip", clip_skip > 0 ? clip_skip : 1, true, false, weight_seed, stream);
+	} else if (!strcmp(T->model, "sd2")) {
+		rc = tower_add(T, "vit_h", "clip", clip_skip > 0 ? clip_skip : 2, true, false, weight_seed, stream);
 	} else if (!strcmp(T->model, "sdxl") || !strcmp(T->model, "tinyxl")) {
 		const char *t1 = T->model[0] == 's' ? "vit_l" : "tiny", *t2 = T->model[0] == 's' ? "vit_bigg" : "tiny";
+		const int skip = clip_skip > 0 ? clip_skip : 2;
 		T->xl = 1;
-		rc = tower_add(T, t1, "clip", 2, false, false, weight_seed, stream);
-		if (rc > 0) rc = tower_add(T, t2, "clip2", 2, false, false, weight_seed, stream);
+		rc = tower_add(T, t1, "clip", skip, false, false, weight_seed, stream);
+		if (rc > 0) rc = tower_add(T, t2, "clip2", skip, false, false, weight_seed, stream);
 		if (rc > 0) rc = tower_add(T, t2, "clip2", 1, true, true, weight_seed, stream);
 	} else mlsd_set_error(-1, "textcond: unknown model '%s'", T->model);
+	g_defer = 0;
 	if (rc < 0) { mlis_amd_textcond_destroy(T); return NULL; }
 	const int d1 = T->enc[0].P.d_embed, d2 = T->xl ? T->enc[1].P.d_embed : 0;
 	T->n_ctx = d1 + d2;
@@ -84,6 +99,25 @@ MLB_API double mlis_amd_textcond_flops(const MLIS_AmdTextCond* T)
 	double f = 0;
 	for (int i=0; T && i<T->n_enc; ++i) { MLCtxInfo I; mlctx_info(T->ctx[i], &I); f += I.flops; }
 	return f;
+}
+
+MLB_API int mlis_amd_textcond_n_towers(const MLIS_AmdTextCond* T) { return T ? T->n_enc : 0; }
+MLB_API MLCtx* mlis_amd_textcond_ctx(MLIS_AmdTextCond* T, int i) { return (T && i >= 0 && i < T->n_enc) ? T->ctx[i] : NULL; }
+MLB_API int mlis_amd_textcond_set_size(MLIS_AmdTextCond* T, int width, int height) { T->width = width; T->height = height; return 1; }
+
+/* token weights (prompt emphasis), mlis_clip_tokens_encode src/mlimgsynth.c:1457-1463: rows 1..n_tok of the embedding are
+ * multiplied by the weight of their token; the pooled feature / label is computed WITHOUT weights (:1542-1543) */
+static void apply_token_weights(float* emb, int d, int n_tok, const float* w)
+{
+	if (!w) return;
+	for (int t=0;t<n_tok;++t) { float *r = emb + (size_t)(t+1)*d; for (int i=0;i<d;++i) r[i] *= w[t]; }
+}
+
+MLB_API int mlis_amd_textcond_encode_w(MLIS_AmdTextCond* T, const int32_t* toks, const float* weights, int n_tok, float* cond, float* label)
+{
+	if (mlis_amd_textcond_encode(T, toks, n_tok, cond, label) < 0) return -1;
+	apply_token_weights(cond, T->n_ctx, n_tok, weights);      /* after the concat: the same weight scales both towers' halves */
+	return 1;
 }
 
 MLB_API int mlis_amd_textcond_encode(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, float* cond, float* label)

@@ -1,0 +1,231 @@
+"""The public libmlimgsynth API driving real generations on the GPU through the prototype table of the reference's FFI
+(tests/mlis_ffi.py): synthetic models, a CHECKPOINT FILE with checkpoint-side tensor names (f1 end to end), img2img /
+in-painting through the IMAGE option, prompts through a vocabulary found in AUX_DIR, batches."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import loader_cases as LC
+import mlis_ffi as F
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mlimgsynth_amd import _lib
+    _lib.lib()
+    return F.bind(_lib.LIB_PATH)
+
+
+TOKS = np.array([5, 17, 300, 42, 7], np.int32)
+NEG = np.array([9, 9, 8], np.int32)
+
+
+def setup_tiny(m, model="synth:tiny", steps=6, **kw):
+    m.set("model", model)
+    m.set("image_dim", 64, 64)
+    m.set("steps", steps)
+    m.set("method", kw.get("method", "euler_a"))
+    m.set("seed", kw.get("seed", 42))
+    m.set("cfg_scale", kw.get("cfg", 7.0))
+    m.tokens(TOKS)
+    m.tokens(NEG, negative=True)
+
+
+def direct_generation(model, steps, seeds, method="euler", s_anc=1.0, cfg=7.0, toks=TOKS, neg=NEG, weights=None):
+    """the same generation through the engine classes (mlis_amd_*), which the other GPU tests hold against the oracle"""
+    from mlimgsynth_amd import engine, text
+    tc = text.TextConditioner(model, 64, 64, seed=1234)
+    cond, label, ncond, nlabel = tc.encode_pair(toks, neg)
+    if weights is not None:
+        cond[1:1 + len(toks)] *= np.asarray(weights, np.float32)[:, None]
+    g = engine.Generator(model, 64, 64, len(seeds), n_step=steps, cfg_scale=cfg, s_ancestral=s_anc, method=method)
+    g.set_cond(cond, label, ncond, nlabel)
+    lat, img = g.generate(seeds)
+    g.destroy()
+    return lat, img, cond
+
+
+def test_generate_synthetic_tiny_matches_engine_and_reports_progress(lib):
+    m = F.Mlis(lib)
+    setup_tiny(m)
+    prog = []
+    CB = F.CALLBACK(lambda ud, ctx, p: (prog.append((p.contents.stage, p.contents.step, p.contents.step_end, p.contents.nfe)), 1)[1])
+    assert lib.mlis_option_set(m.ctx, F.OPT["CALLBACK"], CB, None) == 1
+    m.generate()
+    lat = m.tensor(F.TENSOR["LATENT"])
+    ref_lat, ref_img, _ = direct_generation("tiny", 6, [42])
+    assert np.array_equal(lat, ref_lat)                                           # same engine, same plans, same bits
+    img = m.image(0)
+    assert img.shape == (64, 64, 3) and img.dtype == np.uint8
+    want = np.clip(ref_img[0].transpose(1, 2, 0) * 255, 0, 255).astype(np.uint8)  # truncation, mlimgsynth.c:123-125
+    assert np.array_equal(img, want)
+    assert [p for p in prog if p[0] == 4] == [(4, s, 6, 2 * s) for s in range(1, 7)]   # DENOISE steps with NFE
+    assert prog[0][0] == 1 and prog[-1][0] == 3                                   # COND_ENCODE first, IMAGE_DECODE last
+    info = lib.mlis_infotext_get(m.ctx, 0).decode()
+    assert "Seed: 42, Sampler: euler ancestral, Schedule type: uniform" in info and "Steps: 6, NFE: 12, Size: 64x64" in info
+    assert "Version: MLImgSynth v0.4.2" in info
+    # options are cleared after a generation (mlis_prompt_clear): a second generate needs a prompt again -> empty prompt is valid
+    m.tokens(TOKS); m.tokens(NEG, negative=True)
+    m.generate()                                                                  # Philox streams continue (g_rng.offset is never reset)
+    assert not np.array_equal(m.tensor(F.TENSOR["LATENT"]), lat)
+    m.close()
+
+
+def test_callback_abort_code_is_returned(lib):
+    m = F.Mlis(lib)
+    setup_tiny(m)
+    CB = F.CALLBACK(lambda ud, ctx, p: -77 if (p.contents.stage == 4 and p.contents.step == 2) else 1)
+    lib.mlis_option_set(m.ctx, F.OPT["CALLBACK"], CB, None)
+    assert lib.mlis_generate(m.ctx) == -77
+    m.close()
+
+
+def test_batch_and_other_solver_through_options(lib):
+    m = F.Mlis(lib)
+    setup_tiny(m, steps=8, method="dpmpp2m", seed=100)
+    m.set("scheduler", "karras")
+    m.set("batch_size", 3)
+    m.set("no_decode", 1)
+    m.generate()
+    lat = m.tensor(F.TENSOR["LATENT"])
+    assert lat.shape == (3, 4, 8, 8)
+    from mlimgsynth_amd import engine, text
+    tc = text.TextConditioner("tiny", 64, 64, seed=1234)
+    cond, _, ncond, _ = tc.encode_pair(TOKS, NEG)
+    g = engine.Generator("tiny", 64, 64, 3, n_step=8, cfg_scale=7.0, s_ancestral=0.0, method="dpmpp2m", sched=2)
+    g.set_cond(cond, None, ncond, None)
+    ref, _ = g.generate([100, 101, 102], want_images=False)                      # image i: seed + i (generate.sh:56-59)
+    assert np.array_equal(lat, ref)
+    assert not lib.mlis_image_get(m.ctx, 0) and "not ready" in m.err()
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["F16", "F32"])
+def test_checkpoint_file_with_external_names_equals_synthetic(lib, tmp_path, dtype):
+    """f1 end to end: a single-file checkpoint written by the safetensors package with CHECKPOINT-side names (CompVis UNet /
+    first_stage_model / HF CLIP) and the synthetic values keyed by the internal names must generate bit-identically to the
+    synthetic model: name conversion, index, dtype conversion, layout repack (conv OIHW->OHWI, GEGLU interleave, fused QKV)."""
+    path = str(tmp_path / f"tiny_{dtype}.safetensors")
+    LC.write_checkpoint(path, "tiny", dtype)
+    m = F.Mlis(lib)
+    m.set("model_type", "tiny")                       # the probe tensor of mlis_model_identify has no tiny variant
+    setup_tiny(m, model=path)
+    m.generate()
+    lat, img = m.tensor(F.TENSOR["LATENT"]), m.image(0)
+    m2 = F.Mlis(lib)
+    setup_tiny(m2)
+    m2.generate()
+    assert np.array_equal(lat, m2.tensor(F.TENSOR["LATENT"])) and np.array_equal(img, m2.image(0))
+    assert "Model: tiny_" + dtype in lib.mlis_infotext_get(m.ctx, 0).decode()
+    m.close(); m2.close()
+
+
+def test_checkpoint_sdxl_style_with_fused_open_clip_attention(lib, tmp_path):
+    path = str(tmp_path / "tinyxl.safetensors")
+    LC.write_checkpoint(path, "tinyxl", "F16")
+    outs = []
+    for model in (path, "synth:tinyxl"):
+        m = F.Mlis(lib)
+        if model == path:
+            m.set("model_type", "tinyxl")
+        setup_tiny(m, model=model, steps=4)
+        m.generate()
+        outs.append((m.tensor(F.TENSOR["LATENT"]), m.tensor(F.TENSOR["COND"]), m.tensor(F.TENSOR["LABEL"]), m.tensor(F.TENSOR["NCOND"])))
+        m.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][1].shape == (1, 1, 77, 128) and outs[0][2].shape[-1] == 96
+    assert outs[0][3].any()                            # a non-empty negative prompt is encoded, not zeroed
+
+
+def test_sdxl_empty_negative_prompt_zeroes_uncond(lib):
+    m = F.Mlis(lib)
+    setup_tiny(m, model="synth:tinyxl", steps=2)
+    m.tokens(np.zeros(0, np.int32), negative=True)
+    m.generate()
+    assert not m.tensor(F.TENSOR["NCOND"]).any() and m.tensor(F.TENSOR["NLABEL"]).any()      # mlimgsynth.c:1702-1703
+    m.close()
+
+
+def test_img2img_and_inpaint_through_image_option(lib):
+    rng = np.random.default_rng(1)
+    rgba = (rng.random((64, 64, 4)) * 255).astype(np.uint8)
+    rgba[:, :32, 3] = 255
+    rgba[:, 32:, 3] = 0
+    m = F.Mlis(lib)
+    setup_tiny(m, steps=10)
+    m.set("f_t_ini", 0.5)
+    im = F.Image(rgba.ctypes.data_as(C.POINTER(C.c_uint8)), rgba.size, 64, 64, 4, 0)
+    assert lib.mlis_option_set(m.ctx, F.OPT["IMAGE"], C.byref(im)) == 1
+    m.generate()
+    lat = m.tensor(F.TENSOR["LATENT"])[0]
+    lmask = m.tensor(F.TENSOR["LMASK"])[0, 0]
+    assert lmask.shape == (8, 8) and np.all(lmask[:, :4] == 1) and np.all(lmask[:, 4:] == 0)
+    info = lib.mlis_infotext_get(m.ctx, 0).decode()
+    assert "Mode: inpaint, f_t_ini: 0.5" in info and "Steps: 5, NFE: 10" in info
+    # oracle: encode (sampled with Philox call 0), then the masked img2img loop continuing at offset 1
+    img = rgba[:, :, :3].transpose(2, 0, 1)[None].astype(np.float32) * np.float32(1 / 255.0)
+    OP, V = O.Params(1234), O.vae_params("tiny")
+    mom = O.L().orc_vae_encode_moments(OP.h, b"vae", V, O.to_ot(img))
+    init = O.from_ot(O.L().orc_latent_sample(mom, V, O.fptr(O.randn(42, 0, 256))))[0]
+    from test_sampler_gpu import oracle_sample
+    cond, ncond = m.tensor(F.TENSOR["COND"])[0, 0], m.tensor(F.TENSOR["NCOND"])[0, 0]
+    ref, nfe = oracle_sample("tiny", 8, cond, ncond, None, None, "euler", 1.0, 1, 0.0, 10, 42, f_t_ini=0.5, init=init, lmask=lmask, rng_offset=1)
+    e = rel(lat, ref)
+    print("API inpaint vs oracle rel-L2", e)
+    assert nfe == 10 and e < 5e-2
+    keep = np.broadcast_to(lmask == 1, lat.shape)
+    assert rel(lat[keep], init[keep]) < 4e-3                                      # kept region == the encoded source
+    m.close()
+
+
+def test_prompt_text_with_vocabulary_in_aux_dir(lib, tmp_path):
+    """text prompts: the CLIP merge table is run-time data found through AUX_DIR (here a 6-merge toy table); emphasis weights
+    scale the token rows of the embedding (src/mlimgsynth.c:1457-1463)"""
+    (tmp_path / "merges.txt").write_text("#version: 0.2\nd o\ndo g</w>\nc a\nca t</w>\na n\nan d</w>\n")
+    m = F.Mlis(lib)
+    m.set("aux_dir", str(tmp_path))
+    setup_tiny(m, steps=3)
+    m.set("prompt", "dog (cat:1.5) and")
+    m.set("nprompt", "")
+    tp = C.POINTER(C.c_int32)()
+    n = lib.mlis_text_tokenize(m.ctx, b"dog cat and", C.byref(tp), 4)
+    toks = np.array([tp[i] for i in range(n)], np.int32)
+    assert n == 3 and len(set(toks)) == 3 and toks.min() >= 512                  # three merged word tokens
+    m.set("prompt", "dog (cat:1.5) and")
+    m.generate()
+    cond = m.tensor(F.TENSOR["COND"])[0, 0]
+    ref_lat, _, ref_cond = direct_generation("tiny", 3, [42], toks=toks, neg=np.zeros(0, np.int32), weights=[1.0, 1.5, 1.0])
+    assert np.array_equal(cond, ref_cond) and np.array_equal(m.tensor(F.TENSOR["LATENT"]), ref_lat)
+    m2 = F.Mlis(lib)
+    setup_tiny(m2)
+    m2.set("prompt", "needs a vocabulary")
+    assert lib.mlis_generate(m2.ctx) == -6 and "vocabulary" in m2.err()           # no silent fallback
+    m.close(); m2.close()
+
+
+def test_image_encode_decode_entry_points(lib):
+    m = F.Mlis(lib)
+    setup_tiny(m)
+    img, lat, out = F.Tensor(), F.Tensor(), F.Tensor()
+    lib.mlis_tensor_resize(C.byref(img), 64, 64, 3, 1)
+    src = np.random.default_rng(2).random((3, 64, 64)).astype(np.float32)
+    np.ctypeslib.as_array(img.d, shape=(3, 64, 64))[:] = src
+    assert lib.mlis_image_encode(m.ctx, C.byref(img), C.byref(lat), 0) == 1
+    assert [lat.n[i] for i in range(4)] == [8, 8, 4, 1]
+    assert lib.mlis_image_decode(m.ctx, C.byref(lat), C.byref(out), 0) == 1
+    dec = F.tensor_np(out)
+    OP, V = O.Params(1234), O.vae_params("tiny")
+    ref = O.from_ot(O.L().orc_vae_decode(OP.h, b"vae", V, O.to_ot(F.tensor_np(lat))))
+    assert dec.shape == (1, 3, 64, 64) and rel(dec - 0.5, ref - 0.5) < 4e-3
+    m.close()

@@ -31,7 +31,7 @@ def dry():
 
 def declared_symbols():
     syms = set()
-    for h in ("mlsd_kernels.h", "mlblock_amd.h", "mlimgsynth_amd.h"):
+    for h in ("mlsd_kernels.h", "mlblock_amd.h", "mlimgsynth_amd.h", "mlis_abi.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"static inline[^{]*\{[^}]*\}", "", src)
