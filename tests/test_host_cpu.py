@@ -36,6 +36,7 @@ def declared_symbols():
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"static inline[^{]*\{[^}]*\}", "", src)
         src = re.sub(r"typedef[^;{]*\(\s*\*[^;]*;", "", src)          # function-pointer typedefs are not symbols
+        src = re.sub(r"^\s*#\s*define[^\n]*$", "", src, flags=re.M)   # macros (mlis_ctx_create()) are not symbols
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src):
             name = m.group(1)
             if name not in ("defined", "sizeof"):
