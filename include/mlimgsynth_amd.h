@@ -265,7 +265,8 @@ MLCtx* mlis_amd_encoder_prepare(MLIS_AmdCtx* S);                            /* b
 int mlis_amd_last_n_step(MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */
-int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device */
+int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device; asynchronous */
+int mlis_amd_sync(MLIS_AmdCtx* S);                                          /* wait for the engine's stream */
 void* mlis_amd_latent_device(MLIS_AmdCtx* S);                               /* fp32 NCHW [n][4][lh][lw] */
 void* mlis_amd_image_device(MLIS_AmdCtx* S);                                /* fp32 NCHW [n][3][h][w] */
 int mlis_amd_info(MLIS_AmdCtx* S, double* unet_flops_per_eval, double* decode_flops, int* unet_ops, size_t* mem_params,

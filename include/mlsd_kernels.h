@@ -27,6 +27,7 @@ extern "C" {
 /* ---------------------------------------------------------------- runtime (replaces ggml_backend_*:
  * src/mlimgsynth.c:1131-1161, src/localtensor.h:96-106, src/mlblock.c:257) */
 const char* mlsd_last_error(void);
+const char* mlsd_peek_runtime_error(void);   /* diagnostics: HIP's pending error text (not cleared), "" if none */
 /* dry mode: memory calls are served from host memory so the plan builder can run without a GPU; no kernel
  * can be launched (every launcher fails).  Used by the CPU-only tests of the host logic. */
 void mlsd_runtime_dry(int on);
@@ -134,6 +135,9 @@ typedef struct mlsd_attn_args {
 } mlsd_attn_args;
 
 int mlsd_attention(const mlsd_attn_args* a, void* stream);
+/* diagnostics / A-B timing: 1 = the d_head 64 problems also run on the general kernel instead of the 64-rows-per-wave one */
+void mlsd_attention_force_old(int on);
+void mlsd_attention_x2_min_tq(int tq);     /* smallest Tq (multiple of 256) the 64-rows-per-wave kernel takes (default 2048) */
 
 /* row softmax over fp32 scores -> fp16 probabilities (VAE mid attention, d=512 single head,
  * src/vae.c:46-74, computed as GEMM + softmax + GEMM).  in [rows][ld_in] f32, out [rows][ld_out] f16 */

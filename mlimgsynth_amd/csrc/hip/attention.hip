@@ -29,11 +29,19 @@
 
 namespace {
 
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 struct AttnP {
     const _Float16 *q, *k, *v;
     _Float16* o;
     long ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
     int n_head, Tq, Tk, causal;
+    int nq, G;  // query blocks per (batch, head) group; number of groups
     float sc;  // 1/sqrt(d_head) * log2(e)
 };
 
@@ -58,8 +66,15 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128, qw = q0 + wave * 32;
+    // XCD-aware block -> (group, query block) map: consecutive workgroup ids go round-robin to the 8 XCDs, so id % 8 is the
+    // XCD.  All query blocks of one (batch, head) group run on ONE XCD (group g -> XCD g % 8): that XCD's L2 fetches the
+    // group's K/V once instead of each of the 8 L2s fetching it (the 3.4x fabric traffic measured in round 1).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gk = slot / p.nq, qb = slot - gk * p.nq;
+    const int grp = gk * 8 + xcd;
+    if (grp >= p.G) return;                          // padding blocks of a group count that is not a multiple of 8 (whole block leaves)
+    const int head = grp % p.n_head, b = grp / p.n_head;
+    const int q0 = qb * 128, qw = q0 + wave * 32;
     const int qrow = qw + lr;
 
     const _Float16* Qg = p.q + (long)b * p.bsq + (long)head * DH;
@@ -88,7 +103,13 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     for (int d = 0; d < NDV; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
+    float m_run = -1.0e30f;
+    // row sums l[q] = sum_k P[k][q] run on the matrix pipe: ones[32 x 16] . P puts the sum in every row of the result (64
+    // v_add per tile and the final cross-half exchange disappear; the sum is over the fp16 P the P.V product uses)
+    f32x16 lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 
     int nt = (p.Tk + 63) / 64;
     if (p.causal) { const int lim = (min(q0 + 128, p.Tq) + 63) / 64; nt = min(nt, lim); }
@@ -192,37 +213,35 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
                     if (key >= p.Tk || (p.causal && key > qrow)) sacc[kt][e] = -1.0e30f;
                 }
         }
-        float mx = -1.0e30f;
+        // max through v_max3_f32 (asm): plain fmaxf on MFMA outputs costs a canonicalising v_max per operand
+        float mx = max3f(sacc[0][0], sacc[0][1], sacc[1][0]);
+        mx = max3f(mx, sacc[1][1], sacc[0][2]);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int e = 3; e < 16; e += 2) mx = max3f(mx, sacc[0][e], (e + 1 < 16) ? sacc[0][e + 1] : sacc[0][e]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int e = 2; e < 16; e += 2) mx = max3f(mx, sacc[1][e], sacc[1][e + 1]);
+        mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);
         // deferred rescale (T13): keep the old reference maximum while the new one exceeds it by less than
         // 2^6 in the exp2 domain (P <= 64 fits fp16 with full relative precision); the decision is taken for
         // the whole wave, BEFORE this tile's P is formed, so O, l and P always share one reference.
         const bool grow = (mx - m_run) * p.sc > 6.0f;
         if (__any(grow)) {
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = max3f(m_run, mx, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
             m_run = m_new;
-            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
 #pragma unroll
             for (int d = 0; d < NDV; ++d)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
         }
         const float msc = -m_run * p.sc;
-        float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], p.sc, msc));   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
-                sacc[kt][e] = pv;
-                rs += pv;
-            }
-        l_run += rs;
+            for (int e = 0; e < 16; ++e)
+                sacc[kt][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], p.sc, msc));   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
 
         // ---- O^T += V^T . P   (P = S^T accumulators as B operand, permuted k order)
 #pragma unroll
@@ -234,6 +253,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sacc[kt][8 * s + j];
                 const int kb = 32 * kt + 16 * s;
+                lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);   // row sums on the matrix pipe (ones . P)
 #pragma unroll
                 for (int d = 0; d < NDV; ++d) {
                     const unsigned char* a0 = Vs + (kb + tr_row) * VSTR + (32 * d + tr_col) * 2;
@@ -252,8 +272,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     }
 
     // ---- epilogue: O = O^T / l, heads merged.  oacc[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / lacc[0];
     if (qrow < p.Tq) {
         _Float16* og = p.o + (long)b * p.bso + (long)qrow * p.ldo + (long)head * DH;
 #pragma unroll
@@ -270,6 +289,212 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d_head = 64, no causal mask, Tq a multiple of 256 (every attention of the SDXL UNet): the throughput kernel.
+//   block = 4 waves = 256 query rows; a wave owns TWO 32-row query blocks (64 rows): every K fragment read from LDS feeds
+//   two QK^T MFMAs and every transposed V fragment two P.V MFMAs (half the LDS reads per FLOP of the kernel above), and
+//   the two blocks are independent dependency chains the scheduler interleaves (MFMA of one under the softmax VALU of the
+//   other).  K/V tiles (64 keys) go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write),
+//   double buffered, one barrier per tile.  Unpadded 128-byte rows; the bank-conflict XOR is applied to the SOURCE chunk:
+//     K image: slot = chunk ^ ((row >> 1) & 7)        conflict-free ds_read_b128 of 32 rows x one chunk (as the GEMM tiles)
+//     V image: slot = chunk ^ (((row >> 1) & 1) << 2) conflict-free ds_read_b64_tr_b16 of 4 rows x 64 B per 32-lane half
+//   Keys past Tk (77-token cross attention) are clamped duplicates of the last key and masked.
+__global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
+{
+    constexpr int DH = 64, RB = 128;                 // bytes per K/V row
+    __shared__ __attribute__((aligned(1024))) unsigned char Ks2[2][64 * RB];
+    __shared__ __attribute__((aligned(1024))) unsigned char Vs2[2][64 * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gk = slot / p.nq, qb = slot - gk * p.nq;
+    const int grp = gk * 8 + xcd;
+    if (grp >= p.G) return;
+    const int head = grp % p.n_head, b = grp / p.n_head;
+    const int qw = qb * 256 + wave * 64;
+
+    const _Float16* Qg = p.q + (long)b * p.bsq + (long)head * DH;
+    const _Float16* Kg = p.k + (long)b * p.bsk + (long)head * DH;
+    const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
+
+    // Q fragments of both query blocks (B operand of S^T = K.Q^T): lane (lr = query, lh) holds Q[q][16*ks + 8*lh + j]
+    f16x8 qf[2][4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[sb][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh));
+
+    const int nt = (p.Tk + 63) / 64;
+    // LDS-DMA staging: wave w fills rows 16w .. 16w+15 of the tile with two 1-KiB pieces (8 rows each) per operand
+    const int srow = lane >> 3, sslot = lane & 7;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + srow;
+            const long key = min(t * 64 + row, p.Tk - 1);
+            const int ck = sslot ^ ((row >> 1) & 7), cv = sslot ^ (((row >> 1) & 1) << 2);
+            unsigned char* dk = Ks2[buf] + (wave * 16 + i * 8) * RB;      // wave-uniform piece base, lane-linear image
+            unsigned char* dv = Vs2[buf] + (wave * 16 + i * 8) * RB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + key * p.ldk + ck * 8),
+                                             (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + key * p.ldv + cv * 8),
+                                             (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+        }
+    };
+
+    f32x16 o0[2], o1[2];                              // O^T accumulators of query block 0 / 1: [d-block of 32]
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[d][e] = 0.f; o1[d][e] = 0.f; }
+    float m0 = -1.0e30f, m1 = -1.0e30f;
+    // row sums l[q] = sum_k P[k][q] accumulated on the matrix pipe: ones[32 x 16] . P -> every row of the result holds the sums
+    f32x16 ls0, ls1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ls0[e] = 0.f; ls1[e] = 0.f; }
+    const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing.  K rows lr / 32+lr have the same swizzle term ((32 + lr) >> 1) & 7 == (lr >> 1) & 7.
+    const int kswz = (lr >> 1) & 7;
+    const int tg = lane >> 4, ti = lane & 15;
+    const int tr_row = 4 * (tg >> 1) + (ti >> 2);                    // + key block base (multiple of 8): swizzle term from tr_row alone
+    const int vswz = ((tr_row >> 1) & 1) << 2;
+    const int tr_c = 2 * (tg & 1) + ((ti & 3) >> 1), tr_b = 8 * (ti & 1);   // 16-byte chunk (+4*d) and byte inside it
+
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * 64;
+        const unsigned char* Ks = Ks2[t & 1];
+        const unsigned char* Vs = Vs2[t & 1];
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);   // the buffer tile t-1 used: every wave passed the barrier that ended iteration t-1
+
+        // ---- S^T = K . Q^T for both query blocks: 8 K fragment reads feed 16 MFMAs
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 s00 = zero, s01 = zero, s10 = zero, s11 = zero;        // s<block><key sub-tile>
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = ((2 * ks + lh) ^ kswz) << 4;
+            const f16x8 k0 = *reinterpret_cast<const f16x8*>(Ks + lr * RB + off);
+            const f16x8 k1 = *reinterpret_cast<const f16x8*>(Ks + (32 + lr) * RB + off);
+            s00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0][ks], s00, 0, 0, 0);
+            s10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[1][ks], s10, 0, 0, 0);
+            s01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[0][ks], s01, 0, 0, 0);
+            s11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[1][ks], s11, 0, 0, 0);
+        }
+        if (kv0 + 64 > p.Tk) {                        // ragged last tile (wave-uniform): mask the clamped duplicates
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (key >= p.Tk) { s00[e] = -1.0e30f; s10[e] = -1.0e30f; }
+                if (key + 32 >= p.Tk) { s01[e] = -1.0e30f; s11[e] = -1.0e30f; }
+            }
+        }
+        // ---- online softmax of one query block (registers + one cross-half exchange; deferred rescale, see attn_kernel)
+        // max as v_max3_f32 through asm: a plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand
+        // (100 v_max for 64 scores, MI355X_MICROARCH.md); row sums run on the matrix pipe (P . ones, below) instead of 64 v_add
+        auto softmax = [&](f32x16& sa, f32x16& sb_, float& m_run, f32x16* oacc, f32x16& lacc) __attribute__((always_inline)) {
+            float mx = max3f(sa[0], sa[1], sb_[0]);
+            mx = max3f(mx, sb_[1], sa[2]);
+#pragma unroll
+            for (int e = 3; e < 16; e += 2) mx = max3f(mx, sa[e], (e + 1 < 16) ? sa[e + 1] : sa[e]);
+#pragma unroll
+            for (int e = 2; e < 16; e += 2) mx = max3f(mx, sb_[e], sb_[e + 1]);
+            mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);
+            const bool grow = (mx - m_run) * p.sc > 6.0f;
+            if (__any(grow)) {
+                const float m_new = max3f(m_run, mx, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+            }
+            const float msc = -m_run * p.sc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sa[e] = __builtin_amdgcn_exp2f(fmaf(sa[e], p.sc, msc));
+                sb_[e] = __builtin_amdgcn_exp2f(fmaf(sb_[e], p.sc, msc));
+            }
+        };
+        softmax(s00, s01, m0, o0, ls0);
+        softmax(s10, s11, m1, o1, ls1);
+
+        // ---- O^T += V^T . P for both query blocks: 16 transposed V reads feed 16 MFMAs
+        const bool sub1 = kv0 + 32 < p.Tk;            // the second 32-key sub-tile holds at least one key (wave-uniform)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && !sub1) continue;
+            const f32x16& pa = kt ? s01 : s00;
+            const f32x16& pb = kt ? s11 : s10;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                f16x8 pf0, pf1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pf0[j] = (_Float16)pa[8 * sx + j]; pf1[j] = (_Float16)pb[8 * sx + j]; }
+                const int kb = 32 * kt + 16 * sx;
+                ls0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf0, ls0, 0, 0, 0);
+                ls1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf1, ls1, 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned char* a0 = Vs + (kb + tr_row) * RB + (((4 * d + tr_c) ^ vswz) << 4) + tr_b;
+                    union { h16x4 h[2]; f16x8 f; } vf;
+                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)a0);
+                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(a0 + 8 * RB));
+                    o0[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.f, pf0, o0[d], 0, 0, 0);
+                    o1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.f, pf1, o1[d], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
+        __syncthreads();                                    // all pieces visible; every wave is done reading tile t
+    }
+
+    // ---- epilogue: O = O^T / l, heads merged.  o[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
+    auto store = [&](const f32x16* oacc, float l_run, int sb) __attribute__((always_inline)) {
+        const float inv = 1.0f / l_run;                 // the MFMA row sum already covers all 64 keys of every tile (both lane halves)
+        _Float16* og = p.o + (long)b * p.bso + (long)(qw + 32 * sb + lr) * p.ldo + (long)head * DH;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
+                           (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
+                *reinterpret_cast<f16x4*>(og + 32 * d + 8 * eg + 4 * lh) = h;
+            }
+    };
+    store(o0, ls0[0], 0);
+    store(o1, ls1[0], 1);
+}
+
+int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_kernel
+// the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
+// the general kernel), so they take Tq >= 2048 only
+int g_attn_x2_min_tq = 2048;
+
+int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
+{
+    AttnP p;
+    p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = 0;
+    p.sc = (float)(1.4426950408889634 / sqrt(64.0));
+    p.nq = a->Tq / 256; p.G = a->n_head * a->n_batch;
+    const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
+    hipLaunchKernelGGL(attn64x2_kernel, grid, dim3(256), 0, st, p);
+    return mlsd_check_launch("attn64x2_kernel");
+}
+
 template <int DH>
 int launch_attn(const mlsd_attn_args* a, hipStream_t st)
 {
@@ -279,7 +504,8 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
     p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
     p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = a->causal;
     p.sc = (float)(1.4426950408889634 / sqrt((double)a->d_head));
-    const dim3 grid((a->Tq + 127) / 128, a->n_head, a->n_batch);
+    p.nq = (a->Tq + 127) / 128; p.G = a->n_head * a->n_batch;
+    const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
     hipLaunchKernelGGL(attn_kernel<DH>, grid, dim3(256), 0, st, p);
     return mlsd_check_launch("attn_kernel");
 }
@@ -297,11 +523,18 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
     switch (a->d_head) {
     case 32: return launch_attn<32>(a, st);
     case 40: return launch_attn<40>(a, st);
-    case 64: return launch_attn<64>(a, st);
+    case 64:
+        // every q/k/v row must be 16-byte aligned for the LDS-DMA pieces (strides are multiples of 8 halfs: checked above)
+        if (!g_attn_force_old && !a->causal && a->Tq >= g_attn_x2_min_tq && !(a->Tq & 255) &&
+            !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15)) return launch_attn64x2(a, st);
+        return launch_attn<64>(a, st);
     case 80: return launch_attn<80>(a, st);
     case 160: return launch_attn<160>(a, st);
     default: return mlsd_set_error(-1, "mlsd_attention: unsupported d_head %d (supported: 32,40,64,80,160)", a->d_head);
     }
 }
+
+MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
+MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 
 }  // extern "C"

@@ -27,8 +27,10 @@ int mlsd_check_launch(const char* what);
 #define MLSD_HIP_TRY(expr)                                                                  \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError(); /* reported here: do not leave it pending for the next launch check */ \
             return mlsd_set_error(-(int)e_ - 1000, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                   \
     } while (0)
 
 // ---- small device helpers -------------------------------------------------

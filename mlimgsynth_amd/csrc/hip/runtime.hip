@@ -35,6 +35,13 @@ int mlsd_check_launch(const char* what)
 }
 
 MLSD_API const char* mlsd_last_error(void) { return g_err; }
+/* diagnostics: the runtime's pending (sticky) error without clearing it, "" if none */
+MLSD_API const char* mlsd_peek_runtime_error(void)
+{
+    if (g_dry) return "";
+    hipError_t e = hipPeekAtLastError();
+    return e == hipSuccess ? "" : hipGetErrorString(e);
+}
 MLSD_API void mlsd_runtime_dry(int on) { g_dry = on; }
 MLSD_API int mlsd_runtime_is_dry(void) { return g_dry; }
 

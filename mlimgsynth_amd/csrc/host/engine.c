@@ -523,6 +523,7 @@ MLB_API int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* late
 	return 1;
 }
 
+MLB_API int mlis_amd_sync(MLIS_AmdCtx* S) { return mlsd_stream_sync(S->stream) ? -1 : 1; }
 MLB_API void* mlis_amd_latent_device(MLIS_AmdCtx* S) { return S->d_x; }
 MLB_API void* mlis_amd_image_device(MLIS_AmdCtx* S) { return S->d_img; }
 MLB_API MLCtx* mlis_amd_unet_ctx(MLIS_AmdCtx* S) { return S->unet_ctx; }

@@ -42,10 +42,21 @@ MLB_API MLCtx* mlctx_new(void* stream)
 	MLCtx *C = (MLCtx*)calloc(1, sizeof(MLCtx));
 	C->stream = stream;
 	C->wtype = MLT_F16;
+	C->dry = mlsd_runtime_is_dry();
 	return C;
 }
 
+static void ctx_reset_(MLCtx* C);
 static void ctx_reset(MLCtx* C)
+{	/* memory handed out by the dry runtime is host memory: release it the same way even if the mode changed since */
+	const int was = mlsd_runtime_is_dry();
+	if (C->dry != was) mlsd_runtime_dry(C->dry);
+	ctx_reset_(C);
+	if (C->dry != was) mlsd_runtime_dry(was);
+	C->dry = was;           /* what is built from here on follows the current mode */
+}
+
+static void ctx_reset_(MLCtx* C)
 {
 	if (C->graph_exec) { mlsd_graph_destroy(C->graph_exec); C->graph_exec = NULL; }
 	for (int i=0;i<C->n_tensors;++i) free(C->tensors[i]);

@@ -92,6 +92,7 @@ struct MLCtx {
 	/* batched cross-attention K/V projection of the (step-constant) context: one GEMM for all layers */
 	struct { MLTensor* ctx; char* wbase; char* out16; int n_in, n_total, n_used; } kvb;
 	int prepared, tuned, n_tune_miss;
+	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */
 	MLCtxInfo info;
 };

@@ -628,7 +628,7 @@ static int prompt_tokenize(MLIS_Ctx* S, const MLISPrompt* P, int32_t** ptok, flo
 	int32_t *tok = (int32_t*)malloc(sizeof(int32_t) * cap); float *w = (float*)malloc(sizeof(float) * cap);
 	int nonempty = 0;
 	for (int i=0;i<P->n_chunk;++i) if (P->chunks[i].len > 0) nonempty = 1;
-	if (nonempty && tokenizer_get(S) < 0) { free(tok); free(w); return -1; }
+	if (nonempty) { int r = tokenizer_get(S); if (r < 0) { free(tok); free(w); return r; } }
 	for (int i=0; i<P->n_chunk && nonempty; ++i) {
 		int32_t buf[512];
 		int k = clip_tokenize(S->tok, P->text + P->chunks[i].begin, P->chunks[i].len, buf, 512);
@@ -770,6 +770,7 @@ static int image_fetch(MLIS_Ctx* S, MLIS_Tensor* image, int w, int h)
 {
 	const int B = S->n_batch > 0 ? S->n_batch : 1;
 	mlis_tensor_resize(image, w, h, 3, B);
+	if (mlis_amd_sync(S->eng) < 0) return api_error_lib(S, MLIS_E_UNKNOWN);        /* the decode was enqueued on the engine's own stream */
 	if (mlsd_memcpy(image->d, mlis_amd_image_device(S->eng), (size_t)B*3*w*h*4, 1, NULL) || mlsd_device_sync()) return api_error_lib(S, MLIS_E_UNKNOWN);
 	const size_t n = mlis_tensor_count(image);
 	for (size_t i=0;i<n;++i) if (!isfinite(image->d[i])) return api_error(S, MLIS_E_NAN, "NaN found in decoded image");   /* :1348-1349 */
@@ -918,8 +919,8 @@ MLB_API int mlis_generate(MLIS_Ctx* S)
 MLB_API MLIS_Image* mlis_image_get(MLIS_Ctx* S, int idx)
 {	/* :1775-1793 + mlis_tensor_to_image :118-139: u8 = clamp(v*255, 0, 255) truncated */
 	if (!S || S->signature != CTX_SIGNATURE) return NULL;
-	if (idx < 0 || idx >= S->image.n[3] || idx >= MAX_IMAGES) { api_error(S, MLIS_E_UNKNOWN, "only image idx < %d available", S->image.n[3]); return NULL; }
 	if (!(S->image.flags & LT_F_READY)) { api_error(S, MLIS_E_UNKNOWN, "image not ready"); return NULL; }
+	if (idx < 0 || idx >= S->image.n[3] || idx >= MAX_IMAGES) { api_error(S, MLIS_E_UNKNOWN, "only image idx < %d available", S->image.n[3]); return NULL; }
 	const int n0 = S->image.n[0], n1 = S->image.n[1], n2 = S->image.n[2];
 	MLIS_Image *I = &S->imgex[idx];
 	I->w = n0; I->h = n1; I->c = n2; I->sz = (size_t)n0*n1*n2;

@@ -21,6 +21,7 @@ def model_params(model, lat=8):
         def add(ctx):
             for k, t, ne in ctx.param_list():
                 out.append((k, t == 1, tuple(int(d) for d in ne[::-1])))
+            ctx.destroy()                    # inside the dry block: its memory came from the dry runtime
         un = engine.Unet(model, lat, lat, 1, synth=False)
         add(un.ctx)
         vmodel = "sd1" if model == "sd2" else model

@@ -428,7 +428,9 @@ def test_conv2d_split_k(K):
 @pytest.mark.parametrize("nb,heads,dh,tq,tk,causal", [
     (1, 2, 64, 256, 256, 0), (2, 3, 64, 100, 77, 0), (1, 4, 64, 77, 77, 1), (1, 2, 40, 200, 200, 0),
     (1, 2, 80, 130, 77, 0), (1, 2, 160, 64, 64, 0), (1, 2, 32, 64, 77, 0), (2, 10, 64, 1024, 1024, 0),
-    (1, 1, 64, 1, 1, 0), (1, 2, 64, 300, 300, 1)])
+    (1, 1, 64, 1, 1, 0), (1, 2, 64, 300, 300, 1),
+    # d_head 64, Tq % 256 == 0: the 64-rows-per-wave LDS-DMA kernel (ragged key counts: clamped duplicates are masked)
+    (2, 3, 64, 256, 256, 0), (1, 2, 64, 512, 77, 0), (1, 3, 64, 256, 333, 0), (1, 9, 64, 768, 32, 0), (3, 3, 64, 256, 1, 0)])
 def test_attention(K, nb, heads, dh, tq, tk, causal):
     kernels, _lib = K
     rng = np.random.default_rng(dh + tq)
@@ -453,7 +455,13 @@ def test_attention_fused_qkv_strides(K):
     """q/k/v as column slices of one [T][3*D] projection output (how the UNet self-attention feeds it)."""
     kernels, _lib = K
     rng = np.random.default_rng(3)
-    heads, dh, T = 5, 64, 192
+    _attention_fused_qkv(K, 5, 64, 192)
+    _attention_fused_qkv(K, 5, 64, 512)      # the 64-rows-per-wave kernel on strided rows
+
+
+def _attention_fused_qkv(K, heads, dh, T):
+    kernels, _lib = K
+    rng = np.random.default_rng(3)
     D = heads * dh
     qkv = f16r(rng.standard_normal((1, T, 3 * D)))
     ref = O.from_ot(O.L().orc_attention(O.to_ot(qkv[:, :, :D][None]), O.to_ot(qkv[:, :, D:2 * D][None]),
