@@ -78,6 +78,7 @@ void mlctx_tensor_shape(const MLTensor* t, int64_t ne[4]);
 
 /* ---- parameters (tstore_tensor_read / mlctx_tstore_load: src/mlblock.c:232-292) */
 int mlctx_param_count(const MLCtx* C);
+int mlctx_params_loaded(const MLCtx* C);       /* 1 when every parameter has been set (synth / param_set / tstore_load) */
 /* key = full dotted name as the reference derives it (src/mlblock.c:67-105) */
 int mlctx_param_info(const MLCtx* C, int i, const char** key, int* type, int64_t ne[4]);
 /* load one parameter from host memory in the REFERENCE layout/shape (element count is what is checked,

@@ -261,7 +261,12 @@ int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask);
  * when sample != 0 with one Philox call per image, else the mean; TAE: direct), marked as the next initial latent */
 int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample);
 MLCtx* mlis_amd_encoder_ctx(MLIS_AmdCtx* S);                                /* NULL before the first encode / prepare */
-MLCtx* mlis_amd_encoder_prepare(MLIS_AmdCtx* S);                            /* build the encoder plan now (weights: synth or caller-loaded) */
+MLCtx* mlis_amd_encoder_prepare(MLIS_AmdCtx* S);
+/* VAE tiling (MLIS_OPT_VAE_TILE, src/vae.c:245-300,333-391): tile size in pixels (rounded up to 64; 0 = off).  Decode / encode then
+ * run tile by tile through tile-sized plans; *_tile_prepare build them (NULL when tiling does not apply: TAE, or one tile covers all) */
+int mlis_amd_set_vae_tile(MLIS_AmdCtx* S, int tile_px);
+MLCtx* mlis_amd_decoder_tile_prepare(MLIS_AmdCtx* S);
+MLCtx* mlis_amd_encoder_tile_prepare(MLIS_AmdCtx* S);                            /* build the encoder plan now (weights: synth or caller-loaded) */
 int mlis_amd_last_n_step(MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */

@@ -220,6 +220,11 @@ int mlsd_mask_apply(float* x, const float* x0, const float* mask /*[HW]*/, int H
  * [B][cz][HW]; rnd NCHW [B][cz][HW] or NULL (mean only) */
 int mlsd_latent_sample(const float* moments, int64_t ld, const float* rnd, float* latent, int B, int cz, int HW, float scale,
                        void* stream);
+int mlsd_latent_sample_nchw(const float* moments /* NCHW [B][2cz][HW] */, const float* rnd, float* latent, int B, int cz, int HW,
+                            float scale, void* stream);
+/* ltensor_copy_slice2 (src/localtensor.h:84-94; VAE tiling, src/vae.c:283-297,368-382) on NCHW fp32 [planes][h][w] tensors */
+int mlsd_copy_slice2(float* dst, int dw, int dh, const float* src, int sw, int sh, int n0, int n1, int di0, int di1,
+                     int si0, int si1, int planes, void* stream);
 /* finite check (ltensor_finite_check, src/unet.c:487): counts non-finite values into *count (device int32) */
 int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream);
 /* deterministic synthetic parameter fill, bit-identical to oracle/o_core.c orc_synth_fill.

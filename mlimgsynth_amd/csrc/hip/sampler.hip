@@ -142,9 +142,60 @@ __global__ void latent_sample_kernel(const float* __restrict__ mom, long ld, con
     }
 }
 
+// the same for moments already in the reference layout NCHW [B][2cz][HW] (tiled encode pastes tiles into that layout)
+__global__ void latent_sample_nchw_kernel(const float* __restrict__ mom, const float* __restrict__ rnd, float* __restrict__ out,
+                                          int B, int cz, int HW, float scale)
+{
+    const long total = (long)B * cz * HW;
+    GRID_LOOP(i, total) {
+        const long per = (long)cz * HW;
+        const int b = (int)(i / per);
+        const long j = i - (long)b * per;
+        float v = mom[(long)b * 2 * per + j];
+        if (rnd) {
+            float lv = mom[(long)b * 2 * per + per + j];
+            lv = lv < -30.f ? -30.f : (lv > 20.f ? 20.f : lv);
+            v = (float)__dadd_rn((double)v, __dmul_rn(exp(__dmul_rn((double)lv, 0.5)), (double)rnd[i]));
+        }
+        out[i] = __fmul_rn(v, scale);
+    }
+}
+
+// ltensor_copy_slice2 (src/localtensor.h:84-94) on NCHW fp32 planes: dst[pl][di1+y][di0+x] = src[pl][si1+y][si0+x], n0 x n1 window
+__global__ void copy_slice2_kernel(float* __restrict__ dst, int dw, int dh, const float* __restrict__ src, int sw, int sh,
+                                   int n0, int n1, int di0, int di1, int si0, int si1, int planes)
+{
+    const long total = (long)planes * n1 * n0;
+    GRID_LOOP(i, total) {
+        const int x = (int)(i % n0);
+        const long t = i / n0;
+        const int y = (int)(t % n1), pl = (int)(t / n1);
+        dst[((long)pl * dh + di1 + y) * dw + di0 + x] = src[((long)pl * sh + si1 + y) * sw + si0 + x];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+MLSD_API int mlsd_latent_sample_nchw(const float* moments, const float* rnd, float* latent, int B, int cz, int HW, float scale, void* stream)
+{
+    hipLaunchKernelGGL(latent_sample_nchw_kernel, dim3(nblk((long)B * cz * HW)), dim3(256), 0, (hipStream_t)stream, moments, rnd, latent,
+                       B, cz, HW, scale);
+    return mlsd_check_launch("latent_sample_nchw");
+}
+
+MLSD_API int mlsd_copy_slice2(float* dst, int dw, int dh, const float* src, int sw, int sh, int n0, int n1, int di0, int di1,
+                              int si0, int si1, int planes, void* stream)
+{
+    if (n0 <= 0 || n1 <= 0 || planes <= 0) return 0;
+    if (di0 < 0 || di1 < 0 || si0 < 0 || si1 < 0 || di0 + n0 > dw || di1 + n1 > dh || si0 + n0 > sw || si1 + n1 > sh)
+        return mlsd_set_error(-1, "mlsd_copy_slice2: window out of bounds");
+    hipLaunchKernelGGL(copy_slice2_kernel, dim3(nblk((long)planes * n0 * n1)), dim3(256), 0, (hipStream_t)stream, dst, dw, dh, src, sw, sh,
+                       n0, n1, di0, di1, si0, si1, planes);
+    return mlsd_check_launch("copy_slice2");
+}
+
 
 MLSD_API int mlsd_dxdt_cfg(const float* eps, int64_t ld, const float* x_eval, float* dx, int B, int C, int HW, float cfg,
                            int vparam, float c_out, float c_skip, void* stream)

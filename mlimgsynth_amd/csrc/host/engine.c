@@ -60,6 +60,11 @@ struct MLIS_AmdCtx {
 	int n_draw_max, n_draw_gen;          /* noise draws of the current denoise call: planned / generated so far */
 	int i_eval;
 	mlis_amd_progress_fn cb; void* cb_user;
+	/* VAE tiling (MLIS_OPT_VAE_TILE; src/vae.c:245-300,333-391): tile-sized plans, built on first use */
+	int vae_tile, tl_w, tl_h, ti_w, ti_h;             /* option (pixels); latent / image tile size of the decode and encode plans */
+	MLCtx *dect_ctx, *enct_ctx;
+	MLTensor *t_lat_dect, *t_img_enct;
+	float *d_lat_tile, *d_img_tile, *d_imgin_tile, *d_mom_tile, *d_mom;
 };
 
 static int fail(const char* msg) { return mlsd_set_error(-1, "%s", msg); }
@@ -71,6 +76,9 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	if (S->unet_ctx) mlctx_destroy(S->unet_ctx);
 	if (S->dec_ctx) mlctx_destroy(S->dec_ctx);
 	if (S->enc_ctx) mlctx_destroy(S->enc_ctx);
+	if (S->dect_ctx) mlctx_destroy(S->dect_ctx);
+	if (S->enct_ctx) mlctx_destroy(S->enct_ctx);
+	mlsd_free(S->d_lat_tile); mlsd_free(S->d_img_tile); mlsd_free(S->d_imgin_tile); mlsd_free(S->d_mom_tile); mlsd_free(S->d_mom);
 	mlsd_free(S->d_xin);
 	mlsd_free(S->d_x); mlsd_free(S->d_dx); mlsd_free(S->d_x0); mlsd_free(S->d_lmask); mlsd_free(S->d_img); mlsd_free(S->d_img_in);
 	for (int i=0;i<N_TMP;++i) mlsd_free(S->d_tmp[i]);
@@ -443,8 +451,129 @@ MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 	return 1;
 }
 
+/* ------------------------------------------------------------------ VAE tiling
+ * sdvae_decode / sdvae_encode with tile_px > 0 (src/vae.c:333-391, 245-300): the latent (image) is cut into overlapping
+ * tiles of tile_px (+ a margin of k = 8 latent pixels / 64 image pixels on every side), each tile runs through a tile-sized
+ * plan, and the interior of its result is pasted into the output in the reference's order (later tiles overwrite the
+ * margins of earlier ones).  TAE codecs are never tiled (the reference only tiles sdvae_*). */
+MLB_API int mlis_amd_set_vae_tile(MLIS_AmdCtx* S, int tile_px)
+{
+	if (tile_px < 0) tile_px = 0;
+	if (tile_px != S->vae_tile) {
+		mlsd_stream_sync(S->stream);
+		if (S->dect_ctx) { mlctx_destroy(S->dect_ctx); S->dect_ctx = NULL; }
+		if (S->enct_ctx) { mlctx_destroy(S->enct_ctx); S->enct_ctx = NULL; }
+		S->vae_tile = tile_px;
+	}
+	return 1;
+}
+
+static int tile_dims(int tile_px, int margin2, int full, int unit)
+{	/* n = min(round_up(tile_px, 64)/unit + 2k, full); returns full when one tile covers everything (tiling disabled) */
+	const int t = (tile_px + 63) / 64 * 64;
+	const int n = t / unit + margin2;
+	return n < full ? n : full;
+}
+
+/* builds (once) the decode tile plan; returns NULL with no error when tiling does not apply */
+MLB_API MLCtx* mlis_amd_decoder_tile_prepare(MLIS_AmdCtx* S)
+{
+	if (S->dect_ctx) return S->dect_ctx;
+	if (S->vae_tile <= 0 || S->c.use_tae) return NULL;
+	const int f = S->vae_p.f_down, k = 8;
+	const int n0 = tile_dims(S->vae_tile, 2*k, S->lw, f), n1 = tile_dims(S->vae_tile, 2*k, S->lh, f);
+	if (n0 == S->lw && n1 == S->lh) return NULL;                                      /* one tile: disabled (vae.c:347-348) */
+	const int B = S->B;
+	if (!S->d_lat_tile && mlsd_malloc((void**)&S->d_lat_tile, (size_t)B*4*n0*n1*4)) return NULL;
+	if (!S->d_img_tile && mlsd_malloc((void**)&S->d_img_tile, (size_t)B*3*n0*f*n1*f*4)) return NULL;
+	MLCtx *C = mlctx_new(S->stream);
+	int ok = sdvae_decode_init(C, &S->vae_p, n0, n1, B, &S->t_lat_dect) >= 0 &&
+	         mlctx_input_bind(S->t_lat_dect, S->d_lat_tile, B, NULL, 1 / S->vae_p.scale_factor, 0) >= 0 &&
+	         sdvae_decode_build(C, &S->vae_p, S->t_lat_dect) >= 0;
+	if (ok && !S->c.defer_weights) ok = mlctx_params_synth(C, S->c.weight_seed) >= 0;
+	if (!ok) { mlctx_destroy(C); return NULL; }
+	S->dect_ctx = C; S->tl_w = n0; S->tl_h = n1;
+	return C;
+}
+
+MLB_API MLCtx* mlis_amd_encoder_tile_prepare(MLIS_AmdCtx* S)
+{
+	if (S->enct_ctx) return S->enct_ctx;
+	if (S->vae_tile <= 0 || S->c.use_tae) return NULL;
+	const int f = S->vae_p.f_down, k = f*8, W = S->c.width, H = S->c.height;
+	const int n0 = tile_dims(S->vae_tile, 2*k, W, 1), n1 = tile_dims(S->vae_tile, 2*k, H, 1);
+	if (n0 == W && n1 == H) return NULL;
+	const int B = S->B;
+	if (!S->d_img_in && mlsd_malloc((void**)&S->d_img_in, (size_t)B*3*W*H*4)) return NULL;
+	if (!S->d_imgin_tile && mlsd_malloc((void**)&S->d_imgin_tile, (size_t)B*3*n0*n1*4)) return NULL;
+	if (!S->d_mom_tile && mlsd_malloc((void**)&S->d_mom_tile, (size_t)B*8*(n0/f)*(n1/f)*4)) return NULL;
+	if (!S->d_mom && mlsd_malloc((void**)&S->d_mom, (size_t)B*8*S->hw*4)) return NULL;
+	MLCtx *C = mlctx_new(S->stream);
+	int ok = sdvae_encode_init(C, &S->vae_p, n0, n1, B, &S->t_img_enct) >= 0 &&
+	         mlctx_input_bind(S->t_img_enct, S->d_imgin_tile, B, NULL, 1.0f, 2) >= 0 &&
+	         sdvae_encode_build(C, &S->vae_p, S->t_img_enct) >= 0;
+	if (ok && !S->c.defer_weights) ok = mlctx_params_synth(C, S->c.weight_seed) >= 0;
+	if (!ok) { mlctx_destroy(C); return NULL; }
+	S->enct_ctx = C; S->ti_w = n0; S->ti_h = n1;
+	return C;
+}
+
+static int decode_tiled(MLIS_AmdCtx* S)
+{	/* src/vae.c:351-383 */
+	const int f = S->vae_p.f_down, k = 8, B = S->B;
+	const int lat_n0 = S->lw, lat_n1 = S->lh, n0 = S->tl_w, n1 = S->tl_h;
+	const int img_n0 = lat_n0*f, img_n1 = lat_n1*f;
+	const int step0 = n0 - 2*k, step1 = n1 - 2*k;
+	const int n_tile0 = (lat_n0 + step0 - 1) / step0, n_tile1 = (lat_n1 + step1 - 1) / step1;
+	void *st = S->stream;
+	MLTensor *r = mlctx_result(S->dect_ctx);
+	int64_t ld = 0;
+	const float *y = mlctx_tensor_device_f32(S->dect_ctx, r, &ld);
+	for (int t1=0; t1<n_tile1; ++t1) {
+		const int i1 = t1*step1 < lat_n1 - n1 ? t1*step1 : lat_n1 - n1;
+		for (int t0=0; t0<n_tile0; ++t0) {
+			const int i0 = t0*step0 < lat_n0 - n0 ? t0*step0 : lat_n0 - n0;
+			if (mlsd_copy_slice2(S->d_lat_tile, n0, n1, S->d_x, lat_n0, lat_n1, n0, n1, 0, 0, i0, i1, B*4, st)) return -1;
+			if (mlctx_compute(S->dect_ctx) < 0) return -1;
+			if (mlsd_nhwc_to_nchw_f32(y, ld, B, 3, n0*f*n1*f, S->d_img_tile, 0.5f, 0.5f, st)) return -1;   /* (x+1)/2: elementwise, commutes with the paste */
+			const int d0 = i0 ? k : 0, d1 = i1 ? k : 0;
+			if (mlsd_copy_slice2(S->d_img, img_n0, img_n1, S->d_img_tile, n0*f, n1*f, (n0-k)*f, (n1-k)*f, (i0+d0)*f, (i1+d1)*f,
+					d0*f, d1*f, B*3, st)) return -1;
+		}
+	}
+	return 1;
+}
+
+static int encode_tiled(MLIS_AmdCtx* S)
+{	/* src/vae.c:262-299: tiles of the image -> moments tiles -> pasted into the full moments tensor (NCHW [B][8][lh][lw]) */
+	const int f = S->vae_p.f_down, k = f*8, B = S->B;
+	const int img_n0 = S->c.width, img_n1 = S->c.height, n0 = S->ti_w, n1 = S->ti_h;
+	const int lat_n0 = img_n0/f, lat_n1 = img_n1/f;
+	const int step0 = n0 - 2*k, step1 = n1 - 2*k;
+	const int n_tile0 = (img_n0 + step0 - 1) / step0, n_tile1 = (img_n1 + step1 - 1) / step1;
+	void *st = S->stream;
+	MLTensor *r = mlctx_result(S->enct_ctx);
+	int64_t ld = 0;
+	const float *y = mlctx_tensor_device_f32(S->enct_ctx, r, &ld);
+	for (int t1=0; t1<n_tile1; ++t1) {
+		const int i1 = t1*step1 < img_n1 - n1 ? t1*step1 : img_n1 - n1;
+		for (int t0=0; t0<n_tile0; ++t0) {
+			const int i0 = t0*step0 < img_n0 - n0 ? t0*step0 : img_n0 - n0;
+			if (mlsd_copy_slice2(S->d_imgin_tile, n0, n1, S->d_img_in, img_n0, img_n1, n0, n1, 0, 0, i0, i1, B*3, st)) return -1;
+			if (mlctx_compute(S->enct_ctx) < 0) return -1;
+			if (mlsd_count_nonfinite(y, (size_t)B*(n0/f)*(n1/f)*ld, S->d_nan, st)) return -1;
+			if (mlsd_nhwc_to_nchw_f32(y, ld, B, 8, (n0/f)*(n1/f), S->d_mom_tile, 1.0f, 0.0f, st)) return -1;
+			const int d0 = i0 ? k : 0, d1 = i1 ? k : 0;
+			if (mlsd_copy_slice2(S->d_mom, lat_n0, lat_n1, S->d_mom_tile, n0/f, n1/f, (n0-k)/f, (n1-k)/f, (i0+d0)/f, (i1+d1)/f,
+					d0/f, d1/f, B*8, st)) return -1;
+		}
+	}
+	return 1;
+}
+
 MLB_API int mlis_amd_decode(MLIS_AmdCtx* S)
 {
+	if (S->vae_tile > 0 && !S->c.use_tae && mlis_amd_decoder_tile_prepare(S)) return decode_tiled(S);
 	if (mlctx_compute(S->dec_ctx) < 0) return -1;
 	int64_t ld = 0;
 	MLTensor *r = mlctx_result(S->dec_ctx);
@@ -487,13 +616,19 @@ MLB_API int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample)
 	const int B = S->B, W = S->c.width, H = S->c.height;
 	const size_t img_elems = (size_t)B*3*W*H;
 	void *st = S->stream;
-	if (!S->enc_ctx && !mlis_amd_encoder_prepare(S)) return -1;
+	const int tiled = S->vae_tile > 0 && !S->c.use_tae && mlis_amd_encoder_tile_prepare(S) != NULL;
+	if (!tiled && !S->enc_ctx && !mlis_amd_encoder_prepare(S)) return -1;
 	if (mlsd_memcpy(S->d_img_in, images, img_elems*4, 0, st)) return -1;
-	if (mlctx_compute(S->enc_ctx) < 0) return -1;
-	MLTensor *r = mlctx_result(S->enc_ctx);
-	int64_t ld = 0;
-	const float *y = mlctx_tensor_device_f32(S->enc_ctx, r, &ld);
-	if (mlsd_memset(S->d_nan, 0, 4, st) || mlsd_count_nonfinite(y, (size_t)B*S->hw*ld, S->d_nan, st)) return -1;
+	if (mlsd_memset(S->d_nan, 0, 4, st)) return -1;
+	const float *y; int64_t ld = 0;
+	if (tiled) {
+		if (encode_tiled(S) < 0) return -1;
+		y = NULL;
+	} else {
+		if (mlctx_compute(S->enc_ctx) < 0) return -1;
+		y = mlctx_tensor_device_f32(S->enc_ctx, mlctx_result(S->enc_ctx), &ld);
+		if (mlsd_count_nonfinite(y, (size_t)B*S->hw*ld, S->d_nan, st)) return -1;
+	}
 	if (S->c.use_tae) {
 		if (mlsd_nhwc_to_nchw_f32(y, ld, B, 4, S->hw, S->d_x, 1.0f, 0.0f, st)) return -1;
 	} else {
@@ -503,7 +638,8 @@ MLB_API int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample)
 			rnd = noise_draw(S, 0);
 			if (!rnd) return -1;
 		}
-		if (mlsd_latent_sample(y, ld, rnd, S->d_x, B, S->vae_p.ch_z, S->hw, S->vae_p.scale_factor, st)) return -1;
+		if (tiled) { if (mlsd_latent_sample_nchw(S->d_mom, rnd, S->d_x, B, S->vae_p.ch_z, S->hw, S->vae_p.scale_factor, st)) return -1; }
+		else if (mlsd_latent_sample(y, ld, rnd, S->d_x, B, S->vae_p.ch_z, S->hw, S->vae_p.scale_factor, st)) return -1;
 	}
 	int32_t nan_count = 0;
 	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;

@@ -771,6 +771,7 @@ MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
 
 /* ------------------------------------------------------------------ parameters */
 MLB_API int mlctx_param_count(const MLCtx* C) { return C->n_params; }
+MLB_API int mlctx_params_loaded(const MLCtx* C) { for (int i=0;i<C->n_params;++i) if (!C->params[i].loaded) return 0; return 1; }
 
 MLB_API int mlctx_param_info(const MLCtx* C, int i, const char** key, int* type, int64_t ne[4])
 {

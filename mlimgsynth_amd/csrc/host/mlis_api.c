@@ -583,6 +583,10 @@ static int engine_get(MLIS_Ctx* S, int lw, int lh)
 	}
 	if (mlis_amd_set_sampler(S->eng, n_step, method, sched, S->cfg_scale, S->s_ancestral, S->s_noise, S->f_t_ini, S->f_t_end) < 0)
 		return api_error_lib(S, MLIS_E_OPT_VALUE);
+	/* VAE_TILE (:1318,1345): tile-sized decoder plan, weights loaded like the full-size one */
+	mlis_amd_set_vae_tile(S->eng, S->vae_tile);
+	MLCtx *tc = mlis_amd_decoder_tile_prepare(S->eng);
+	if (tc && !mlctx_params_loaded(tc) && ctx_weights(S, tc, 0) < 0) return -1;
 	return 1;
 }
 
@@ -745,12 +749,11 @@ MLB_API int mlis_image_encode(MLIS_Ctx* S, const MLIS_Tensor* image, MLIS_Tensor
 	if (image->n[2] != 3 || image->n[3] != 1) return api_error(S, MLIS_E_IMAGE, "invalid input image shape: %dx%dx%dx%d", image->n[0], image->n[1], image->n[2], image->n[3]);
 	const int w = image->n[0], h = image->n[1];
 	if (engine_for_image(S, w, h) < 0) return -1;
-	MLCtx *ec = mlis_amd_encoder_ctx(S->eng);
-	if (!ec) {
-		ec = mlis_amd_encoder_prepare(S->eng);
-		if (!ec) return api_error_lib(S, MLIS_E_UNKNOWN);
-		if (ctx_weights(S, ec, !!(S->flags & CF_USE_TAE)) < 0) return -1;
-	}
+	MLCtx *ec = mlis_amd_encoder_tile_prepare(S->eng);          /* VAE_TILE: the tile-sized encoder, when tiling applies */
+	if (!ec) ec = mlis_amd_encoder_ctx(S->eng);
+	if (!ec) ec = mlis_amd_encoder_prepare(S->eng);
+	if (!ec) return api_error_lib(S, MLIS_E_UNKNOWN);
+	if (!mlctx_params_loaded(ec) && ctx_weights(S, ec, !!(S->flags & CF_USE_TAE)) < 0) return -1;
 	const int B = S->n_batch > 0 ? S->n_batch : 1;
 	const size_t per = (size_t)3 * w * h;
 	float *imgs = (float*)malloc(per * B * 4);

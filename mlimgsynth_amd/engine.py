@@ -225,6 +225,8 @@ def _proto2():
     l.mlis_amd_last_unet_ms.argtypes = [vp]
     l.mlis_amd_last_nfe.argtypes = [vp]
     l.mlis_amd_last_n_step.argtypes = [vp]
+    l.mlis_amd_sync.argtypes = [vp]
+    l.mlis_amd_set_vae_tile.argtypes = [vp, c_int]
     l.mlis_amd_seed.argtypes = [vp, ctypes.POINTER(c_u64)]
     l.mlis_amd_set_init_latent.argtypes = [vp, FP]
     l.mlis_amd_set_lmask.argtypes = [vp, FP]
@@ -362,6 +364,17 @@ class Generator:
 
     def decode(self):
         check1(_proto2().mlis_amd_decode(self.h), "mlis_amd_decode")
+        check1(_proto2().mlis_amd_sync(self.h), "mlis_amd_sync")
+
+    def set_vae_tile(self, tile_px):
+        check1(_proto2().mlis_amd_set_vae_tile(self.h, int(tile_px)), "mlis_amd_set_vae_tile")
+
+    def image(self):
+        from ._lib import lib
+        out = np.empty((self.B, 3, self.h_px, self.w), np.float32)
+        lib().mlsd_memcpy(out.ctypes.data_as(vp), vp(self.image_ptr()), ctypes.c_size_t(out.nbytes), 1, None)
+        lib().mlsd_device_sync()
+        return out
 
     def latent_ptr(self):
         return _proto2().mlis_amd_latent_device(self.h)

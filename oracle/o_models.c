@@ -451,6 +451,74 @@ OT* orc_vae_encode_moments(OParams* P, const char* prefix, const OrcVaeParams* V
 	return x;
 }
 
+/* ltensor_copy_slice2 on [W,H,C,1] tensors (src/localtensor.c:15-60) */
+static void copy_slice2(OT* dst, const OT* src, int n0, int n1, int di0, int di1, int si0, int si1)
+{
+	const int64_t C = src->ne[2];
+	for (int64_t c=0;c<C;++c) for (int y=0;y<n1;++y) for (int x=0;x<n0;++x)
+		dst->d[(c*dst->ne[1] + di1 + y)*dst->ne[0] + di0 + x] = src->d[(c*src->ne[1] + si1 + y)*src->ne[0] + si0 + x];
+}
+
+/* sdvae_decode with tile_px > 0, src/vae.c:333-391 */
+OT* orc_vae_decode_tiled(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* latent, int tile_px)
+{
+	const int f = V->f_down, k = 8, lat_n0 = (int)latent->ne[0], lat_n1 = (int)latent->ne[1];
+	int n0 = lat_n0, n1 = lat_n1;
+	if (tile_px > 0) {
+		tile_px = ((tile_px + 63) / 64) * 64;
+		n0 = tile_px/f + k*2 < lat_n0 ? tile_px/f + k*2 : lat_n0;
+		n1 = tile_px/f + k*2 < lat_n1 ? tile_px/f + k*2 : lat_n1;
+		if (n0 == lat_n0 && n1 == lat_n1) tile_px = 0;
+	}
+	if (tile_px <= 0) return orc_vae_decode(P, prefix, V, latent);
+	const int step0 = n0 - k*2, step1 = n1 - k*2;
+	const int n_tile0 = (lat_n0 + step0 - 1) / step0, n_tile1 = (lat_n1 + step1 - 1) / step1;
+	OT *img = ot_new(lat_n0*f, lat_n1*f, 3, 1), *ltmp = ot_new(n0, n1, 4, 1);
+	for (int t1=0; t1<n_tile1; ++t1) {
+		int i1 = t1*step1 < lat_n1 - n1 ? t1*step1 : lat_n1 - n1;
+		for (int t0=0; t0<n_tile0; ++t0) {
+			int i0 = t0*step0 < lat_n0 - n0 ? t0*step0 : lat_n0 - n0;
+			copy_slice2(ltmp, latent, n0, n1, 0, 0, i0, i1);
+			OT *t = orc_vae_decode(P, prefix, V, ltmp);     /* includes the (x+1)/2 post, elementwise: commutes with the paste */
+			int d0 = i0 ? k : 0, d1 = i1 ? k : 0;
+			copy_slice2(img, t, (n0-k)*f, (n1-k)*f, (i0+d0)*f, (i1+d1)*f, d0*f, d1*f);
+			ot_free(t);
+		}
+	}
+	ot_free(ltmp);
+	return img;
+}
+
+/* sdvae_encode with tile_px > 0, src/vae.c:231-316 (moments, before sampling) */
+OT* orc_vae_encode_moments_tiled(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img, int tile_px)
+{
+	const int f = V->f_down, k = f*8, img_n0 = (int)img->ne[0], img_n1 = (int)img->ne[1];
+	int n0 = img_n0, n1 = img_n1;
+	if (tile_px > 0) {
+		tile_px = ((tile_px + 63) / 64) * 64;
+		n0 = tile_px + k*2 < img_n0 ? tile_px + k*2 : img_n0;
+		n1 = tile_px + k*2 < img_n1 ? tile_px + k*2 : img_n1;
+		if (n0 == img_n0 && n1 == img_n1) tile_px = 0;
+	}
+	if (tile_px <= 0) return orc_vae_encode_moments(P, prefix, V, img);
+	const int step0 = n0 - k*2, step1 = n1 - k*2;
+	const int n_tile0 = (img_n0 + step0 - 1) / step0, n_tile1 = (img_n1 + step1 - 1) / step1;
+	OT *mom = ot_new(img_n0/f, img_n1/f, V->ch_z*2, 1), *itmp = ot_new(n0, n1, 3, 1);
+	for (int t1=0; t1<n_tile1; ++t1) {
+		int i1 = t1*step1 < img_n1 - n1 ? t1*step1 : img_n1 - n1;
+		for (int t0=0; t0<n_tile0; ++t0) {
+			int i0 = t0*step0 < img_n0 - n0 ? t0*step0 : img_n0 - n0;
+			copy_slice2(itmp, img, n0, n1, 0, 0, i0, i1);
+			OT *t = orc_vae_encode_moments(P, prefix, V, itmp);
+			int d0 = i0 ? k : 0, d1 = i1 ? k : 0;
+			copy_slice2(mom, t, (n0-k)/f, (n1-k)/f, (i0+d0)/f, (i1+d1)/f, d0/f, d1/f);
+			ot_free(t);
+		}
+	}
+	ot_free(itmp);
+	return mom;
+}
+
 /* sdvae_latent_sample / sdvae_latent_mean, src/vae.c:188-229: moments [W,H,2cz,1] -> latent [W,H,cz,1];
  * rnd = n floats of N(0,1) (one rng_randn call) or NULL for the mean */
 OT* orc_latent_sample(const OT* mom, const OrcVaeParams* V, const float* rnd)

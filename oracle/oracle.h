@@ -177,6 +177,8 @@ ORACLE_API int orc_generate_latent(OParams* P, const char* prefix, const OrcUnet
 /* ---- "next" rows: image encoders, latent sample, mask downsize, general sampler (all solvers, Karras, s_noise, img2img,
  * in-painting).  method: 1 euler, 2 heun, 3 taylor3, 4 dpmpp2m, 5 dpmpp2s (MLIS_Method); sched: 1 uniform, 2 karras */
 ORACLE_API OT* orc_vae_encode_moments(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img);
+ORACLE_API OT* orc_vae_decode_tiled(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* latent, int tile_px);
+ORACLE_API OT* orc_vae_encode_moments_tiled(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img, int tile_px);
 ORACLE_API OT* orc_latent_sample(const OT* moments, const OrcVaeParams* V, const float* rnd);
 ORACLE_API OT* orc_tae_encode(OParams* P, const char* prefix, const OT* img);
 ORACLE_API void orc_mask_downsize(const float* mask, int w, int h, int f, float* lmask);

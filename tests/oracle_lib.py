@@ -129,6 +129,10 @@ def L():
         l.orc_set_act_rounding.argtypes = [c_int]
         l.orc_vae_encode_moments.restype = OTP
         l.orc_vae_encode_moments.argtypes = [c_vp, ctypes.c_char_p, ctypes.POINTER(VaeParams), OTP]
+        l.orc_vae_decode_tiled.restype = OTP
+        l.orc_vae_decode_tiled.argtypes = [c_vp, ctypes.c_char_p, ctypes.POINTER(VaeParams), OTP, c_int]
+        l.orc_vae_encode_moments_tiled.restype = OTP
+        l.orc_vae_encode_moments_tiled.argtypes = [c_vp, ctypes.c_char_p, ctypes.POINTER(VaeParams), OTP, c_int]
         l.orc_latent_sample.restype = OTP
         l.orc_latent_sample.argtypes = [OTP, ctypes.POINTER(VaeParams), FP]
         l.orc_tae_encode.restype = OTP
