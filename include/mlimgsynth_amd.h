@@ -173,6 +173,10 @@ typedef struct { char* name; int dtype; int n_dim; int64_t shape[4]; /* shape[0]
  * q/k/v_proj views (tensor_callback_main / open_clip_attn_conv, src/mlimgsynth.c:989-1055) */
 MLTStore* mlts_open_safetensors(const char* path, int convert_names);
 void mlts_close(MLTStore* S);
+/* LoRA (src/lora.c:9-138, tensor_callback_lora src/mlimgsynth.c:1068-1092): open a kohya-named LoRA file, merge it into the
+ * model store: W += (scale | alpha/rank | 1) * mult * up.down for every "<X>.lora_down.weight"; returns the number of tensors patched */
+MLTStore* mlts_open_lora(const char* path);
+int mlts_lora_apply(MLTStore* model, const MLTStore* lora, float mult, int wtype);
 int mlts_count(const MLTStore* S);
 const MLTSEntry* mlts_at(const MLTStore* S, int i);
 const MLTSEntry* mlts_find(const MLTStore* S, const char* name);

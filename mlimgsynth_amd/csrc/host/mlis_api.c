@@ -9,7 +9,7 @@
  * and re-uploads them inside every mlis_generate); BATCH_SIZE > 1 works (image i uses seed + i, generate.sh:56-59);
  * the CLIP vocabulary is data found through AUX_DIR (the reference compiles src/clip_merges.c.h in); MODEL may be
  * "synth:<sd1|sd2|sdxl|tiny|tinyxl|tinyv>[:seed]" for the synthetic-weight models used by the benchmark and the tests.
- * LoRA options are accepted and reported as not implemented (still open).
+ * LoRA files (kohya naming) are merged into the weights at load time on the host (src/lora.c:9-138).
  */
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
@@ -23,7 +23,9 @@
 
 #define CTX_SIGNATURE 0x4d4c4953u
 enum { CF_USE_TAE = 1, CF_NO_DECODE = 2, CF_NO_PROMPT_PARSE = 4, CF_UNET_SPLIT = 8, CF_WEIGHT_TYPE_SET = 16, CF_MODEL_TYPE_SET = 32 };
-enum { READY_BACKEND = 1, READY_MODEL = 2 };
+enum { READY_BACKEND = 1, READY_MODEL = 2, READY_LORAS = 4 };
+enum { LF_PROMPT = 1 };
+#define MAX_LORAS 32
 #define LT_F_READY 1
 #define LT_F_OWNMEM 2
 #define N_TMP_TENSORS 4
@@ -44,6 +46,7 @@ struct MLIS_Ctx {
 	MLIS_ErrorHandler errh; void* errh_ud;
 	/* state */
 	int rflags;
+	struct { char* path; float mult; int flags; } loras[MAX_LORAS]; int n_lora, n_lora_applied;
 	char mname[16];
 	uint64_t synth_seed; int synth;
 	MLTStore *ts, *ts_tae;
@@ -159,6 +162,9 @@ MLB_API float mlis_tensor_similarity(const MLIS_Tensor* a, const MLIS_Tensor* b)
 }
 static int tensor_good(const MLIS_Tensor* t) { return t->d && mlis_tensor_count(t) > 0; }
 
+static int lora_add(MLIS_Ctx* S, const char* name, size_t len, float mult, int flags);
+static void loras_remove(MLIS_Ctx* S, int only_prompt);
+
 /* ------------------------------------------------------------------ context */
 MLB_API MLIS_Ctx* mlis_ctx_create_i(int version)
 {
@@ -203,6 +209,7 @@ MLB_API void mlis_ctx_destroy(MLIS_Ctx** pctx)
 	for (int i=0;i<N_TMP_TENSORS;++i) mlis_tensor_free(&S->tmp[i]);
 	for (int i=0;i<MAX_IMAGES;++i) if (S->imgex[i].flags & LT_F_OWNMEM) free(S->imgex[i].d);
 	free(S->infotext); free(S->tokens); free(S->tokens_w);
+	loras_remove(S, 0);
 	S->signature = 0;
 	free(S);
 	*pctx = NULL;
@@ -249,7 +256,41 @@ static void prompt_set(MLIS_Ctx* S, int neg, const char* text, int* err)
 	S->have_ptok[neg] = 0;
 	if (S->flags & CF_NO_PROMPT_PARSE) mlis_prompt_set_raw(P, text);
 	else if (mlis_prompt_set_parse(P, text) < 0) { *err = api_error_lib(S, MLIS_E_PROMPT_PARSE); return; }
-	else if (P->n_lora) *err = api_error(S, MLIS_E_UNKNOWN, "LoRA in the prompt: LoRA merging is not implemented in this library");
+	else for (int i=0; i<P->n_lora; ++i) {            /* <lora:NAME:MULT> in the prompt (:49-52) */
+		int r = lora_add(S, P->lora_names + P->loras[i].name_off, (size_t)P->loras[i].len, P->loras[i].w, LF_PROMPT);
+		if (r < 0) { *err = r; return; }
+	}
+}
+
+static int file_exists(const char* p);
+
+/* mlis_cfg_lora_add + mlis_lora_path_find (:632-680): a path, or NAME -> <lora_dir>/NAME.safetensors */
+static int lora_add(MLIS_Ctx* S, const char* name, size_t len, float mult, int flags)
+{
+	if (S->n_lora >= MAX_LORAS) return api_error(S, MLIS_E_UNKNOWN, "too many loras");
+	char path[1200];
+	snprintf(path, sizeof(path), "%.*s", (int)len, name);
+	if (!file_exists(path)) {
+		const char *d = S->path_lora_dir ? S->path_lora_dir : "";
+		const size_t dl = strlen(d);
+		snprintf(path, sizeof(path), "%s%s%.*s.safetensors", d, (dl && d[dl-1] != '/' && d[dl-1] != '\\') ? "/" : "", (int)len, name);
+		if (!file_exists(path)) return api_error(S, MLIS_E_FILE_NOT_FOUND, "lora model file not found '%s'", path);
+	}
+	S->loras[S->n_lora].path = strdup(path); S->loras[S->n_lora].mult = mult; S->loras[S->n_lora].flags = flags;
+	S->n_lora++;
+	S->rflags &= ~READY_LORAS;
+	return 1;
+}
+
+static void loras_remove(MLIS_Ctx* S, int only_prompt)
+{
+	int k = 0;
+	for (int i=0;i<S->n_lora;++i) {
+		if (only_prompt && !(S->loras[i].flags & LF_PROMPT)) { S->loras[k++] = S->loras[i]; continue; }
+		free(S->loras[i].path);
+		S->rflags &= ~READY_LORAS;
+	}
+	S->n_lora = k;
 }
 
 typedef struct { int is_str; va_list* ap; const char* cur; const char* arg_b; size_t arg_n; } ArgSrc;
@@ -329,8 +370,13 @@ static int option_apply(MLIS_Ctx* S, int id, ArgSrc* A)
 		break;
 	case MLIS_OPT_AUX_DIR: if (!(s = arg_str(A, 1, 0))) BAD_VALUE; str_set(&S->path_aux, s); if (S->tok) { clip_tokr_free(S->tok); S->tok = NULL; } break;
 	case MLIS_OPT_LORA_DIR: if (!(s = arg_str(A, 1, 0))) BAD_VALUE; str_set(&S->path_lora_dir, s); break;
-	case MLIS_OPT_LORA: free(arg_str(A, 0, 1)); return api_error(S, MLIS_E_UNKNOWN, "LoRA merging is not implemented in this library");
-	case MLIS_OPT_LORA_CLEAR: break;
+	case MLIS_OPT_LORA: {
+		if (!(s = arg_str(A, 0, 1))) BAD_VALUE;
+		f = 1;
+		if (A->is_str) { if (!arg_float(A, 0, 1, 1, &f)) BAD_VALUE; } else f = (float)va_arg(*A->ap, double);
+		err = lora_add(S, s, strlen(s), f, 0);
+	} break;
+	case MLIS_OPT_LORA_CLEAR: loras_remove(S, 0); break;
 	case MLIS_OPT_PROMPT: if (!(s = arg_str(A, 1, 0))) BAD_VALUE; prompt_set(S, 0, s, &err); break;
 	case MLIS_OPT_NPROMPT: if (!(s = arg_str(A, 1, 0))) BAD_VALUE; prompt_set(S, 1, s, &err); break;
 	case MLIS_OPT_NO_PROMPT_PARSE: if (!arg_bool(A, &i)) BAD_VALUE; if (i) S->flags |= CF_NO_PROMPT_PARSE; else S->flags &= ~CF_NO_PROMPT_PARSE; break;
@@ -481,7 +527,7 @@ MLB_API const MLIS_BackendInfo* mlis_backend_info_get(MLIS_Ctx* S, unsigned idx,
 	return &S->backend_info;
 }
 
-static int file_exists(const char* p) { struct stat st; return p && !stat(p, &st); }
+static int file_exists(const char* p) { struct stat st; return p && *p && !stat(p, &st); }
 
 MLB_API int mlis_setup(MLIS_Ctx* S)
 {
@@ -525,6 +571,31 @@ MLB_API int mlis_setup(MLIS_Ctx* S)
 			if (!S->ts_tae) return api_error_lib(S, file_exists(S->path_tae) ? MLIS_E_UNKNOWN : MLIS_E_FILE_NOT_FOUND);
 		}
 		S->rflags |= READY_MODEL;
+		S->rflags &= ~READY_LORAS;
+		S->n_lora_applied = 0;
+	}
+	if (!(S->rflags & READY_LORAS)) {
+		/* :1276-1296: patched tensors are dropped (the store is re-read) and every active LoRA is merged again; the resident
+		 * engine and text towers hold the old weights, so they are rebuilt */
+		if (S->n_lora || S->n_lora_applied) {
+			if (S->synth) return api_error(S, MLIS_E_UNKNOWN, "LoRA needs a checkpoint file (the synthetic models have no tensor store)");
+			engine_drop(S); textcond_drop(S);
+			if (S->n_lora_applied) {
+				mlts_close(S->ts);
+				S->ts = mlts_open_safetensors(S->path_model, 1);
+				if (!S->ts) { S->rflags &= ~READY_MODEL; return api_error_lib(S, MLIS_E_UNKNOWN); }
+			}
+			S->n_lora_applied = 0;
+			for (int i=0;i<S->n_lora;++i) {
+				MLTStore *L = mlts_open_lora(S->loras[i].path);
+				if (!L) return api_error_lib(S, MLIS_E_UNKNOWN);
+				int r = mlts_lora_apply(S->ts, L, S->loras[i].mult, S->wtype);
+				mlts_close(L);
+				if (r < 0) return api_error_lib(S, MLIS_E_UNKNOWN);
+				S->n_lora_applied++;
+			}
+		}
+		S->rflags |= READY_LORAS;
 	}
 	return 1;
 }
@@ -916,6 +987,7 @@ MLB_API int mlis_generate(MLIS_Ctx* S)
 	mlis_prompt_free(&S->prompt); mlis_prompt_free(&S->nprompt);
 	S->have_ptok[0] = S->have_ptok[1] = 0;
 	S->f_t_ini = 1; S->f_t_end = 0; S->tuflags = 0;
+	loras_remove(S, 1);                                  /* mlis_cfg_loras_prompt_remove */
 	return 1;
 }
 

@@ -12,6 +12,7 @@
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
 #include <ctype.h>
+#include <math.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -19,6 +20,7 @@
 
 struct MLTStore {
 	MLTSEntry* e; int n, cap;
+	void** owned; int n_owned, cap_owned;     /* heap buffers of patched tensors (LoRA) */
 	void* map; size_t map_size;
 	int n_unused, n_split;
 };
@@ -113,6 +115,8 @@ MLB_API void mlts_close(MLTStore* S)
 {
 	if (!S) return;
 	for (int i=0;i<S->n;++i) free(S->e[i].name);
+	for (int i=0;i<S->n_owned;++i) free(S->owned[i]);
+	free(S->owned);
 	free(S->e);
 	if (S->map) munmap(S->map, S->map_size);
 	free(S);
@@ -142,7 +146,14 @@ static int qkv_split(MLTStore* S, const MLTSEntry* e, const char* newname)
 	return 1;
 }
 
-MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names)
+static MLTStore* open_safetensors(const char* path, int mode);
+
+MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names) { return open_safetensors(path, convert_names ? 1 : 0); }
+/* LoRA file (kohya naming): "lora_" prefix stripped, then tnconv_sd; an unmatched "*.lora_down.weight" is an error, other
+ * unmatched tensors are dropped (tensor_callback_lora, src/mlimgsynth.c:1068-1092) */
+MLB_API MLTStore* mlts_open_lora(const char* path) { return open_safetensors(path, 2); }
+
+static MLTStore* open_safetensors(const char* path, int convert_names)
 {
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) { mlsd_set_error(-6 /* MLIS_E_FILE_NOT_FOUND */, "could not open '%s'", path); return NULL; }
@@ -195,8 +206,18 @@ MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names)
 		if (e.dtype < 0 || want != e.size) { mlsd_set_error(-1, "safetensors tensor '%s': invalid size %zu for dtype/shape", name, e.size); goto fail; }
 		if (!convert_names) { ts_add(S, name, &e); continue; }
 		char conv[512];
-		const int r = tnconv_sd(name, conv, sizeof(conv));                   /* tensor_callback_main :1033-1055 */
+		const char *nm = name;
+		if (convert_names == 2) {                                            /* tensor_callback_lora :1068-1092 */
+			if (strncmp(name, "lora_", 5)) { S->n_unused++; continue; }
+			nm = name + 5;
+		}
+		const int r = tnconv_sd(nm, conv, sizeof(conv));                     /* tensor_callback_main :1033-1055 */
 		if (r < 0) goto fail;
+		if (convert_names == 2 && r == 0) {
+			const size_t l = strlen(nm);
+			if (l >= 17 && !strcmp(nm + l - 17, ".lora_down.weight")) { mlsd_set_error(-1, "unmatched lora tensor: %s", name); goto fail; }
+			S->n_unused++; continue;
+		}
 		if (r == 0) { S->n_unused++; continue; }
 		if (r == TNCONV_R_QKV_PROJ) { if (qkv_split(S, &e, conv) < 0) goto fail; continue; }
 		ts_add(S, conv, &e);
@@ -260,4 +281,83 @@ MLB_API int mlctx_tstore_load(MLCtx* C, const MLTStore* S)
 		n++;
 	}
 	return n;
+}
+
+/* ------------------------------------------------------------------ LoRA merge (src/lora.c:9-138)
+ * For every "<X>.lora_down.weight" of the LoRA store: W[X.weight] += scale * up . down with
+ *   down [n_inner][n0], up [n1][n_inner] (row-major as stored), W [n1][n0];  scale = (X.scale | X.alpha / n_inner | 1) * mult.
+ * Like the reference the operands are taken at the model's weight type (F16: rounded), the product accumulates in fp32 and
+ * the sum is stored back at the weight type; the patched tensor replaces the file's data in the store (heap buffer). */
+static float f16_to_f32_(uint16_t h) { return mlb_f16_bits_to_f32(h); }
+
+static float* entry_to_f32(const MLTSEntry* e, int round_f16)
+{
+	const int64_t n = e->shape[0]*e->shape[1]*e->shape[2]*e->shape[3];
+	float *o = (float*)malloc(sizeof(float) * (size_t)(n ? n : 1));
+	for (int64_t i=0;i<n;++i) {
+		float v;
+		switch (e->dtype) {
+		case MLT_F16: v = f16_to_f32_(((const uint16_t*)e->data)[i]); break;
+		case MLT_BF16: { uint32_t u = (uint32_t)((const uint16_t*)e->data)[i] << 16; memcpy(&v, &u, 4); } break;
+		case MLT_F64: { double d; memcpy(&d, (const char*)e->data + i*8, 8); v = (float)d; } break;
+		default: memcpy(&v, (const char*)e->data + i*4, 4); break;
+		}
+		o[i] = round_f16 ? f16_to_f32_(mlb_f32_to_f16_bits(v)) : v;
+	}
+	return o;
+}
+
+MLB_API int mlts_lora_apply(MLTStore* D, const MLTStore* L, float mult, int wtype)
+{
+	int n_applied = 0;
+	const int r16 = wtype != MLT_F32;
+	char key[600];
+	for (int i=0; i<L->n; ++i) {
+		const MLTSEntry *ld = &L->e[i];
+		const size_t ln = strlen(ld->name);
+		if (ln < 17 || strcmp(ld->name + ln - 17, ".lora_down.weight")) continue;
+		const int bl = (int)(ln - 17);
+		snprintf(key, sizeof(key), "%.*s.weight", bl, ld->name);
+		MLTSEntry *dst = (MLTSEntry*)mlts_find(D, key);
+		if (!dst) return mlsd_set_error(-1, "lora tensor not found in model: %s", key);
+		snprintf(key, sizeof(key), "%.*s.lora_up.weight", bl, ld->name);
+		const MLTSEntry *lu = mlts_find(L, key);
+		if (!lu) return mlsd_set_error(-1, "lora up tensor not found: %s", key);
+		snprintf(key, sizeof(key), "%.*s.scale", bl, ld->name);
+		const MLTSEntry *ls = mlts_find(L, key);
+		snprintf(key, sizeof(key), "%.*s.alpha", bl, ld->name);
+		const MLTSEntry *la = mlts_find(L, key);
+		const int64_t n_inner = ld->shape[ld->n_dim - 1];
+		const int64_t cd = ld->shape[0]*ld->shape[1]*ld->shape[2]*ld->shape[3], cu = lu->shape[0]*lu->shape[1]*lu->shape[2]*lu->shape[3];
+		const int64_t cw = dst->shape[0]*dst->shape[1]*dst->shape[2]*dst->shape[3];
+		const int64_t n0 = cd / n_inner, n1 = cu / n_inner;
+		if (!(dst->n_dim >= 2 && ld->n_dim == dst->n_dim && lu->n_dim == dst->n_dim && cw == n0 * n1))
+			return mlsd_set_error(-1, "lora up/down invalid shapes for %.*s", bl, ld->name);
+		float scale = 1;
+		if (ls) { float *t = entry_to_f32(ls, 0); scale = t[0]; free(t); }
+		else if (la) { float *t = entry_to_f32(la, 0); scale = t[0] / n_inner; free(t); }
+		scale *= mult;
+		float *down = entry_to_f32(ld, r16), *up = entry_to_f32(lu, r16), *w = entry_to_f32(dst, r16);
+		for (int64_t o=0;o<n1;++o) {
+			float *wr = w + o*n0;
+			for (int64_t r=0;r<n_inner;++r) {
+				const float u = up[o*n_inner + r] * scale;
+				const float *dr = down + r*n0;
+				for (int64_t c=0;c<n0;++c) wr[c] += u * dr[c];
+			}
+		}
+		free(down); free(up);
+		if (!isfinite(w[0])) { free(w); return mlsd_set_error(-1, "NaN in LoRA result"); }
+		void *buf;
+		if (r16) {
+			uint16_t *h = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cw);
+			for (int64_t c=0;c<cw;++c) h[c] = mlb_f32_to_f16_bits(w[c]);
+			free(w); buf = h; dst->dtype = MLT_F16; dst->size = (size_t)cw * 2;
+		} else { buf = w; dst->dtype = MLT_F32; dst->size = (size_t)cw * 4; }
+		dst->data = buf;
+		if (D->n_owned == D->cap_owned) { D->cap_owned = D->cap_owned ? D->cap_owned*2 : 64; D->owned = (void**)realloc(D->owned, sizeof(void*)*D->cap_owned); }
+		D->owned[D->n_owned++] = buf;
+		n_applied++;
+	}
+	return n_applied;
 }

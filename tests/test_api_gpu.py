@@ -229,3 +229,66 @@ def test_image_encode_decode_entry_points(lib):
     ref = O.from_ot(O.L().orc_vae_decode(OP.h, b"vae", V, O.to_ot(F.tensor_np(lat))))
     assert dec.shape == (1, 3, 64, 64) and rel(dec - 0.5, ref - 0.5) < 4e-3
     m.close()
+
+
+def test_lora_merge_matches_prepatched_checkpoint(lib, tmp_path):
+    """f4: a kohya-named LoRA file (lora_unet_..., lora_te_...) merged at load time == generating from a checkpoint whose weights
+    were patched beforehand with W + mult * alpha/rank * up.down (src/lora.c:9-138); also through <lora:NAME:MULT> in the prompt."""
+    from safetensors.numpy import load_file, save_file
+    import ckpt_names as CN
+    base = str(tmp_path / "tiny.safetensors")
+    LC.write_checkpoint(base, "tiny", "F16")
+    rng = np.random.default_rng(4)
+    rank, alpha, mult = 4, 2.0, 0.75
+    targets = ["unet.in.2.1.transf.0.attn1.q_proj", "unet.in.2.1.transf.0.attn2.k_proj", "unet.out.1.1.transf.0.ff.net.2",
+               "clip.text.encoder.layers.1.attn.v_proj", "clip.text.encoder.layers.0.mlp.fc1"]
+    params = {k: (f16, shape) for k, f16, shape in LC.model_params("tiny")}
+    tensors = load_file(base)
+    lora = {}
+    for t in targets:
+        f16, shape = params[t + ".weight"]
+        n_out, n_in = shape[-2], shape[-1]
+        down = (rng.standard_normal((rank, n_in)) * 0.2).astype(np.float16)
+        up = (rng.standard_normal((n_out, rank)) * 0.2).astype(np.float16)
+        ext = CN.external_name(t + ".weight", "sd1")[:-len(".weight")]
+        if ext.startswith("model.diffusion_model."):
+            kn = "lora_unet_" + ext[len("model.diffusion_model."):].replace(".", "_")
+        else:                                          # HF text tower: kohya spells it lora_te_text_model_encoder_layers_N_...
+            kn = "lora_te_" + ext[len("cond_stage_model.transformer."):].replace(".", "_")
+        lora[kn + ".lora_down.weight"] = down
+        lora[kn + ".lora_up.weight"] = up
+        lora[kn + ".alpha"] = np.array(alpha, np.float32)
+        w = tensors[ext + ".weight"].astype(np.float32)
+        delta = (up.astype(np.float32) * np.float32(alpha / rank * mult)) @ down.astype(np.float32)
+        tensors[ext + ".weight"] = (w + delta).astype(np.float16)
+    lora["lora_unet_unrelated.metadata_tensor"] = np.zeros(1, np.float32)            # unmatched non-LoRA tensor: dropped
+    patched = str(tmp_path / "tiny_patched.safetensors")
+    save_file(tensors, patched)
+    (tmp_path / "loras").mkdir()
+    save_file(lora, str(tmp_path / "loras" / "style.safetensors"))
+
+    def run(model, lora_opt=None, prompt_lora=False):
+        m = F.Mlis(lib)
+        m.set("model_type", "tiny")
+        m.set("lora_dir", str(tmp_path / "loras"))
+        setup_tiny(m, model=model, steps=4)
+        if lora_opt:
+            m.set("lora", "style", mult)
+        if prompt_lora:
+            m.set("aux_dir", str(tmp_path))
+            m.set("prompt", f"<lora:style:{mult}>")      # empty text after the option is removed: no vocabulary needed
+            m.tokens(TOKS)                               # explicit tokens still take precedence for the text itself
+        m.generate()
+        out = m.tensor(F.TENSOR["LATENT"])
+        m.close()
+        return out
+    ref = run(patched)
+    plain = run(base)
+    got = run(base, lora_opt=True)
+    got2 = run(base, prompt_lora=True)
+    print("lora vs prepatched rel-L2", rel(got, ref), "plain vs prepatched", rel(plain, ref))
+    assert rel(got, ref) < 2e-3 and rel(plain, ref) > 10 * max(rel(got, ref), 1e-6)     # fp32 sum order of the rank-4 product may differ in the last f16 bit
+    assert np.array_equal(got, got2)
+    m = F.Mlis(lib)
+    assert lib.mlis_option_set_str(m.ctx, b"lora", b"does_not_exist,1") == -6
+    m.close()
