@@ -58,6 +58,9 @@ void      mlctx_block_begin(MLCtx* C);
 MLTensor* mlctx_tensor_add(MLCtx* C, const char* name, MLTensor* t);
 MLTensor* mlctx_input_new(MLCtx* C, const char* name, int dtype, int n0, int n1, int n2, int n3);
 MLTensor* mlctx_result(MLCtx* C);
+/* graph-split marker of the reference (src/mlblock.h:133-139, used by --unet-split): no-op here, returns its argument */
+MLTensor* mlctx_split_add(MLCtx* C, MLTensor* t);
+void mlctx_free(MLCtx* C);                /* reference name of mlctx_destroy (src/mlblock.h:82) */
 
 /* ---- inputs / outputs at the host boundary (ltensor_to/from_backend, src/localtensor.h:96-106).
  * Host data is in the reference layout (ne[0] fastest: NCHW fp32 for images). */

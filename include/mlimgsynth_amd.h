@@ -48,15 +48,25 @@ typedef struct {
 	MLTensor *t_x, *t_t, *t_c, *t_l, *t_out;
 } UnetState;
 
+/* host tensor of the reference's boundary (LocalTensor, src/localtensor.h:16-27 == MLIS_Tensor, include/mlimgsynth.h:409-413):
+ * fp32, shape n[0] fastest, flags LT_F_OWNMEM = 1 / LT_F_READY = 2 */
+typedef struct LocalTensor { float* d; int n[4]; int flags; } LocalTensor;
+
+/* the reference's own entry points, same signatures (src/unet.h:55-62): batch 1, graph built at init, weights loaded afterwards
+ * (mlctx_params_synth / mlctx_tstore_load on C).  `split` (--unet-split weight streaming, src/unet.c:390-458) is accepted and
+ * ignored: weights are resident.  x [lw,lh,4,1], cond [n_ctx,77,1,1], label [adm,1,1,1] or NULL -> dx like x (resized). */
+int unet_denoise_init(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, bool split);
+int unet_denoise_run(UnetState* S, const LocalTensor* x, const LocalTensor* cond, const LocalTensor* label, float sigma, LocalTensor* dx);
+
 /* builds the batch-N graph on C (prefix "unet"); weights are loaded afterwards with
  * mlctx_params_synth / mlctx_param_set */
-int unet_denoise_init(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, unsigned n_batch);
+int unet_denoise_init_n(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, unsigned n_batch);
 /* second half of the init: records the graph and calls mlctx_prep (split so that the x input can first be
  * bound to a device-resident latent with mlctx_input_bind) */
 int unet_denoise_build(UnetState* S);
 /* host-boundary evaluation (tests, drop-in for src/unet.c:460-498 with a batch): x [N][4][lh][lw] NCHW,
  * cond [N][77][n_ctx], label [N][adm] or NULL, sigma[N] -> dx like x.  Applies c_in, sigma->t, v-param. */
-int unet_denoise_run(UnetState* S, const float* x, const float* cond, const float* label,
+int unet_denoise_run_n(UnetState* S, const float* x, const float* cond, const float* label,
 	const float* sigma, float* dx);
 
 /* ---------------------------------------------------------------- VAE / TAE decoders */

@@ -157,7 +157,7 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 	/* ---- UNet plan, x bound to the resident evaluation point (c_in scaling + cond/uncond duplication in the gather) */
 	S->unet_ctx = mlctx_new(stream);
 	if (S->c.use_hipgraph) mlctx_set_flags(S->unet_ctx, MLB_F_HIPGRAPH);
-	if (unet_denoise_init(&S->unet, S->unet_ctx, &S->unet_p, S->lw, S->lh, N) < 0) goto err;
+	if (unet_denoise_init_n(&S->unet, S->unet_ctx, &S->unet_p, S->lw, S->lh, N) < 0) goto err;
 	if (mlctx_input_bind(S->unet.t_x, S->d_xin, B, S->d_cin, 1.0f, 0) < 0) { fail("input bind failed"); goto err; }
 	if (unet_denoise_build(&S->unet) < 0) goto err;
 	if (!S->c.defer_weights && mlctx_params_synth(S->unet_ctx, S->c.weight_seed) < 0) goto err;
@@ -282,7 +282,7 @@ static const float* noise_draw(MLIS_AmdCtx* S, int k)
 	return S->d_noise + (size_t)k*lat_elems;
 }
 
-/* mlis_denoise_dxdt + unet_denoise_run (src/mlimgsynth.c:1565-1587, src/unet.c:460-498): one batched evaluation at
+/* mlis_denoise_dxdt + unet_denoise_run_n (src/mlimgsynth.c:1565-1587, src/unet.c:460-498): one batched evaluation at
  * x_eval (device), sigma -> raw UNet output stays in the plan's result tensor.  `prefetch_draws`: noise draws to generate
  * on the host while this evaluation runs. */
 static int unet_eval(MLIS_AmdCtx* S, const float* x_eval, float sigma, int prefetch_upto)

@@ -84,6 +84,9 @@ MLB_API void mlctx_destroy(MLCtx* C)
 	free(C);
 }
 
+MLB_API void mlctx_free(MLCtx* C) { mlctx_destroy(C); }
+MLB_API MLTensor* mlctx_split_add(MLCtx* C, MLTensor* t) { (void)C; return t; }
+
 MLB_API void mlctx_begin(MLCtx* C, const char* name)
 {
 	mlsd_stream_sync(C->stream);

@@ -26,8 +26,8 @@ enum { CF_USE_TAE = 1, CF_NO_DECODE = 2, CF_NO_PROMPT_PARSE = 4, CF_UNET_SPLIT =
 enum { READY_BACKEND = 1, READY_MODEL = 2, READY_LORAS = 4 };
 enum { LF_PROMPT = 1 };
 #define MAX_LORAS 32
-#define LT_F_READY 1
-#define LT_F_OWNMEM 2
+#define LT_F_OWNMEM 1      /* src/localtensor.h:22-27 */
+#define LT_F_READY 2
 #define N_TMP_TENSORS 4
 #define MAX_IMAGES 64
 

@@ -266,7 +266,7 @@ MLB_API float unet_t_to_sigma(const UnetParams* P, float t)
 }
 
 /* ------------------------------------------------------------------ graph setup / host-boundary run */
-MLB_API int unet_denoise_init(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, unsigned n_batch)
+MLB_API int unet_denoise_init_n(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, unsigned n_batch)
 {
 	unet_params_init();
 	memset(S, 0, sizeof(*S));
@@ -290,7 +290,7 @@ MLB_API int unet_denoise_build(UnetState* S)
 	return 1;
 }
 
-MLB_API int unet_denoise_run(UnetState* S, const float* x, const float* cond, const float* label,
+MLB_API int unet_denoise_run_n(UnetState* S, const float* x, const float* cond, const float* label,
 	const float* sigma, float* dx)
 {
 	MLCtx *C = S->ctx;
@@ -323,4 +323,28 @@ MLB_API int unet_denoise_run(UnetState* S, const float* x, const float* cond, co
 	}
 	free(xs); free(ts);
 	return R;
+}
+
+/* ------------------------------------------------------------------ the reference's signatures (src/unet.h:55-62, src/unet.c:336-388,460-498) */
+MLB_API int unet_denoise_init(UnetState* S, MLCtx* C, const UnetParams* P, unsigned lw, unsigned lh, bool split)
+{
+	(void)split;   /* --unet-split re-uploads half the weights per half-graph to save memory (:390-458): replaced by residency */
+	if (unet_denoise_init_n(S, C, P, lw, lh, 1) < 0) return -1;
+	return unet_denoise_build(S);
+}
+
+MLB_API int unet_denoise_run(UnetState* S, const LocalTensor* x, const LocalTensor* cond, const LocalTensor* label, float sigma, LocalTensor* dx)
+{
+	const UnetParams *P = S->par;
+	if (!x || !cond || !dx || x->n[0] != S->lw || x->n[1] != S->lh || x->n[2] != P->n_ch_in || x->n[3] != 1)
+		return mlsd_set_error(-1, "unet_denoise_run: x shape does not match the initialised graph");
+	if (cond->n[0] != P->n_ctx || cond->n[1] != 77) return mlsd_set_error(-1, "unet_denoise_run: cond must be [%d,77]", P->n_ctx);
+	if (P->ch_adm_in && (!label || label->n[0] != P->ch_adm_in)) return mlsd_set_error(-1, "unet_denoise_run: label must be [%d]", P->ch_adm_in);
+	const size_t n = (size_t)x->n[0]*x->n[1]*x->n[2];
+	if (dx != x) {   /* ltensor_resize_like(dx, x) (:466) */
+		if (!(dx->flags & 1)) dx->d = NULL;
+		dx->d = (float*)realloc(dx->d, n * sizeof(float));
+		memcpy(dx->n, x->n, sizeof(dx->n)); dx->flags |= 1;
+	}
+	return unet_denoise_run_n(S, x->d, cond->d, label ? label->d : NULL, &sigma, dx->d);
 }

@@ -72,9 +72,9 @@ def L():
         l.mlctx_compute.argtypes = [vp]
         l.mlctx_sync.argtypes = [vp]
         l.unet_params_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(UnetParams)]
-        l.unet_denoise_init.argtypes = [ctypes.POINTER(UnetState), vp, ctypes.POINTER(UnetParams), ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+        l.unet_denoise_init_n.argtypes = [ctypes.POINTER(UnetState), vp, ctypes.POINTER(UnetParams), ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
         l.unet_denoise_build.argtypes = [ctypes.POINTER(UnetState)]
-        l.unet_denoise_run.argtypes = [ctypes.POINTER(UnetState), FP, FP, FP, FP, FP]
+        l.unet_denoise_run_n.argtypes = [ctypes.POINTER(UnetState), FP, FP, FP, FP, FP]
         l.unet_sigma_to_t.restype = c_f
         l.unet_sigma_to_t.argtypes = [ctypes.POINTER(UnetParams), c_f]
         l.unet_t_to_sigma.restype = c_f
@@ -164,13 +164,13 @@ def unet_params(model):
 
 
 class Unet:
-    """unet_denoise_init / unet_denoise_run (src/unet.c:336-498) with a batch dimension."""
+    """unet_denoise_init_n / unet_denoise_run_n (src/unet.c:336-498) with a batch dimension."""
 
     def __init__(self, model, lw, lh, n_batch, stream=None, flags=0, seed=1234, synth=True):
         self.P = unet_params(model)
         self.ctx = MLCtx(stream, flags)
         self.S = UnetState()
-        check1(L().unet_denoise_init(ctypes.byref(self.S), self.ctx.h, ctypes.byref(self.P), lw, lh, n_batch), "unet_denoise_init")
+        check1(L().unet_denoise_init_n(ctypes.byref(self.S), self.ctx.h, ctypes.byref(self.P), lw, lh, n_batch), "unet_denoise_init_n")
         check1(L().unet_denoise_build(ctypes.byref(self.S)), "unet_denoise_build")
         if synth:
             self.ctx.params_synth(seed)
@@ -182,7 +182,7 @@ class Unet:
         sigma = np.ascontiguousarray(sigma, np.float32)
         lab = np.ascontiguousarray(label, np.float32) if label is not None else None
         dx = np.empty_like(x)
-        check1(L().unet_denoise_run(ctypes.byref(self.S), fptr(x), fptr(cond), fptr(lab), fptr(sigma), fptr(dx)), "unet_denoise_run")
+        check1(L().unet_denoise_run_n(ctypes.byref(self.S), fptr(x), fptr(cond), fptr(lab), fptr(sigma), fptr(dx)), "unet_denoise_run_n")
         return dx
 
 

@@ -240,7 +240,7 @@ def test_lora_merge_matches_prepatched_checkpoint(lib, tmp_path):
     LC.write_checkpoint(base, "tiny", "F16")
     rng = np.random.default_rng(4)
     rank, alpha, mult = 4, 2.0, 0.75
-    targets = ["unet.in.2.1.transf.0.attn1.q_proj", "unet.in.2.1.transf.0.attn2.k_proj", "unet.out.1.1.transf.0.ff.net.2",
+    targets = ["unet.in.1.1.transf.0.attn1.q_proj", "unet.in.3.1.transf.0.attn2.k_proj", "unet.out.1.1.transf.0.ff.net.2",
                "clip.text.encoder.layers.1.attn.v_proj", "clip.text.encoder.layers.0.mlp.fc1"]
     params = {k: (f16, shape) for k, f16, shape in LC.model_params("tiny")}
     tensors = load_file(base)

@@ -326,9 +326,11 @@ def test_tae_encoder_vs_oracle():
 
 def test_vae_tiling_decode_and_encode_vs_oracle():
     """MLIS_OPT_VAE_TILE (src/vae.c:245-300,333-391): overlapping tiles of tile_px + margins through tile-sized plans, interiors
-    pasted in the reference's order.  192x256 image / 24x32 latent with 64-px tiles: 3x2 (decode: latent tiles 24x24) tiles."""
+    pasted in the reference's order.  256x256 image / 32x32 latent with 64-px tiles: latent tiles of 24x24 at offsets {0, 8}
+    (decode), image tiles of 192x192 at offsets {0, 64} (encode).  (A dimension that one tile covers completely while the other
+    is tiled keeps its last margin unwritten in the reference, src/vae.c:368-382: both dimensions are tiled here.)"""
     from mlimgsynth_amd import engine
-    W, H = 256, 192
+    W, H = 256, 256
     g = engine.Generator("tiny", W, H, 1, n_step=2)
     g.set_vae_tile(64)
     rng = np.random.default_rng(12)
@@ -342,7 +344,7 @@ def test_vae_tiling_decode_and_encode_vs_oracle():
     e_t, e_full = rel(img - 0.5, ref_t - 0.5), rel(img - 0.5, ref_full - 0.5)
     print("tiled decode vs oracle tiled", e_t, "vs oracle untiled", e_full)
     assert e_t < 4e-3 and e_full > 2 * e_t            # it really is the tiled result (tile borders differ from the full decode)
-    # encode: image tiles 192x192 (64 + 2*64 margin) over a 256x192 image -> 2x1 tiles
+    # encode: image tiles 192x192 (64 + 2*64 margin) over the 256x256 image -> 2x2 tiles
     src = rng.random((1, 3, H, W)).astype(F)
     g.seed([5])
     lat = g.encode(src, sample=True)
