@@ -86,34 +86,33 @@ def main():
     g = engine.Generator(model, width, height, B, n_step=a.denoise_steps, cfg_scale=a.cfg, s_ancestral=1.0,
                          use_tae=a.tae, use_hipgraph=bool(hipgraph), weight_seed=1234)
     P = g.P
-    n_ctx, adm = P.n_ctx, P.ch_adm_in
     tc = text.TextConditioner(model, width, height, seed=1234) if rank == 0 else None
     prompt = np.random.default_rng(7).integers(0, 49405 if model in ("sd1", "sdxl") else 900, 8).astype(np.int32)
-    # conditioning buffers on the device (broadcast targets): cond, uncond [77][n_ctx], label, unlabel [adm]
-    d_cond = torch.zeros(2, 77, n_ctx, dtype=torch.float32, device=dev)
-    d_label = torch.zeros(2, max(adm, 1), dtype=torch.float32, device=dev)
-    lat_shape = (B, 4, height // 8, width // 8)
-    d_lat = torch.empty(lat_shape, dtype=torch.float32, device=dev)
+    pp = prompt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    Lh = engine._proto2()
+    Lh.mlis_amd_textcond_apply.argtypes = [_lib.vp, _lib.vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+    Lh.mlis_amd_bcast_cond.argtypes = [_lib.vp, _lib.vp, ctypes.c_int]
+    Lh.mlis_amd_gather_results.argtypes = [_lib.vp, _lib.vp, ctypes.c_int, _lib.vp]
+    comm, d_gather = None, None
+    if world > 1:
+        # the library owns the data-path collectives (RCCL over xGMI through its C entry points); torch.distributed only carries
+        # the 128-byte unique id to the other ranks and provides the barrier / max-over-ranks of the timing contract
+        comm = mdist.rccl_comm(L, world, rank, dev)
+        d_gather = _lib.DeviceBuffer(world * B * 4 * (height // 8) * (width // 8) * 4)
     info = g.info()
     t_setup = time.time() - t_setup
 
-    def one_step(idx):
-        if rank == 0:
-            cond, label, ncond, nlabel = tc.encode_pair(prompt, ())
-            d_cond.copy_(torch.from_numpy(np.stack([cond, ncond])), non_blocking=False)
-            if adm:
-                d_label.copy_(torch.from_numpy(np.stack([label, nlabel])), non_blocking=False)
-        if world > 1:
-            mdist.broadcast_conditioning(d_cond, d_label if adm else None, 0)   # RCCL over xGMI: ~1.3 MB once per batch
-            torch.cuda.synchronize()
-        cp, lp = d_cond.data_ptr(), d_label.data_ptr()
-        g.set_cond_device(cp, lp if adm else None, cp + 77 * n_ctx * 4, (lp + max(adm, 1) * 4) if adm else None)
+    def one_step(idx, want_images=False):
+        if rank == 0:     # CLIP towers are resident on rank 0: encode prompt + (empty) negative prompt straight into the plan's inputs
+            engine.check1(Lh.mlis_amd_textcond_apply(tc.h, g.h, pp, prompt.size, None, 0), "mlis_amd_textcond_apply")
+        if world > 1:     # ~1.3 MB once per batch, device to device, no host hop
+            engine.check1(Lh.mlis_amd_bcast_cond(g.h, comm, 0), "mlis_amd_bcast_cond")
         # independent Philox stream per image (seed 42 + global image index): results do not depend on the GPU count
-        g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=False)   # syncs its stream
-        if world > 1:
-            _lib.check(L.mlsd_memcpy(_lib.vp(d_lat.data_ptr()), _lib.vp(g.latent_ptr()), ctypes.c_size_t(d_lat.numel() * 4), 2, None))
-            _lib.check(L.mlsd_device_sync())
-            mdist.gather_latents(d_lat, 0)             # 256 KiB per image
+        out = g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=want_images)   # syncs its stream
+        if world > 1:     # all-gather of the final latents: 256 KiB per SDXL image
+            engine.check1(Lh.mlis_amd_gather_results(g.h, comm, 0, _lib.vp(d_gather.ptr)), "mlis_amd_gather_results")
+            engine.check1(Lh.mlis_amd_sync(g.h), "mlis_amd_sync")
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -122,7 +121,7 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        one_step(-1 - i)
+        one_step(a.steps + i)           # non-negative image indices (negative ones wrapped in the uint64 seeds)
     fence()
     t0 = time.perf_counter()
     unet_ms = 0.0
@@ -132,10 +131,18 @@ def main():
     fence()
     el = time.perf_counter() - t0
     el = mdist.max_over_ranks(el, dev)
+    # PCIe-inclusive variant (the reference's mlis_generate ends with host pixels): one more step that also copies the fp32
+    # images of this rank to host memory; reported beside `value`, never as `value`
+    fence()
+    t1 = time.perf_counter()
+    one_step(a.steps + a.warmup, want_images=True)
+    fence()
+    el_host = mdist.max_over_ranks(time.perf_counter() - t1, dev)
 
     if rank != 0:
         if world > 1:
             dist.barrier()
+            L.mlsd_rccl_destroy(comm)
             dist.destroy_process_group()
         return
 
@@ -156,6 +163,7 @@ def main():
         "job_tflops": round(value * flop_per_img / 1e12, 1),
         "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / (world * PEAK_MFMA_F16_TFLOPS), 4),
         "unet_eval_ms": round(unet_ms / (a.steps * a.denoise_steps), 3),
+        "images_per_s_with_d2h_of_fp32_images": round(B * world / el_host, 4),
     }
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the engine's stream, one UNet evaluation
@@ -181,7 +189,7 @@ def main():
     # HBM-side traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
     # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", f"r1_{a.workload}_b{B}_pmc_traffic.json")
+    pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{a.workload}_b{B}_pmc_traffic.json") for r_ in ("r2", "r1")) if os.path.exists(p_)), "")
     if os.path.exists(pmc):
         try:
             with open(pmc) as fh:
@@ -192,7 +200,7 @@ def main():
             pass
     # matrix-pipe utilisation of that kernel from a SQ counter pass (tools/pmc_mfma_summary.py), same provenance
     mfma_busy = None
-    pmc2 = os.path.join(ROOT, "profiles", f"r1_{a.workload}_b{B}_pmc_mfma.json")
+    pmc2 = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{a.workload}_b{B}_pmc_mfma.json") for r_ in ("r2", "r1")) if os.path.exists(p_)), "")
     if os.path.exists(pmc2):
         try:
             with open(pmc2) as fh:
@@ -248,6 +256,7 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        L.mlsd_rccl_destroy(comm)
         dist.destroy_process_group()
 
 

@@ -135,6 +135,7 @@ int sdxl_label_build(const float* feat, int n_feat, int width, int height, float
  * (src/mlimgsynth.c:1423-1468,1501-1563).  model "sd1" | "sdxl" | "tiny" | "tinyxl"; tokens without BOS/EOS/padding.
  * cond [77][n_ctx]; label [n_label] (SDXL: pooled bigG feature || size embeddings; NULL for SD1). */
 typedef struct MLIS_AmdTextCond MLIS_AmdTextCond;
+typedef struct MLIS_AmdCtx MLIS_AmdCtx;          /* the generation driver, below */
 MLIS_AmdTextCond* mlis_amd_textcond_create(const char* model, int width, int height, uint64_t weight_seed, void* stream);
 /* clip_skip 0 = model default; defer_weights != 0: the towers are built without weights, the caller loads them into
  * mlis_amd_textcond_ctx(T, i) for i < mlis_amd_textcond_n_towers(T) (mlctx_tstore_load / mlctx_param_set) */
@@ -152,6 +153,9 @@ int mlis_amd_textcond_encode(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok
 /* prompt + negative prompt; an EMPTY negative prompt on SDXL zeroes ncond (uncond_empty_zero, :1702-1703) */
 int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg,
 	float* cond, float* label, float* ncond, float* nlabel);
+
+/* prompt + negative prompt encoded and written into an engine's conditioning inputs in one call (launchers; rank 0 of a multi-GPU job) */
+int mlis_amd_textcond_apply(MLIS_AmdTextCond* T, MLIS_AmdCtx* E, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg);
 
 /* ---- CLIP BPE tokenizer (host).  Replaces clip_tokenize and helpers, src/clip.c:59-278 (public entry
  * mlis_text_tokenize, include/mlimgsynth.h); pinned by the 14 KATs of src/test_text_tokenize_clip.c:41-66.
@@ -223,8 +227,6 @@ int  dnsamp_schedule(const UnetParams* P, int n_step, int sched, float f_t_ini, 
 void dnsamp_ancestral(float s1, float s2, float eta, float* s_down, float* s_up);
 
 /* ---------------------------------------------------------------- generation driver (mlis_generate slice) */
-typedef struct MLIS_AmdCtx MLIS_AmdCtx;
-
 typedef struct {
 	const char* model;       /* "sd1" | "sdxl" | "tiny" | "tinyxl" */
 	int width, height;       /* pixels (multiple of 8) */
@@ -288,6 +290,10 @@ int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* i
 int mlis_amd_sync(MLIS_AmdCtx* S);                                          /* wait for the engine's stream */
 void* mlis_amd_latent_device(MLIS_AmdCtx* S);                               /* fp32 NCHW [n][4][lh][lw] */
 void* mlis_amd_image_device(MLIS_AmdCtx* S);                                /* fp32 NCHW [n][3][h][w] */
+/* multi-GPU exchange steps over RCCL (mlsd_rccl_* communicator): conditioning broadcast from `root` into the plan's inputs;
+ * all-gather of the final latents (what 0) or images (what 1) into recv_dev [world][per-rank bytes] */
+int mlis_amd_bcast_cond(MLIS_AmdCtx* S, void* comm, int root);
+int mlis_amd_gather_results(MLIS_AmdCtx* S, void* comm, int what, void* recv_dev);
 int mlis_amd_info(MLIS_AmdCtx* S, double* unet_flops_per_eval, double* decode_flops, int* unet_ops, size_t* mem_params,
 	size_t* mem_compute);
 MLCtx* mlis_amd_unet_ctx(MLIS_AmdCtx* S);

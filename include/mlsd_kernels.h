@@ -57,6 +57,16 @@ int mlsd_capture_end(void* stream, void** graph_exec);
 int mlsd_graph_launch(void* graph_exec, void* stream);
 int mlsd_graph_destroy(void* graph_exec);
 
+/* ---------------------------------------------------------------- RCCL over xGMI (librccl opened lazily with dlopen)
+ * The two exchange steps of the image-sharded multi-GPU job: broadcast of the conditioning, gather of the
+ * results.  One communicator per process (one process per GPU); the 128-byte unique id from rank 0 reaches the other ranks by
+ * any side channel of the launcher.  Buffers are device pointers; calls are asynchronous on `stream`. */
+int mlsd_rccl_unique_id(void* out128);
+int mlsd_rccl_init(void** comm, int world, int rank, const void* id128);
+int mlsd_rccl_destroy(void* comm);
+int mlsd_rccl_bcast(void* comm, void* buf, size_t nbytes, int root, void* stream);
+int mlsd_rccl_all_gather(void* comm, const void* send, void* recv, size_t nbytes_per_rank, void* stream);
+
 /* ---------------------------------------------------------------- GEMM / implicit-GEMM conv
  * Replaces ggml_mul_mat (+ggml_add bias) at src/mlblock_nn.c:22-25 and ggml_conv_2d (+bias) at
  * src/mlblock_nn.c:44-50, with the adjacent elementwise nodes fused as epilogues:

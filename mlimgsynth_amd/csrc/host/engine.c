@@ -234,6 +234,26 @@ MLB_API int mlis_amd_set_cond_device(MLIS_AmdCtx* S, const void* cond, const voi
 	return set_cond(S, cond, label, uncond, unlabel, 2);
 }
 
+/* ------------------------------------------------------------------ multi-GPU (one process per GPU, images sharded over ranks)
+ * rank `root` has set the conditioning (mlis_amd_set_cond*); every rank then calls this: the plan's conditioning inputs are
+ * broadcast in place over RCCL (cond [N][77][n_ctx] + label [N][adm] fp32: 1.3 MB for SDXL), no host hop, no per-step collective */
+MLB_API int mlis_amd_bcast_cond(MLIS_AmdCtx* S, void* comm, int root)
+{
+	const UnetParams *P = &S->unet_p;
+	if (mlsd_rccl_bcast(comm, mlctx_input_device_ptr(S->unet.t_c), (size_t)S->N*77*P->n_ctx*4, root, S->stream)) return -1;
+	if (P->ch_adm_in && mlsd_rccl_bcast(comm, mlctx_input_device_ptr(S->unet.t_l), (size_t)S->N*P->ch_adm_in*4, root, S->stream)) return -1;
+	S->cond_set = 1;
+	return 1;
+}
+
+/* all-gather of the final latents (what = 0: [B][4][lh][lw] fp32 per rank) or decoded images (what = 1: [B][3][H][W] fp32) into
+ * `recv_dev` (world x the per-rank size, rank-major) on every rank; asynchronous on the engine's stream */
+MLB_API int mlis_amd_gather_results(MLIS_AmdCtx* S, void* comm, int what, void* recv_dev)
+{
+	const size_t nb = what ? (size_t)S->B*3*S->c.width*S->c.height*4 : (size_t)S->B*4*S->hw*4;
+	return mlsd_rccl_all_gather(comm, what ? (void*)S->d_img : (void*)S->d_x, recv_dev, nb, S->stream) ? -1 : 1;
+}
+
 MLB_API int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds)
 {
 	for (int b=0;b<S->B;++b) { S->rng[b].seed = seeds[b]; S->rng[b].offset = 0; }

@@ -149,3 +149,17 @@ MLB_API int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* to
 	if (T->xl && n_neg == 0) memset(ncond, 0, sizeof(float) * 77 * (size_t)T->n_ctx);
 	return 1;
 }
+
+/* mlis_text_cond_encode for prompt + negative prompt straight into an engine's conditioning inputs (no caller-side staging):
+ * what mlis_generate does between :1688 and :1707, as one library call for launchers (bench.py, multi-GPU rank 0) */
+MLB_API int mlis_amd_textcond_apply(MLIS_AmdTextCond* T, MLIS_AmdCtx* E, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg)
+{
+	const size_t nc = (size_t)77 * T->n_ctx, nl = (size_t)(T->n_label > 0 ? T->n_label : 1);
+	float *buf = (float*)malloc(sizeof(float) * 2 * (nc + nl));
+	if (!buf) return mlsd_set_error(-1, "textcond_apply: out of memory");
+	float *cond = buf, *ncond = buf + nc, *label = buf + 2*nc, *nlabel = label + nl;
+	int r = mlis_amd_textcond_encode_pair(T, toks, n_tok, neg, n_neg, cond, T->n_label ? label : NULL, ncond, T->n_label ? nlabel : NULL);
+	if (r > 0) r = mlis_amd_set_cond(E, cond, T->n_label ? label : NULL, ncond, T->n_label ? nlabel : NULL);
+	free(buf);
+	return r;
+}

@@ -338,14 +338,18 @@ MLB_API int mlts_lora_apply(MLTStore* D, const MLTStore* L, float mult, int wtyp
 		else if (la) { float *t = entry_to_f32(la, 0); scale = t[0] / n_inner; free(t); }
 		scale *= mult;
 		float *down = entry_to_f32(ld, r16), *up = entry_to_f32(lu, r16), *w = entry_to_f32(dst, r16);
-		for (int64_t o=0;o<n1;++o) {
-			float *wr = w + o*n0;
+		float *delta = (float*)malloc(sizeof(float) * (size_t)n0);
+		for (int64_t o=0;o<n1;++o) {       /* up.down accumulated in fp32, scaled, then added to W (src/lora.c:57-61) */
+			for (int64_t c=0;c<n0;++c) delta[c] = 0;
 			for (int64_t r=0;r<n_inner;++r) {
-				const float u = up[o*n_inner + r] * scale;
+				const float u = up[o*n_inner + r];
 				const float *dr = down + r*n0;
-				for (int64_t c=0;c<n0;++c) wr[c] += u * dr[c];
+				for (int64_t c=0;c<n0;++c) delta[c] += u * dr[c];
 			}
+			float *wr = w + o*n0;
+			for (int64_t c=0;c<n0;++c) wr[c] += delta[c] * scale;
 		}
+		free(delta);
 		free(down); free(up);
 		if (!isfinite(w[0])) { free(w); return mlsd_set_error(-1, "NaN in LoRA result"); }
 		void *buf;

@@ -42,3 +42,22 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def rccl_comm(L, world, rank, device):
+    """RCCL communicator of the C library (mlsd_rccl_*): rank 0 draws the 128-byte unique id, torch.distributed carries it to the
+    other ranks (the only thing it is used for on the data path), every rank joins.  Returns the opaque communicator handle."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        rc = L.mlsd_rccl_unique_id(buf)
+        assert rc == 0, L.mlsd_last_error()
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if dist.get_backend() == "nccl":
+        t = t.to(device)
+    dist.broadcast(t, 0)
+    raw = bytes(t.cpu().numpy().tobytes())
+    comm = ctypes.c_void_p()
+    rc = L.mlsd_rccl_init(ctypes.byref(comm), world, rank, raw)
+    assert rc == 0, L.mlsd_last_error()
+    return comm

@@ -215,3 +215,51 @@ def test_host_rng_and_schedule_match_oracle():
     ref = np.empty(64, np.float32)
     O.L().orc_schedule(20, 1, 1.0, 0.0, O.fptr(ref))
     assert np.array_equal(sig, ref[:21])
+
+
+def test_rccl_entry_points_single_rank():
+    """The library's RCCL path (mlsd_rccl_*, mlis_amd_bcast_cond, mlis_amd_gather_results) on a 1-rank communicator: the same
+    calls the multi-GPU launcher makes, runnable on the 1-GPU box (the N > 1 behaviour is covered by tests/test_dist_cpu.py
+    for the sharding logic and by the driver's 8-GPU run for the collectives themselves)."""
+    from mlimgsynth_amd import _lib, engine
+    L = _lib.lib()
+    Lh = engine._proto2()
+    Lh.mlis_amd_bcast_cond.argtypes = [_lib.vp, _lib.vp, ctypes.c_int]
+    Lh.mlis_amd_gather_results.argtypes = [_lib.vp, _lib.vp, ctypes.c_int, _lib.vp]
+    uid = ctypes.create_string_buffer(128)
+    assert L.mlsd_rccl_unique_id(uid) == 0, _lib.last_error()
+    comm = ctypes.c_void_p()
+    assert L.mlsd_rccl_init(ctypes.byref(comm), 1, 0, uid.raw) == 0, _lib.last_error()
+    U = O.unet_params("tiny")
+    rng = np.random.default_rng(2)
+    cond, unc = rng.standard_normal((77, U.n_ctx)).astype(np.float32), rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    g = engine.Generator("tiny", 64, 64, 2, n_step=3)
+    g.set_cond(cond, None, unc, None)
+    ref, _ = g.generate([5, 6], want_images=False)
+    engine.check1(Lh.mlis_amd_bcast_cond(g.h, comm, 0), "bcast")          # root == self: conditioning unchanged
+    got, _ = g.generate([5, 6], want_images=False)
+    assert np.array_equal(got, ref)
+    recv = _lib.DeviceBuffer(ref.nbytes)
+    engine.check1(Lh.mlis_amd_gather_results(g.h, comm, 0, _lib.vp(recv.ptr)), "gather")
+    engine.check1(Lh.mlis_amd_sync(g.h), "sync")
+    assert np.array_equal(recv.download(ref.shape, np.float32), ref)
+    assert L.mlsd_rccl_destroy(comm) == 0
+    g.destroy()
+
+
+def test_bench_two_gpu_smoke_when_available():
+    """the world > 1 branch of bench.py on real GPUs (skipped on the 1-GPU boxes of this pool)"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--workload", "tiny", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0

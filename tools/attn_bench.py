@@ -1,7 +1,8 @@
 """Attention micro-benchmark on the SDXL self-attention shapes (diagnostics / PMC target)."""
 import ctypes, sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mlimgsynth_amd import _lib, kernels
 L = _lib.lib(); vp = _lib.vp
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
