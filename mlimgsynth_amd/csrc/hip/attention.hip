@@ -36,6 +36,14 @@ __device__ __forceinline__ float max3f(float a, float b, float c)
     return r;
 }
 
+// two fp32 FMAs per VALU issue slot (v_pk_fma_f32): the softmax argument s*sc - m*sc of two scores at once
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp2_pair(float a, float b, float sc, float msc)
+{
+    const f32x2 t = __builtin_elementwise_fma(f32x2{a, b}, f32x2{sc, sc}, f32x2{msc, msc});
+    return f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
+}
+
 struct AttnP {
     const _Float16 *q, *k, *v;
     _Float16* o;
@@ -45,7 +53,7 @@ struct AttnP {
     float sc;  // 1/sqrt(d_head) * log2(e)
 };
 
-template <int DH>
+template <int DH, bool VSUM>
 // waves_per_eu caps the occupancy the register allocator aims for: left free it chose 4 waves/SIMD (128 VGPRs) and
 // spilled the K/V staging registers to scratch inside the loop
 __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, (DH <= 80 ? 3 : 1)))) void attn_kernel(const AttnP p)
@@ -109,6 +117,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     f32x16 lacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    f32x2 vsum = {0.f, 0.f};                        // VSUM: per-lane partial row sums on the VALU (v_pk_add_f32), see attn64x2_kernel
     const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 
     int nt = (p.Tk + 63) / 64;
@@ -229,8 +238,11 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
             const float m_new = max3f(m_run, mx, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
             m_run = m_new;
+            if constexpr (VSUM) vsum *= alpha;
+            else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+                for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+            }
 #pragma unroll
             for (int d = 0; d < NDV; ++d)
 #pragma unroll
@@ -240,8 +252,11 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                sacc[kt][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], p.sc, msc));   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 r = exp2_pair(sacc[kt][e], sacc[kt][e + 1], p.sc, msc);
+                sacc[kt][e] = r.x; sacc[kt][e + 1] = r.y;
+                if constexpr (VSUM) vsum += r;
+            }
 
         // ---- O^T += V^T . P   (P = S^T accumulators as B operand, permuted k order)
 #pragma unroll
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sacc[kt][8 * s + j];
                 const int kb = 32 * kt + 16 * s;
-                lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);   // row sums on the matrix pipe (ones . P)
+                if constexpr (!VSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);   // row sums on the matrix pipe (ones . P)
 #pragma unroll
                 for (int d = 0; d < NDV; ++d) {
                     const unsigned char* a0 = Vs + (kb + tr_row) * VSTR + (32 * d + tr_col) * 2;
@@ -272,7 +287,9 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     }
 
     // ---- epilogue: O = O^T / l, heads merged.  oacc[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
-    const float inv = 1.0f / lacc[0];
+    float l_fin = lacc[0];
+    if constexpr (VSUM) { const float l = vsum.x + vsum.y; l_fin = l + __shfl_xor(l, 32, 64); }
+    const float inv = 1.0f / l_fin;
     if (qrow < p.Tq) {
         _Float16* og = p.o + (long)b * p.bso + (long)qrow * p.ldo + (long)head * DH;
 #pragma unroll
@@ -300,6 +317,9 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
 //     K image: slot = chunk ^ ((row >> 1) & 7)        conflict-free ds_read_b128 of 32 rows x one chunk (as the GEMM tiles)
 //     V image: slot = chunk ^ (((row >> 1) & 1) << 2) conflict-free ds_read_b64_tr_b16 of 4 rows x 64 B per 32-lane half
 //   Keys past Tk (77-token cross attention) are clamped duplicates of the last key and masked.
+//   VSUM: row sums l on the VALU (v_pk_add_f32 over the fp32 P, one cross-half exchange at the end) instead of the ones . P
+//   MFMAs (8 of the 40 MFMAs per tile): trades 256 matrix-pipe cycles for 128 VALU cycles per tile.
+template <bool VSUM>
 __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
 {
     constexpr int DH = 64, RB = 128;                 // bytes per K/V row
@@ -356,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
     f32x16 ls0, ls1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ls0[e] = 0.f; ls1[e] = 0.f; }
+    f32x2 vs0 = {0.f, 0.f}, vs1 = {0.f, 0.f};         // VSUM: per-lane partial row sums (two interleaved chains)
     const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 
     stage(0, 0);
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
         // ---- online softmax of one query block (registers + one cross-half exchange; deferred rescale, see attn_kernel)
         // max as v_max3_f32 through asm: a plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand
         // (100 v_max for 64 scores, MI355X_MICROARCH.md); row sums run on the matrix pipe (P . ones, below) instead of 64 v_add
-        auto softmax = [&](f32x16& sa, f32x16& sb_, float& m_run, f32x16* oacc, f32x16& lacc) __attribute__((always_inline)) {
+        auto softmax = [&](f32x16& sa, f32x16& sb_, float& m_run, f32x16* oacc, f32x16& lacc, f32x2& vsum) __attribute__((always_inline)) {
             float mx = max3f(sa[0], sa[1], sb_[0]);
             mx = max3f(mx, sb_[1], sa[2]);
 #pragma unroll
@@ -416,18 +437,22 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                if constexpr (VSUM) vsum *= alpha;
+                else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+                    for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+                }
             }
             const float msc = -m_run * p.sc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sa[e] = __builtin_amdgcn_exp2f(fmaf(sa[e], p.sc, msc));
-                sb_[e] = __builtin_amdgcn_exp2f(fmaf(sb_[e], p.sc, msc));
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 ra = exp2_pair(sa[e], sa[e + 1], p.sc, msc), rb = exp2_pair(sb_[e], sb_[e + 1], p.sc, msc);
+                sa[e] = ra.x; sa[e + 1] = ra.y; sb_[e] = rb.x; sb_[e + 1] = rb.y;
+                if constexpr (VSUM) vsum += ra + rb;
             }
         };
-        softmax(s00, s01, m0, o0, ls0);
-        softmax(s10, s11, m1, o1, ls1);
+        softmax(s00, s01, m0, o0, ls0, vs0);
+        softmax(s10, s11, m1, o1, ls1, vs1);
 
         // ---- O^T += V^T . P for both query blocks: 16 transposed V reads feed 16 MFMAs
         const bool sub1 = kv0 + 32 < p.Tk;            // the second 32-key sub-tile holds at least one key (wave-uniform)
@@ -442,8 +467,10 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { pf0[j] = (_Float16)pa[8 * sx + j]; pf1[j] = (_Float16)pb[8 * sx + j]; }
                 const int kb = 32 * kt + 16 * sx;
-                ls0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf0, ls0, 0, 0, 0);
-                ls1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf1, ls1, 0, 0, 0);
+                if constexpr (!VSUM) {
+                    ls0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf0, ls0, 0, 0, 0);
+                    ls1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf1, ls1, 0, 0, 0);
+                }
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const unsigned char* a0 = Vs + (kb + tr_row) * RB + (((4 * d + tr_c) ^ vswz) << 4) + tr_b;
@@ -472,14 +499,21 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
                 *reinterpret_cast<f16x4*>(og + 32 * d + 8 * eg + 4 * lh) = h;
             }
     };
-    store(o0, ls0[0], 0);
-    store(o1, ls1[0], 1);
+    if constexpr (VSUM) {
+        const float l0 = vs0.x + vs0.y, l1 = vs1.x + vs1.y;         // a lane half holds the keys 4*lh + {0..3} + 8j of every 32
+        store(o0, l0 + __shfl_xor(l0, 32, 64), 0);
+        store(o1, l1 + __shfl_xor(l1, 32, 64), 1);
+    } else {
+        store(o0, ls0[0], 0);
+        store(o1, ls1[0], 1);
+    }
 }
 
 int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_kernel
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
+int g_attn_vsum = 0;        // 1 = attn64x2_kernel<VSUM>: row sums on the VALU
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
 {
@@ -491,7 +525,8 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
     p.sc = (float)(1.4426950408889634 / sqrt(64.0));
     p.nq = a->Tq / 256; p.G = a->n_head * a->n_batch;
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
-    hipLaunchKernelGGL(attn64x2_kernel, grid, dim3(256), 0, st, p);
+    if (g_attn_vsum) hipLaunchKernelGGL(attn64x2_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn64x2_kernel<false>, grid, dim3(256), 0, st, p);
     return mlsd_check_launch("attn64x2_kernel");
 }
 
@@ -506,7 +541,8 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
     p.sc = (float)(1.4426950408889634 / sqrt((double)a->d_head));
     p.nq = (a->Tq + 127) / 128; p.G = a->n_head * a->n_batch;
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
-    hipLaunchKernelGGL(attn_kernel<DH>, grid, dim3(256), 0, st, p);
+    if (g_attn_vsum) hipLaunchKernelGGL((attn_kernel<DH, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_kernel<DH, false>), grid, dim3(256), 0, st, p);
     return mlsd_check_launch("attn_kernel");
 }
 
@@ -536,5 +572,6 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
 
 MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
+MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 
 }  // extern "C"

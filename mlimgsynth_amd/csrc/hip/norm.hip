@@ -313,6 +313,53 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = tid; c < cols; c += 256) yr[c] = (_Float16)(__expf((xr[c] - mx) * scale) * inv);
 }
 
+// rows of up to 16384 columns (the VAE mid block at 1024^2: 16384 keys) are held in registers: ONE fp32 read and one fp16
+// write per score instead of three reads (the materialised score matrix is 1 GiB per image, so this pass is HBM-bound)
+constexpr int SM_MAXQ = 16;   // float4 per thread
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ in, long ld_in, _Float16* __restrict__ out,
+                                                               long ld_out, int rows, int cols, float scale)
+{
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = in + (long)row * ld_in;
+    const int Q = cols >> 2;
+    float4 v[SM_MAXQ];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXQ; ++i) {
+        const int q = tid + i * 256;
+        if (q < Q) {
+            v[i] = *reinterpret_cast<const float4*>(xr + 4 * q);
+            mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        } else v[i] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXQ; ++i) {
+        // same expression as the three-pass kernel: exp((x - max) * scale); lanes past the row hold -3e38 -> exp = 0
+        v[i].x = __expf((v[i].x - mx) * scale); v[i].y = __expf((v[i].y - mx) * scale);
+        v[i].z = __expf((v[i].z - mx) * scale); v[i].w = __expf((v[i].w - mx) * scale);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    _Float16* yr = out + (long)row * ld_out;
+#pragma unroll
+    for (int i = 0; i < SM_MAXQ; ++i) {
+        const int q = tid + i * 256;
+        if (q < Q) {
+            f16x4 h = {(_Float16)(v[i].x * inv), (_Float16)(v[i].y * inv), (_Float16)(v[i].z * inv), (_Float16)(v[i].w * inv)};
+            *reinterpret_cast<f16x4*>(yr + 4 * q) = h;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -360,6 +407,11 @@ MLSD_API int mlsd_softmax_rows(const float* in, int64_t ld_in, void* out, int64_
                                float scale, void* stream)
 {
     if (rows <= 0) return 0;
+    if (!(cols & 3) && cols <= 4 * 256 * SM_MAXQ && !(ld_in & 3) && !(ld_out & 3) && !((uintptr_t)in & 15) && !((uintptr_t)out & 7)) {
+        hipLaunchKernelGGL(softmax_rows_reg_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, (_Float16*)out,
+                           (long)ld_out, rows, cols, scale);
+        return mlsd_check_launch("softmax_rows_reg_kernel");
+    }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, (_Float16*)out,
                        (long)ld_out, rows, cols, scale);
     return mlsd_check_launch("softmax_rows_kernel");

@@ -713,6 +713,13 @@ MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flo
 			const mlsd_attn_args *a = &op->u.attn;
 			snprintf(buf, sizeof(buf), "%s b%d h%d d%d %dx%d", op->label, a->n_batch, a->n_head, a->d_head, a->Tq, a->Tk);
 			*label = buf;
+		} else if (op->kind == OP_LN && (C->flags & MLB_F_OPSHAPES)) {
+			snprintf(buf, sizeof(buf), "%s %dx%d", op->label, op->u.ln.rows, op->u.ln.d);
+			*label = buf;
+		} else if (op->kind == OP_GN && (C->flags & MLB_F_OPSHAPES)) {
+			const mlsd_gn_args *a = &op->u.gn;
+			snprintf(buf, sizeof(buf), "%s n%d hw%d c%d+%d%s", op->label, a->n_img, a->HW, a->C1, a->C2, a->raw16 ? " +raw" : "");
+			*label = buf;
 		} else *label = op->label;
 	}
 	if (flops) *flops = C->ops[i].flops;

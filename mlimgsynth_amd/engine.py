@@ -261,9 +261,9 @@ def schedule(model, n_step, sched=1, f_t_ini=1.0, f_t_end=0.0):
 class Decoder:
     """sdvae_decode / sdtae_decode (src/vae.c:318-411, src/tae.c:117-136), batched, no tiling."""
 
-    def __init__(self, model, lw, lh, n_batch, tae=False, stream=None, seed=1234):
+    def __init__(self, model, lw, lh, n_batch, tae=False, stream=None, seed=1234, flags=0):
         l = _proto2()
-        self.ctx = MLCtx(stream)
+        self.ctx = MLCtx(stream, flags)
         self.tae, self.lw, self.lh, self.n = tae, lw, lh, n_batch
         self.t_lat = vp()
         if tae:

@@ -579,6 +579,16 @@ def test_layout_and_small_ops(K):
     _lib.check(L.mlsd_softmax_rows(vp(dsx.ptr), ctypes.c_int64(300), vp(dso.ptr), ctypes.c_int64(304), 5, 300, ctypes.c_float(0.25), None))
     e = np.exp((s - s.max(1, keepdims=True)) * 0.25)
     assert np.abs(dso.download((5, 304), np.float16)[:, :300].astype(np.float32) - e / e.sum(1, keepdims=True)).max() < 1e-3
+    # ... the three-pass fallback (columns not a multiple of 4) and a full-width register row (16384 keys: VAE mid block at 1024^2)
+    for rows_, cols_ in ((3, 301), (2, 16384), (2, 4100)):
+        s = rng.standard_normal((rows_, cols_)).astype(np.float32) * 4
+        ldo = (cols_ + 7) // 8 * 8
+        dsx, dso = dev(_lib, s), _lib.DeviceBuffer(rows_ * ldo * 2)
+        _lib.check(L.mlsd_softmax_rows(vp(dsx.ptr), ctypes.c_int64(cols_), vp(dso.ptr), ctypes.c_int64(ldo), rows_, cols_, ctypes.c_float(0.25), None))
+        e = np.exp((s.astype(np.float64) - s.max(1, keepdims=True)) * 0.25)
+        want = e / e.sum(1, keepdims=True)
+        got = dso.download((rows_, ldo), np.float16)[:, :cols_].astype(np.float64)
+        assert np.abs(got - want).max() < 1e-3 and abs(got.sum(1) - 1).max() < 2e-3, (rows_, cols_)
     # CLIP embedding gather + position add
     tok = rng.integers(0, 50, (2, 7)).astype(np.int32)
     tw, pw = f16r(rng.standard_normal((50, 16))), rng.standard_normal((7, 16)).astype(np.float32)

@@ -17,12 +17,17 @@ for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)
     do = _lib.DeviceBuffer(nb * tq * D * 2)
     a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
                          bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
-    for old in (1, 0):
-        L.mlsd_attention_force_old(old)
+    L.mlsd_attention_x2_min_tq(256)                      # let the 64-rows/wave kernel take every shape here
+    outs = {}
+    for name, old, vsum in (("general kernel ", 1, 0), ("general + vsum ", 1, 1), ("64-rows/wave   ", 0, 0), ("64-rows + vsum ", 0, 1)):
+        L.mlsd_attention_force_old(old); L.mlsd_attention_vsum(vsum)
         for _ in range(3): kernels.attention(a)
         L.mlsd_event_record(ev[0], None)
         for _ in range(reps): kernels.attention(a)
         L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
         ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
         t = ms.value / reps
-        print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {'general kernel ' if old else '64-rows/wave   '}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s")
+        outs[name] = do.download((nb, tq, D), np.float16).astype(np.float32)
+        err = np.abs(outs[name] - outs["general kernel "]).max()
+        print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s   max|diff vs general| {err:.2e}")
+L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(0); L.mlsd_attention_x2_min_tq(2048)
