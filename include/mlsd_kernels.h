@@ -127,6 +127,7 @@ int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
 /* timing-only builds of the main loop (needs -DMLSD_GEMM_EXPERIMENTS; otherwise ignored) */
 void mlsd_gemm_set_debug(int d);
+void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */
 size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit);
 
 /* ---------------------------------------------------------------- fused attention

@@ -513,7 +513,7 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
-int g_attn_vsum = 0;        // 1 = attn64x2_kernel<VSUM>: row sums on the VALU
+int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
 {

@@ -70,6 +70,7 @@ struct GemmP {
     int kt_per;
     long ws_stride;
     int gw;    // tile-order panel width (0: row-major)
+    unsigned long long* tbuf;   // diagnostics: per-block cycle stamps of the ping-pong kernels (tools/gemm_trace.py), or null
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -562,6 +563,7 @@ int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
 }
 
 int g_gemm_dbg = 0;
+unsigned long long* g_gemm_tbuf = nullptr;   // device buffer of 8 stamps per block (mlsd_gemm_set_trace)
 int g_gemm_panel = 8;   // tile-order panel width in tiles (0: row-major)
 int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
 
@@ -583,7 +585,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
-    p.dbg = g_gemm_dbg;
+    p.dbg = g_gemm_dbg; p.tbuf = nullptr;
     p.gw = g_gemm_panel;
     int kt_per;
     const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
@@ -648,7 +650,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.vec = 1;                                             // pp_eligible() checked the alignment
-    p.dbg = g_gemm_dbg; p.gw = g_gemm_panel;
+    p.dbg = g_gemm_dbg; p.gw = g_gemm_panel; p.tbuf = g_gemm_tbuf;
     p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on these tiles
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
@@ -658,7 +660,31 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_pp_kernel");
     };
-    return a->conv ? go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true>) : go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false>);
+    // the epilogue the kernel is built with (gemm_pp.hpp): the bulk launches of the UNet / VAE have no activation in the GEMM
+    int epi = PP_EPI_GENERIC;
+    if (!(g_gemm_dbg & 2) && !a->bias_m) {
+        if (a->act == MLSD_ACT_NONE) {
+            if (a->C16 && !a->C32 && !a->resid) epi = PP_EPI_F16;
+            else if (a->C32 && !a->C16) epi = a->resid ? PP_EPI_F32_RES : PP_EPI_F32;
+        } else if (a->act == MLSD_ACT_GEGLU && BN == 256 && a->C16 && !a->C32 && !a->resid && !a->conv) epi = PP_EPI_GEGLU16;
+    }
+    if (a->conv) {
+        switch (epi) {
+        case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32>);
+        case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES>);
+        default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_GENERIC>);
+        }
+    }
+    switch (epi) {
+    case PP_EPI_F16: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F16>);
+    case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32>);
+    case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES>);
+    case PP_EPI_GEGLU16:
+        if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16>);
+        break;
+    default: break;
+    }
+    return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC>);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
@@ -758,6 +784,10 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+/* diagnostics: device buffer of 8 x uint64 per block (256 blocks) that the ping-pong kernels fill with s_memtime stamps:
+ * [0] kernel entry, [1] prologue done, [2] first epilogue begins, [3] first epilogue issued, [4] last epilogue begins,
+ * [5] last epilogue issued, [6] block exit (after the final wait), [7] tiles walked; NULL switches it off */
+MLSD_API void mlsd_gemm_set_trace(void* buf) { g_gemm_tbuf = (unsigned long long*)buf; }
 
 MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 

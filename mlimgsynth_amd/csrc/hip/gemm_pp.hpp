@@ -64,7 +64,11 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
 // tiles ahead, must enter output tile ti+1 while the MFMAs are in tile ti): the per-phase staging code is LDS-DMA
 // instructions on running row pointers and nothing else (out-of-range rows are CLAMPED to the last valid row instead of
 // zero-filled: their products land in output rows/columns that are never stored).
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV>
+// EPI selects the epilogue the kernel is BUILT with (launch_pp picks it from the arguments): 0 = generic (any activation,
+// per-row bias, any output combination: decided per element at run time), 1 = fp16 out, 2 = fp32 out, 3 = fp32 out + fp32
+// residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
+enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4 };
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -306,9 +310,88 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             }
         }
     };
+    // FAST VARIANTS.  The generic rows above decide per element what to do (null checks on per-lane pointers, the activation
+    // kind, act-before/after-residual): ~30 instructions and 5 taken branches per 4 outputs, measured at 7 us per 256x256
+    // tile WITHOUT its stores (tools/gemm_ksweep.py "no-stores") -- a quarter of a K = 1280 tile.  Everything the UNet
+    // launches in bulk has no activation in the GEMM (SiLU/GELU live in the norm kernels or the GEGLU path) and no per-row
+    // bias, so those launches use a kernel BUILT with one straight-line body (template parameter EPI; a run-time choice
+    // between bodies inside one kernel cost 20-70 spilled registers in the K loop): a 4-output group is 1-2 packed adds,
+    // the conversion and the store.
+    // Residual rows are fetched PF row blocks ahead of their use (all of them on the 128-row tile: 80 registers that the
+    // main loop's fragments no longer need; two blocks = 32 registers on the 256-row tile).
+    auto epi_fast = [&](auto S32_, auto S16_, auto RES_, int wrow0, int wcol0) __attribute__((always_inline)) {
+        constexpr bool S32 = decltype(S32_)::value, S16 = decltype(S16_)::value, RES = decltype(RES_)::value;
+        constexpr int NR = 2 * RA;                               // 16-row blocks of the wave's slab: r = qa * RA + i
+        constexpr int PF = (BM == 128) ? NR : 2;
+        f32x4 rr[RES ? NR : 1][RES ? NCB : 1];
+        const float* rbase = RES ? p.resid + (long)(wrow0 + l15) * p.ldr + wcol0 + 4 * lg : nullptr;
+        auto row_of = [&](int r) __attribute__((always_inline)) { return (r / RA) * (WM / 2) + (r % RA) * 16; };
+        auto fetch = [&](int r) __attribute__((always_inline)) {
+            if constexpr (RES) {
+                const float* rp = rbase + (long)row_of(r) * p.ldr;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) rr[r][c] = *reinterpret_cast<const f32x4*>(rp + c * 16);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < PF && r < NR; ++r) fetch(r);
+        float* c32b = S32 ? p.C32 + (long)(wrow0 + l15) * p.ldc32 + wcol0 + 4 * lg : nullptr;
+        _Float16* c16b = S16 ? p.C16 + (long)(wrow0 + l15) * p.ldc16 + wcol0 + 4 * lg : nullptr;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + PF < NR) fetch(r + PF);
+            const int qa = r / RA, i = r % RA;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                f32x4 v = acc[qa][i][c] + cb[c];
+                if constexpr (RES) v += rr[r][c];
+                if constexpr (S32) *reinterpret_cast<f32x4*>(c32b + (long)row_of(r) * p.ldc32 + c * 16) = v;
+                if constexpr (S16) {
+                    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<f16x4*>(c16b + (long)row_of(r) * p.ldc16 + c * 16) = h;
+                }
+            }
+        }
+    };
+    // GEGLU with fp16 output only (the UNet's feed-forward projection): value (column blocks 0,1) and gate (2,3) of an
+    // output element sit in the same lane; straight-line as above
+    auto epi_fast_geglu = [&](int wrow0, int wcol0) __attribute__((always_inline)) {
+        if constexpr (CB0 == 2 && CB1 == 2) {
+            _Float16* c16b = p.C16 + (long)(wrow0 + l15) * p.ldc16 + (wcol0 >> 6) * 32 + 4 * lg;
+#pragma unroll
+            for (int r = 0; r < 2 * RA; ++r) {
+                const int qa = r / RA, i = r % RA;
+                _Float16* cp = c16b + (long)(qa * (WM / 2) + i * 16) * p.ldc16;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 a4 = acc[qa][i][j] + cb[j], g4 = acc[qa][i][2 + j] + cb[2 + j];
+                    f16x4 h = {(_Float16)(a4[0] * gelu_tanh_f(g4[0])), (_Float16)(a4[1] * gelu_tanh_f(g4[1])),
+                               (_Float16)(a4[2] * gelu_tanh_f(g4[2])), (_Float16)(a4[3] * gelu_tanh_f(g4[3]))};
+                    *reinterpret_cast<f16x4*>(cp + j * 16) = h;
+                }
+            }
+        }
+    };
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int wrow0 = tcur.m0 + wr * WM, wcol0 = tcur.n0 + wc * WN;
         if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % WM == 0, N % WN == 0: a wave's block is all in or all out
+        const float* rbias = p.rowbias ? p.rowbias + (long)(tcur.m0 / p.rows_per_batch) * p.ldrb : nullptr;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int n = wcol0 + c * 16 + 4 * lg;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (rbias) v += *reinterpret_cast<const f32x4*>(rbias + n);
+            cb[c] = v;
+        }
+        using std::integral_constant;
+        using T = std::true_type;
+        using F = std::false_type;
+        if constexpr (EPI == PP_EPI_F16) { epi_fast(F{}, T{}, F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32) { epi_fast(T{}, F{}, F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_RES) { epi_fast(T{}, F{}, T{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_GEGLU16) { epi_fast_geglu(wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_GENERIC) {
         if constexpr (RESBATCH) {
             if (p.resid) {
 #pragma unroll
@@ -321,16 +404,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                                 p.resid + (long)(wrow0 + qa * (WM / 2) + i * 16 + l15) * p.ldr + wcol0 + c * 16 + 4 * lg);
             }
         }
-        const float* rbias = p.rowbias ? p.rowbias + (long)(tcur.m0 / p.rows_per_batch) * p.ldrb : nullptr;
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const int n = wcol0 + c * 16 + 4 * lg;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (rbias) v += *reinterpret_cast<const f32x4*>(rbias + n);
-            cb[c] = v;
-        }
-        using std::integral_constant;
         epi_rows(integral_constant<int, 0>{}, integral_constant<int, 0>{}, wrow0, wcol0);
         epi_rows(integral_constant<int, 0>{}, integral_constant<int, 1>{}, wrow0, wcol0);
         if constexpr (RA > 2) {
@@ -343,8 +416,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             epi_rows(integral_constant<int, 1>{}, integral_constant<int, 2>{}, wrow0, wcol0);
             epi_rows(integral_constant<int, 1>{}, integral_constant<int, 3>{}, wrow0, wcol0);
         }
+        }
     };
 
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (p.tbuf && tid == 0) p.tbuf[(long)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     // ---- prologue: U1..U4 of stream position 0 and U1 of position 1 in flight; U1(0), U2(0) retired and visible
     sa[0].par = sa[1].par = sb2.par = sb3.par = 0;
     enter_A(sa[0], 0); enter_A(sa[1], 1); enter_B2(sb2); enter_B3(sb3);
@@ -353,6 +431,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1); issue_A(sa[0], 0);
     wait_vmcnt<W4>();
     __builtin_amdgcn_s_barrier();
+    stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0 from here on
 
 #define MLSD_PP_PHASE(QA, QB, LOAD_A, LOAD_B, ISSUE, WAITN)                                                  \
@@ -387,7 +466,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             // rejoin (group 0's extra barrier pairs with group 1's last one) so that all 8 waves run their
             // epilogues side by side, then group 1 drops one barrier behind again (equal barrier counts).
             if (wr == 0) __builtin_amdgcn_s_barrier();
+            if (ti == 0) stamp(2);
+            if (ti == ntile - 1) stamp(4);
             if (!(p.dbg & 1)) epilogue();
+            if (ti == 0) stamp(3);
+            if (ti == ntile - 1) stamp(5);
             zero_acc();
             kt = 0; ++ti;
             tcur = tnext;                                  // every sequence has entered tile ti by now (K >= 3 K tiles)
@@ -397,4 +480,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     }
 #undef MLSD_PP_PHASE
     wait_vmcnt<0>();                               // the tail stages (clamped rows) still target this block's LDS
+    stamp(6);
+    if (p.tbuf && tid == 0) p.tbuf[(long)blockIdx.x * 8 + 7] = ntile;
 }

@@ -30,4 +30,4 @@ for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)
         outs[name] = do.download((nb, tq, D), np.float16).astype(np.float32)
         err = np.abs(outs[name] - outs["general kernel "]).max()
         print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s   max|diff vs general| {err:.2e}")
-L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(0); L.mlsd_attention_x2_min_tq(2048)
+L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048)
