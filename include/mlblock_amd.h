@@ -24,7 +24,8 @@ extern "C" {
 typedef struct MLCtx MLCtx;
 typedef struct MLTensor MLTensor;
 
-enum { MLT_F32 = 0, MLT_F16 = 1, MLT_I32 = 26, MLT_I64 = 27, MLT_F64 = 28, MLT_BF16 = 30 };  /* ggml_type numbering (mlimgsynth.h:336-339) */
+enum { MLT_F32 = 0, MLT_F16 = 1, MLT_Q4_0 = 2, MLT_Q4_1 = 3, MLT_Q5_0 = 6, MLT_Q5_1 = 7, MLT_Q8_0 = 8, MLT_I32 = 26, MLT_I64 = 27, MLT_F64 = 28,
+       MLT_BF16 = 30 };  /* ggml_type numbering (mlimgsynth.h:336-339); the Q* block types only occur in GGUF files (dequantised on upload) */
 
 enum MLCtxFlags {           /* src/mlblock.h:29-36 */
 	MLB_F_MULTI_COMPUTE = 1,

@@ -185,7 +185,9 @@ typedef struct MLTStore MLTStore;
 typedef struct { char* name; int dtype; int n_dim; int64_t shape[4]; /* shape[0] fastest */ size_t size; const void* data; } MLTSEntry;
 /* convert_names != 0: names go through tnconv_sd, unused tensors are dropped and open_clip in_proj tensors are split into
  * q/k/v_proj views (tensor_callback_main / open_clip_attn_conv, src/mlimgsynth.c:989-1055) */
-MLTStore* mlts_open_safetensors(const char* path, int convert_names);
+MLTStore* mlts_open(const char* path, int convert_names);              /* safetensors or GGUF v2/v3, detected by content */
+MLTStore* mlts_open_safetensors(const char* path, int convert_names);  /* same (kept name) */
+int       mlts_entry_to_f32(const MLTSEntry* e, float* out, int64_t n); /* any stored type (incl. GGUF block-quantised) -> fp32 */
 void mlts_close(MLTStore* S);
 /* LoRA (src/lora.c:9-138, tensor_callback_lora src/mlimgsynth.c:1068-1092): open a kohya-named LoRA file, merge it into the
  * model store: W += (scale | alpha/rank | 1) * mult * up.down for every "<X>.lora_down.weight"; returns the number of tensors patched */

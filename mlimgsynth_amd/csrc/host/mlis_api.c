@@ -564,7 +564,7 @@ MLB_API int mlis_setup(MLIS_Ctx* S)
 			const char *m = mlts_model_identify(S->ts, &wt);
 			if (m) { if (model_type_set(S, model_from(m, strlen(m))) < 0) return MLIS_E_OPT_VALUE; }
 			else if (!(S->flags & CF_MODEL_TYPE_SET)) return api_error(S, MLIS_E_UNKNOWN, "could not detect the model type");
-			if (wt >= 0 && !(S->flags & CF_WEIGHT_TYPE_SET)) S->wtype = wt;
+			if (wt >= 0 && !(S->flags & CF_WEIGHT_TYPE_SET)) S->wtype = (wt == MLT_F32 || wt == MLT_BF16) ? wt : MLT_F16;   /* quantised GGUF weights: dequantised, kept as F16 */
 		}
 		if ((S->flags & CF_USE_TAE) && !S->synth && !str_empty(S->path_tae)) {
 			S->ts_tae = mlts_open_safetensors(S->path_tae, 0);

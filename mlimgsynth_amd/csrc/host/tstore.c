@@ -6,8 +6,12 @@
  *   mlctx_tstore_load    src/mlblock.c:266-292  every plan parameter is looked up by name, the element COUNT is
  *                        checked (not the shape, :243: that is how SDXL's Linear proj_in/out load into 1x1 convs),
  *                        converted to the parameter's type and uploaded (here: repacked to the device layout).
- * The file is mmap'd read-only; nothing is copied until a parameter is uploaded.  safetensors only (the GGUF reader of
- * tensorstore_gguf.c is not on this round's path).
+ * The file is mmap'd read-only; nothing is copied until a parameter is uploaded.  Two containers, detected by content like
+ * tstore_read's format probe: safetensors (JSON header) and GGUF v2/v3 (tensorstore_gguf.c:171-235: key/value metadata is
+ * skipped, tensor data starts at the next multiple of 32 after the tensor table).  GGUF tensors may be block-quantised
+ * (Q8_0, Q4_0, Q4_1, Q5_0, Q5_1): the reference converts them through ggml's type traits (tensorstore.c:187-225), which
+ * are not in the reference tree; the block layouts below restate ggml's published formats (ggml-common.h block_q*),
+ * dequantised to fp32 on upload (the device weight type is F16 either way).  PARITY of the quantised types is UNPINNED.
  */
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
@@ -99,6 +103,48 @@ static size_t dtype_size(int t)
 	return 0;
 }
 
+/* block-quantised ggml types: elements per block / bytes per block (0 = not a block type) */
+static int qblock_elems(int t) { return (t == MLT_Q8_0 || t == MLT_Q4_0 || t == MLT_Q4_1 || t == MLT_Q5_0 || t == MLT_Q5_1) ? 32 : 0; }
+static size_t qblock_bytes(int t)
+{
+	switch (t) { case MLT_Q8_0: return 34; case MLT_Q4_0: return 18; case MLT_Q4_1: return 20; case MLT_Q5_0: return 22; case MLT_Q5_1: return 24; }
+	return 0;
+}
+/* bytes of n elements of type t, or 0 if n is not a whole number of blocks / the type is unknown */
+static size_t dtype_bytes(int t, int64_t n)
+{
+	const int qb = qblock_elems(t);
+	if (qb) return (n % qb) ? 0 : (size_t)(n / qb) * qblock_bytes(t);
+	return (size_t)n * dtype_size(t);
+}
+
+/* ggml block formats (restated from the published layout; little-endian, fp16 scales):
+ *   Q8_0: d, q[32] int8                      x[j] = d*q[j]
+ *   Q4_0: d, qs[16]                          x[j] = d*((qs[j]&15) - 8),  x[j+16] = d*((qs[j]>>4) - 8)
+ *   Q4_1: d, m, qs[16]                       x[j] = d*(qs[j]&15) + m,    x[j+16] = d*(qs[j]>>4) + m
+ *   Q5_0: d, qh[4], qs[16]                   5th bit of x[j] = bit j of qh, of x[j+16] = bit j+16;   x = d*(q - 16)
+ *   Q5_1: d, m, qh[4], qs[16]                x = d*q + m */
+static void dequant_blocks(int t, const unsigned char* b, int64_t n, float* o)
+{
+	const size_t bs = qblock_bytes(t);
+	for (int64_t ib=0; ib<n/32; ++ib, b+=bs, o+=32) {
+		uint16_t dh; memcpy(&dh, b, 2);
+		const float d = mlb_f16_bits_to_f32(dh);
+		if (t == MLT_Q8_0) { const signed char *q = (const signed char*)b + 2; for (int j=0;j<32;++j) o[j] = d * (float)q[j]; continue; }
+		float m = 0.f; const unsigned char *q = b + 2;
+		if (t == MLT_Q4_1 || t == MLT_Q5_1) { uint16_t mh; memcpy(&mh, q, 2); m = mlb_f16_bits_to_f32(mh); q += 2; }
+		uint32_t qh = 0;
+		if (t == MLT_Q5_0 || t == MLT_Q5_1) { memcpy(&qh, q, 4); q += 4; }
+		for (int j=0;j<16;++j) {
+			int x0 = q[j] & 15, x1 = q[j] >> 4;
+			if (t == MLT_Q5_0 || t == MLT_Q5_1) { x0 |= (int)((qh >> j) & 1) << 4; x1 |= (int)((qh >> (j + 16)) & 1) << 4; }
+			if (t == MLT_Q4_0) { o[j] = d * (float)(x0 - 8); o[j+16] = d * (float)(x1 - 8); }
+			else if (t == MLT_Q5_0) { o[j] = d * (float)(x0 - 16); o[j+16] = d * (float)(x1 - 16); }
+			else { o[j] = d * (float)x0 + m; o[j+16] = d * (float)x1 + m; }
+		}
+	}
+}
+
 static MLTSEntry* ts_add(MLTStore* S, const char* name, const MLTSEntry* src)
 {
 	for (int i=0;i<S->n;++i) if (!strcmp(S->e[i].name, name)) {   /* tstore_tensor_add replaces an existing key */
@@ -146,30 +192,46 @@ static int qkv_split(MLTStore* S, const MLTSEntry* e, const char* newname)
 	return 1;
 }
 
-static MLTStore* open_safetensors(const char* path, int mode);
+static MLTStore* open_store(const char* path, int mode);
 
-MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names) { return open_safetensors(path, convert_names ? 1 : 0); }
+/* mlts_open: safetensors or GGUF, by content.  convert_names = 1 applies tnconv_sd + the open_clip QKV split
+ * (tensor_callback_main); 0 keeps the file's names (internal dotted names: synthetic checkpoints, tests). */
+MLB_API MLTStore* mlts_open(const char* path, int convert_names) { return open_store(path, convert_names ? 1 : 0); }
+MLB_API MLTStore* mlts_open_safetensors(const char* path, int convert_names) { return open_store(path, convert_names ? 1 : 0); }
 /* LoRA file (kohya naming): "lora_" prefix stripped, then tnconv_sd; an unmatched "*.lora_down.weight" is an error, other
  * unmatched tensors are dropped (tensor_callback_lora, src/mlimgsynth.c:1068-1092) */
-MLB_API MLTStore* mlts_open_lora(const char* path) { return open_safetensors(path, 2); }
+MLB_API MLTStore* mlts_open_lora(const char* path) { return open_store(path, 2); }
 
-static MLTStore* open_safetensors(const char* path, int convert_names)
+/* one tensor of the file: renamed / split / dropped according to `mode` (0 raw, 1 model, 2 LoRA); <0 on error */
+static int add_file_tensor(MLTStore* S, const char* name, const MLTSEntry* e, int mode)
 {
-	int fd = open(path, O_RDONLY);
-	if (fd < 0) { mlsd_set_error(-6 /* MLIS_E_FILE_NOT_FOUND */, "could not open '%s'", path); return NULL; }
-	struct stat st;
-	if (fstat(fd, &st) < 0 || st.st_size < 10) { close(fd); mlsd_set_error(-1, "'%s': not a safetensors file", path); return NULL; }
-	void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-	close(fd);
-	if (map == MAP_FAILED) { mlsd_set_error(-1, "mmap of '%s' failed", path); return NULL; }
-	MLTStore *S = (MLTStore*)calloc(1, sizeof(*S));
-	S->map = map; S->map_size = (size_t)st.st_size;
-	const unsigned char *b = (const unsigned char*)map;
+	if (!mode) { ts_add(S, name, e); return 1; }
+	char conv[512];
+	const char *nm = name;
+	if (mode == 2) {                                                     /* tensor_callback_lora :1068-1092 */
+		if (strncmp(name, "lora_", 5)) { S->n_unused++; return 0; }
+		nm = name + 5;
+	}
+	const int r = tnconv_sd(nm, conv, sizeof(conv));                     /* tensor_callback_main :1033-1055 */
+	if (r < 0) return -1;
+	if (mode == 2 && r == 0) {
+		const size_t l = strlen(nm);
+		if (l >= 17 && !strcmp(nm + l - 17, ".lora_down.weight")) return mlsd_set_error(-1, "unmatched lora tensor: %s", name);
+		S->n_unused++; return 0;
+	}
+	if (r == 0) { S->n_unused++; return 0; }
+	if (r == TNCONV_R_QKV_PROJ) return qkv_split(S, e, conv) < 0 ? -1 : 1;
+	ts_add(S, conv, e);
+	return 1;
+}
+
+static int parse_safetensors(MLTStore* S, const char* path, int mode)
+{
+	const unsigned char *b = (const unsigned char*)S->map;
 	uint64_t hlen = 0;
 	for (int i=7;i>=0;--i) hlen = (hlen << 8) | b[i];
-	if (hlen < 2 || hlen > 0xffffff || 8 + hlen > S->map_size || b[8] != '{') {   /* tstore_detect_safet :300-308 */
-		mlsd_set_error(-1, "'%s': invalid safetensors header", path); mlts_close(S); return NULL;
-	}
+	if (hlen < 2 || hlen > 0xffffff || 8 + hlen > S->map_size || b[8] != '{')   /* tstore_detect_safet :300-308 */
+		return mlsd_set_error(-1, "'%s': invalid safetensors header", path);
 	const char *data0 = (const char*)b + 8 + hlen;
 	const size_t data_size = S->map_size - 8 - hlen;
 	JCur c = { (const char*)b + 8, (const char*)b + 8 + hlen };
@@ -193,42 +255,123 @@ static MLTStore* open_safetensors(const char* path, int convert_names)
 				if (!j_eat(&c, '[') || j_uint(&c, &off0) < 0 || !j_eat(&c, ',') || j_uint(&c, &off1) < 0 || !j_eat(&c, ']')) goto bad;
 				have |= 4;
 			}
-			else { mlsd_set_error(-1, "safetensors tensor '%s': unknown key '%s'", name, key); goto fail; }
+			else return mlsd_set_error(-1, "safetensors tensor '%s': unknown key '%s'", name, key);
 		} while (j_eat(&c, ','));
 		if (!j_eat(&c, '}') || have != 7) goto bad;
-		if (nd > 4) { mlsd_set_error(-1, "safetensors tensor '%s': %d dimensions", name, nd); goto fail; }
-		if (off1 < off0 || off1 > data_size) { mlsd_set_error(-1, "safetensors tensor '%s': invalid offsets", name); goto fail; }
+		if (nd > 4) return mlsd_set_error(-1, "safetensors tensor '%s': %d dimensions", name, nd);
+		if (off1 < off0 || off1 > data_size) return mlsd_set_error(-1, "safetensors tensor '%s': invalid offsets", name);
 		e.n_dim = nd;
 		for (int i=0;i<4;++i) e.shape[i] = 1;
 		for (int i=0;i<nd;++i) e.shape[i] = (int64_t)shp[nd-1-i];           /* reversed: shape[0] fastest (ggml order) */
 		e.size = off1 - off0; e.data = data0 + off0;
 		const size_t want = (size_t)(e.shape[0]*e.shape[1]*e.shape[2]*e.shape[3]) * dtype_size(e.dtype);
-		if (e.dtype < 0 || want != e.size) { mlsd_set_error(-1, "safetensors tensor '%s': invalid size %zu for dtype/shape", name, e.size); goto fail; }
-		if (!convert_names) { ts_add(S, name, &e); continue; }
-		char conv[512];
-		const char *nm = name;
-		if (convert_names == 2) {                                            /* tensor_callback_lora :1068-1092 */
-			if (strncmp(name, "lora_", 5)) { S->n_unused++; continue; }
-			nm = name + 5;
-		}
-		const int r = tnconv_sd(nm, conv, sizeof(conv));                     /* tensor_callback_main :1033-1055 */
-		if (r < 0) goto fail;
-		if (convert_names == 2 && r == 0) {
-			const size_t l = strlen(nm);
-			if (l >= 17 && !strcmp(nm + l - 17, ".lora_down.weight")) { mlsd_set_error(-1, "unmatched lora tensor: %s", name); goto fail; }
-			S->n_unused++; continue;
-		}
-		if (r == 0) { S->n_unused++; continue; }
-		if (r == TNCONV_R_QKV_PROJ) { if (qkv_split(S, &e, conv) < 0) goto fail; continue; }
-		ts_add(S, conv, &e);
+		if (e.dtype < 0 || want != e.size) return mlsd_set_error(-1, "safetensors tensor '%s': invalid size %zu for dtype/shape", name, e.size);
+		if (add_file_tensor(S, name, &e, mode) < 0) return -1;
 	} while (j_eat(&c, ','));
 	if (!j_eat(&c, '}')) goto bad;
-	return S;
+	return 1;
 bad:
-	mlsd_set_error(-1, "'%s': malformed safetensors header near byte %ld", path, (long)(c.p - (const char*)b));
-fail:
-	mlts_close(S);
-	return NULL;
+	return mlsd_set_error(-1, "'%s': malformed safetensors header near byte %ld", path, (long)(c.p - (const char*)b));
+}
+
+/* ---- GGUF v2 / v3 (tensorstore_gguf.c).  Cursor over the mapped file; every read is bounds-checked. */
+typedef struct { const unsigned char *p, *end; } GCur;
+static int g_take(GCur* c, void* out, size_t n) { if ((size_t)(c->end - c->p) < n) return -1; memcpy(out, c->p, n); c->p += n; return 0; }
+static int g_skip(GCur* c, uint64_t n) { if ((uint64_t)(c->end - c->p) < n) return -1; c->p += n; return 0; }
+static int g_string(GCur* c, char* out, size_t max, uint64_t limit)     /* u64 length + bytes; out may be NULL (skipped) */
+{
+	uint64_t len;
+	if (g_take(c, &len, 8) < 0 || len > limit) return -1;
+	if (out) { if (len >= max || (uint64_t)(c->end - c->p) < len) return -1; memcpy(out, c->p, len); out[len] = 0; }
+	return g_skip(c, len);
+}
+/* metadata value sizes by gguf type id: u8 i8 u16 i16 u32 i32 f32 bool string array u64 i64 f64 (gguf_meta_type_to_any :22-37) */
+static const int k_gguf_scalar_size[13] = { 1, 1, 2, 2, 4, 4, 4, 1, -1, -2, 8, 8, 8 };
+static int g_skip_value(GCur* c, uint32_t type, int depth)
+{
+	if (type >= 13) return -1;
+	const int sz = k_gguf_scalar_size[type];
+	if (sz > 0) return g_skip(c, (uint64_t)sz);
+	if (sz == -1) return g_string(c, NULL, 0, 0xffffff);
+	if (depth) return -1;                                                /* arrays of arrays: TS_E_METADATA in the reference */
+	uint32_t at; uint64_t len;
+	if (g_take(c, &at, 4) < 0 || g_take(c, &len, 8) < 0 || len > 0xffffff || at >= 13) return -1;
+	if (k_gguf_scalar_size[at] > 0) return g_skip(c, len * (uint64_t)k_gguf_scalar_size[at]);
+	if (k_gguf_scalar_size[at] != -1) return -1;
+	for (uint64_t i=0;i<len;++i) if (g_string(c, NULL, 0, 0xffff) < 0) return -1;
+	return 0;
+}
+
+static int gguf_dtype(uint32_t t)
+{
+	switch (t) {
+	case 0: return MLT_F32; case 1: return MLT_F16; case 30: return MLT_BF16; case 28: return MLT_F64; case 26: return MLT_I32; case 27: return MLT_I64;
+	case 8: return MLT_Q8_0; case 2: return MLT_Q4_0; case 3: return MLT_Q4_1; case 6: return MLT_Q5_0; case 7: return MLT_Q5_1;
+	}
+	return -1;
+}
+
+static int parse_gguf(MLTStore* S, const char* path, int mode)
+{
+	GCur c = { (const unsigned char*)S->map, (const unsigned char*)S->map + S->map_size };
+	uint32_t magic, version; uint64_t n_tensor, n_meta;
+	if (g_take(&c, &magic, 4) < 0 || g_take(&c, &version, 4) < 0) return mlsd_set_error(-1, "'%s': truncated GGUF header", path);
+	if (version != 2 && version != 3) return mlsd_set_error(-1, "'%s': unsupported GGUF version %u", path, version);   /* :190-191 */
+	if (g_take(&c, &n_tensor, 8) < 0 || g_take(&c, &n_meta, 8) < 0 || n_tensor > 65535 || n_meta > 65535)
+		return mlsd_set_error(-1, "'%s': invalid GGUF counts", path);
+	char name[512];
+	for (uint64_t i=0;i<n_meta;++i) {
+		uint32_t type;
+		if (g_string(&c, name, sizeof(name), 256) < 0 || !name[0] || g_take(&c, &type, 4) < 0 || g_skip_value(&c, type, 0) < 0)
+			return mlsd_set_error(-1, "'%s': malformed GGUF metadata entry %llu", path, (unsigned long long)i);
+	}
+	/* the tensor table comes first, the data offset is only known after it: collect, then resolve */
+	MLTSEntry *tmp = (MLTSEntry*)calloc((size_t)n_tensor + 1, sizeof(MLTSEntry));
+	char (*names)[512] = (char(*)[512])malloc(((size_t)n_tensor + 1) * 512);
+	int R = 1;
+	for (uint64_t i=0;i<n_tensor && R>0;++i) {
+		uint32_t nd, gt; uint64_t dims[4] = {1,1,1,1}, off;
+		if (g_string(&c, names[i], 512, 256) < 0 || !names[i][0] || g_take(&c, &nd, 4) < 0 || nd > 4 || g_take(&c, dims, 8*(size_t)nd) < 0 ||
+		    g_take(&c, &gt, 4) < 0 || g_take(&c, &off, 8) < 0) { R = mlsd_set_error(-1, "'%s': malformed GGUF tensor entry %llu", path, (unsigned long long)i); break; }
+		for (int d=0;d<4;++d) if (dims[d] > 0xffffff) R = mlsd_set_error(-1, "gguf tensor '%s': dimension overflow", names[i]);
+		MLTSEntry *e = &tmp[i];
+		e->dtype = gguf_dtype(gt);
+		if (e->dtype < 0) { R = mlsd_set_error(-1, "gguf tensor '%s': unknown tensor type %u", names[i], gt); break; }
+		e->n_dim = (int)nd;
+		for (int d=0;d<4;++d) e->shape[d] = (int64_t)dims[d];                /* GGUF dims are already fastest-first */
+		e->size = dtype_bytes(e->dtype, e->shape[0]*e->shape[1]*e->shape[2]*e->shape[3]);
+		if (!e->size && dims[0]*dims[1]*dims[2]*dims[3] != 0) { R = mlsd_set_error(-1, "gguf tensor '%s': %lld elements are not whole blocks", names[i], (long long)(dims[0]*dims[1]*dims[2]*dims[3])); break; }
+		e->data = (const void*)(uintptr_t)off;                             /* relative for now */
+	}
+	if (R > 0) {
+		uint64_t base = (uint64_t)(c.p - (const unsigned char*)S->map);
+		base += (32 - base % 32) % 32;                                     /* gguf_align: GGUF_ALIGNMENT 32, general.alignment is not consulted */
+		for (uint64_t i=0;i<n_tensor && R>0;++i) {
+			MLTSEntry *e = &tmp[i];
+			const uint64_t off = base + (uint64_t)(uintptr_t)e->data;
+			if (off > S->map_size || e->size > S->map_size - off) { R = mlsd_set_error(-1, "gguf tensor '%s': data outside the file", names[i]); break; }
+			e->data = (const char*)S->map + off;
+			if (add_file_tensor(S, names[i], e, mode) < 0) R = -1;
+		}
+	}
+	free(names); free(tmp);
+	return R;
+}
+
+static MLTStore* open_store(const char* path, int mode)
+{
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) { mlsd_set_error(-6 /* MLIS_E_FILE_NOT_FOUND */, "could not open '%s'", path); return NULL; }
+	struct stat st;
+	if (fstat(fd, &st) < 0 || st.st_size < 10) { close(fd); mlsd_set_error(-1, "'%s': not a safetensors / GGUF file", path); return NULL; }
+	void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (map == MAP_FAILED) { mlsd_set_error(-1, "mmap of '%s' failed", path); return NULL; }
+	MLTStore *S = (MLTStore*)calloc(1, sizeof(*S));
+	S->map = map; S->map_size = (size_t)st.st_size;
+	const int r = !memcmp(map, "GGUF", 4) ? parse_gguf(S, path, mode) : parse_safetensors(S, path, mode);   /* tstore_detect_gguf :237-242 */
+	if (r < 0) { mlts_close(S); return NULL; }
+	return S;
 }
 
 MLB_API int mlts_count(const MLTStore* S) { return S ? S->n : 0; }
@@ -277,7 +420,14 @@ MLB_API int mlctx_tstore_load(MLCtx* C, const MLTStore* S)
 		if (cnt != ne[0]*ne[1]*ne[2]*ne[3])                                              /* tstore_tensor_read :243 */
 			return mlsd_set_error(-1, "tensor '%s': %lld elements in the file, %lld expected", key, (long long)cnt,
 				(long long)(ne[0]*ne[1]*ne[2]*ne[3]));
-		if (mlctx_param_set(C, key, e->dtype, e->data, cnt) < 0) return -1;
+		if (qblock_elems(e->dtype)) {                                                    /* data_convert through to_float, tensorstore.c:205-214 */
+			float *f = (float*)malloc(sizeof(float) * (size_t)cnt);
+			dequant_blocks(e->dtype, (const unsigned char*)e->data, cnt, f);
+			const int r = mlctx_param_set(C, key, MLT_F32, f, cnt);
+			free(f);
+			if (r < 0) return -1;
+		}
+		else if (mlctx_param_set(C, key, e->dtype, e->data, cnt) < 0) return -1;
 		n++;
 	}
 	return n;
@@ -294,6 +444,11 @@ static float* entry_to_f32(const MLTSEntry* e, int round_f16)
 {
 	const int64_t n = e->shape[0]*e->shape[1]*e->shape[2]*e->shape[3];
 	float *o = (float*)malloc(sizeof(float) * (size_t)(n ? n : 1));
+	if (qblock_elems(e->dtype)) {
+		dequant_blocks(e->dtype, (const unsigned char*)e->data, n, o);
+		if (round_f16) for (int64_t i=0;i<n;++i) o[i] = f16_to_f32_(mlb_f32_to_f16_bits(o[i]));
+		return o;
+	}
 	for (int64_t i=0;i<n;++i) {
 		float v;
 		switch (e->dtype) {
@@ -305,6 +460,17 @@ static float* entry_to_f32(const MLTSEntry* e, int round_f16)
 		o[i] = round_f16 ? f16_to_f32_(mlb_f32_to_f16_bits(v)) : v;
 	}
 	return o;
+}
+
+/* tstore_tensor_data_get with conversion to F32 (tensorstore.c:256-323): n = element count of the entry */
+MLB_API int mlts_entry_to_f32(const MLTSEntry* e, float* out, int64_t n)
+{
+	if (!e || !out || n != e->shape[0]*e->shape[1]*e->shape[2]*e->shape[3]) return mlsd_set_error(-1, "mlts_entry_to_f32: bad arguments");
+	if (e->dtype == MLT_I32 || e->dtype == MLT_I64) return mlsd_set_error(-1, "mlts_entry_to_f32: integer tensor '%s'", e->name);
+	float *f = entry_to_f32(e, 0);
+	memcpy(out, f, sizeof(float) * (size_t)n);
+	free(f);
+	return 1;
 }
 
 MLB_API int mlts_lora_apply(MLTStore* D, const MLTStore* L, float mult, int wtype)

@@ -130,6 +130,32 @@ def test_checkpoint_file_with_external_names_equals_synthetic(lib, tmp_path, dty
     m.close(); m2.close()
 
 
+def test_checkpoint_gguf_container_equals_safetensors(lib, tmp_path):
+    """f1, GGUF container (tensorstore_gguf.c): the same checkpoint as .gguf with F16 tensors generates bit-identically; with the
+    attention projections block-quantised (Q8_0, dequantised on upload) the latent stays within the quantisation noise."""
+    import gguf_io as G
+    from safetensors.numpy import load_file
+    st = str(tmp_path / "tinyxl.safetensors")
+    LC.write_checkpoint(st, "tinyxl", "F16")
+    src = load_file(st)
+    plain = [(k, v.astype(np.float32), "F32" if v.dtype == np.float32 else "F16") for k, v in src.items()]
+    quant = [(k, v, "Q8_0" if (kind == "F16" and v.ndim == 2 and v.shape[1] % 32 == 0 and "attn" in k and "in_proj" not in k) else kind) for k, v, kind in plain]
+    assert sum(1 for _, _, kind in quant if kind == "Q8_0") > 10
+    G.write(str(tmp_path / "plain.gguf"), plain, [("general.architecture", G.T_STR, "sdxl")])
+    G.write(str(tmp_path / "q8.gguf"), quant, [("general.architecture", G.T_STR, "sdxl")], version=2)
+    lat = {}
+    for name in ("tinyxl.safetensors", "plain.gguf", "q8.gguf"):
+        m = F.Mlis(lib)
+        m.set("model_type", "tinyxl")
+        setup_tiny(m, model=str(tmp_path / name), steps=4)
+        m.generate()
+        lat[name] = m.tensor(F.TENSOR["LATENT"])
+        m.close()
+    assert np.array_equal(lat["plain.gguf"], lat["tinyxl.safetensors"])
+    r = rel(lat["q8.gguf"], lat["tinyxl.safetensors"])
+    assert 0 < r < 5e-2, r
+
+
 def test_checkpoint_sdxl_style_with_fused_open_clip_attention(lib, tmp_path):
     path = str(tmp_path / "tinyxl.safetensors")
     LC.write_checkpoint(path, "tinyxl", "F16")

@@ -148,3 +148,122 @@ def test_malformed_files_fail_loudly(L, tmp_path):
     assert "malformed" in _lib.last_error() or "invalid" in _lib.last_error()
     assert not L.mlts_open_safetensors(str(tmp_path / "missing.safetensors").encode(), 1)
     assert "could not open" in _lib.last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------- GGUF
+def _gguf_api(L):
+    L.mlts_open.restype = ctypes.c_void_p
+    L.mlts_open.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.mlts_entry_to_f32.argtypes = [ctypes.POINTER(TSEntry), ctypes.POINTER(ctypes.c_float), ctypes.c_int64]
+    return L
+
+
+def _entry_f32(L, e):
+    n = int(np.prod([e.contents.shape[i] for i in range(4)]))
+    out = np.empty(n, np.float32)
+    assert L.mlts_entry_to_f32(e, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n) == 1
+    return out
+
+
+@pytest.mark.parametrize("version", [2, 3])
+def test_gguf_index_metadata_and_every_tensor_type(L, tmp_path, version):
+    """GGUF v2/v3 container (src/ccompute/tensorstore_gguf.c:171-235): metadata of every value type is skipped, tensor
+    dims are fastest-first, data starts at the next multiple of 32 after the tensor table; F32/F16/BF16 and the block types
+    Q8_0/Q4_0/Q4_1/Q5_0/Q5_1 convert to fp32 by the published block formulas (expected values computed by the test's own
+    quantiser from the integer codes it wrote)."""
+    import gguf_io as G
+    _gguf_api(L)
+    rng = np.random.default_rng(version)
+    tensors = [("a.f32", rng.standard_normal((3, 5)).astype(np.float32), "F32"),
+               ("b.f16", rng.standard_normal((2, 3, 3, 4)).astype(np.float32), "F16"),
+               ("c.bf16", rng.standard_normal((7,)).astype(np.float32) * 100, "BF16")]
+    for kind in ("Q8_0", "Q4_0", "Q4_1", "Q5_0", "Q5_1"):
+        tensors.append((f"w.{kind.lower()}", rng.standard_normal((6, 64)).astype(np.float32) * rng.uniform(0.1, 3), kind))
+    tensors.append(("z.zero", np.zeros((2, 32), np.float32), "Q4_0"))
+    meta = [("general.architecture", G.T_STR, "sd"), ("general.alignment", G.T_U32, 32), ("x.u8", G.T_U8, 7), ("x.i8", G.T_I8, -3),
+            ("x.u16", G.T_U16, 65000), ("x.i16", G.T_I16, -300), ("x.i32", G.T_I32, -70000), ("x.f32", G.T_F32, 1.5), ("x.bool", G.T_BOOL, 1),
+            ("x.u64", G.T_U64, 2 ** 40), ("x.i64", G.T_I64, -2 ** 40), ("x.f64", G.T_F64, 2.25),
+            ("x.arr_i32", G.T_ARR, (G.T_I32, [1, 2, 3])), ("x.arr_str", G.T_ARR, (G.T_STR, ["ab", "", "cde"])), ("x.arr_empty", G.T_ARR, (G.T_F32, []))]
+    path = str(tmp_path / f"t{version}.gguf")
+    expect = G.write(path, tensors, meta, version)
+    S = L.mlts_open(path.encode(), 0)
+    assert S, L.mlsd_last_error()
+    assert L.mlts_count(S) == len(tensors)
+    for name, arr, kind in tensors:
+        e = L.mlts_find(S, name.encode())
+        assert e and e.contents.dtype == G.GGML[kind] and e.contents.n_dim == arr.ndim
+        assert [e.contents.shape[i] for i in range(4)] == (list(arr.shape[::-1]) + [1, 1, 1, 1])[:4]
+        got = _entry_f32(L, e).reshape(arr.shape)
+        assert np.array_equal(got, expect[name]), name                                   # bit-exact: fp16 scale x small integer (+ fp16 min) in fp32
+        if kind.startswith("Q"):
+            step = np.abs(arr).max() / {"Q8_0": 127, "Q4_0": 7, "Q4_1": 7.5, "Q5_0": 15, "Q5_1": 15.5}[kind]
+            assert np.abs(got - arr).max() <= 1.01 * step + 1e-3 * np.abs(arr).max(), kind   # and the codes do describe the data
+    L.mlts_close(S)
+
+
+def test_gguf_checkpoint_loads_like_safetensors(L, tmp_path):
+    """the same tiny checkpoint as safetensors and as GGUF (checkpoint-side names, fused open_clip in_proj, F16 + Q8_0 linear
+    weights): same index after name conversion + QKV split; the plan loads from it in the dry runtime"""
+    import gguf_io as G
+    from safetensors.numpy import load_file
+    from mlimgsynth_amd import _lib, engine
+    _gguf_api(L)
+    st = str(tmp_path / "m.safetensors")
+    LC.write_checkpoint(st, "tinyxl", "F16")
+    src = load_file(st)
+    tensors = []
+    for k, v in src.items():
+        kind = "F32" if v.dtype == np.float32 else "F16"
+        if kind == "F16" and v.ndim == 2 and v.shape[1] % 32 == 0 and "attn" in k and "in_proj" not in k:
+            kind = "Q8_0"
+        tensors.append((k, v.astype(np.float32), kind))
+    gg = str(tmp_path / "m.gguf")
+    expect = G.write(gg, tensors, [("general.architecture", G.T_STR, "sdxl")])
+    A, B = L.mlts_open(st.encode(), 1), L.mlts_open(gg.encode(), 1)
+    assert A and B, L.mlsd_last_error()
+    assert L.mlts_count(A) == L.mlts_count(B)
+    nq = 0
+    for i in range(L.mlts_count(A)):
+        ea = L.mlts_at(A, i)
+        eb = L.mlts_find(B, ea.contents.name)
+        assert eb and [ea.contents.shape[j] for j in range(4)] == [eb.contents.shape[j] for j in range(4)]
+        fa, fb = _entry_f32(L, ea), _entry_f32(L, eb)
+        if eb.contents.dtype == G.GGML["Q8_0"]:
+            nq += 1
+            assert np.abs(fa - fb).max() <= np.abs(fa).max() / 127 * 0.51 + 1e-6
+        else:
+            assert np.array_equal(fa, fb), ea.contents.name
+    assert nq > 10
+    L.mlsd_runtime_dry(1)
+    try:
+        un = engine.Unet("tinyxl", 8, 8, 2, synth=False)
+        assert L.mlctx_tstore_load(un.ctx.h, B) == len(LC.model_params("tinyxl")) - sum(1 for k, _, _ in LC.model_params("tinyxl") if not k.startswith("unet."))
+        un.ctx.destroy()
+    finally:
+        L.mlsd_runtime_dry(0)
+        L.mlts_close(A); L.mlts_close(B)
+
+
+def test_gguf_malformed_files_fail_loudly(L, tmp_path):
+    import struct
+    import gguf_io as G
+    _gguf_api(L)
+    good = str(tmp_path / "g.gguf")
+    G.write(good, [("a", np.ones((2, 32), np.float32), "Q8_0")], [("k", G.T_U32, 1)])
+    raw = open(good, "rb").read()
+
+    def opens(b, name):
+        p = str(tmp_path / name)
+        open(p, "wb").write(b)
+        return L.mlts_open(p.encode(), 0)
+    assert opens(raw, "ok.gguf")
+    assert not opens(raw[:4] + struct.pack("<I", 1) + raw[8:], "v1.gguf") and b"version" in L.mlsd_last_error()      # tensorstore_gguf.c:190-191
+    assert not opens(raw[:40], "trunc.gguf")
+    assert not opens(raw[:-40], "short_data.gguf") and b"outside the file" in L.mlsd_last_error()
+    bad_type = raw.replace(struct.pack("<IQ", 8, 0), struct.pack("<IQ", 99, 0))
+    assert not opens(bad_type, "type.gguf") and b"unknown tensor type" in L.mlsd_last_error()
+    # 33 elements of a block type: not whole blocks
+    p = str(tmp_path / "blk.gguf")
+    head = b"GGUF" + struct.pack("<IQQ", 3, 1, 0) + struct.pack("<Q", 1) + b"a" + struct.pack("<IQIQ", 1, 33, 8, 0)
+    open(p, "wb").write(head + b"\0" * 128)
+    assert not L.mlts_open(p.encode(), 0) and b"whole blocks" in L.mlsd_last_error()
