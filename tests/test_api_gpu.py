@@ -320,3 +320,39 @@ def test_lora_merge_matches_prepatched_checkpoint(lib, tmp_path):
     m = F.Mlis(lib)
     assert lib.mlis_option_set_str(m.ctx, b"lora", b"does_not_exist,1") == -6
     m.close()
+
+
+def test_python_wrapper_generates_like_the_ffi_table(lib):
+    """mlimgsynth_amd/mlimgsynth.py (the counterpart of python/mlimgsynth.py): the class a reference user scripts against drives
+    the same generation; the prompt goes through token ids here because the container has no CLIP vocabulary."""
+    from mlimgsynth_amd import mlimgsynth as W
+    m = F.Mlis(lib)
+    setup_tiny(m, steps=4)
+    m.generate()
+    want_img, want_lat = m.image(0), m.tensor(F.TENSOR["LATENT"])
+    m.close()
+    with W.MLImgSynth() as w:
+        w.option_set("model", "synth:tiny")
+        w.option_set(W.MLIS_OPT_IMAGE_DIM, 64, 64)
+        w.option_set(W.MLIS_OPT_STEPS, 4)
+        w.option_set("method", "euler_a")
+        w.option_set(W.MLIS_OPT_SEED, 42)
+        w.option_set(W.MLIS_OPT_CFG_SCALE, 7.0)
+        seen = []
+        w.callback_set(lambda p: seen.append((p.stage, p.step)) or 0)
+        w.setup()
+        for toks, neg in ((TOKS, 0), (NEG, 1)):
+            t = np.ascontiguousarray(toks, np.int32)
+            assert lib.mlis_amd_prompt_tokens_set(C.c_void_p(w._ctx), t.ctypes.data_as(C.POINTER(C.c_int32)), None, t.size, neg) > 0
+        w.generate()
+        img = w.image_get(0)
+        assert (img.w, img.h, img.c) == (64, 64, 3) and np.array_equal(img.numpy(), want_img)
+        lat = w.tensor_get(W.MLIS_TENSOR_LATENT)
+        assert lat.n == (8, 8, 4, 1) and np.array_equal(lat.numpy(), want_lat)
+        assert "Steps: 4" in w.infotext_get(0) and (W.MLIS_STAGE_DENOISE, 4) in seen
+        back = w.image_decode(lat)
+        assert back.n == (64, 64, 3, 1) and np.isfinite(back.numpy()).all()
+        again = w.image_encode(back)
+        assert again.n == (8, 8, 4, 1)
+        with pytest.raises(RuntimeError, match="vocabulary"):
+            w.text_tokenize("no vocabulary file in this container")
