@@ -13,12 +13,14 @@ def label(name):
         bm, bn, bk, wm, wn, conv, ns = m.groups()
         w16 = "w16" if int(wm) * int(wn) == 16 else ""
         return f"gemm<{bm}x{bn}x{bk}s{ns}{w16},{'conv' if conv == 'true' else 'linear'}>"
-    m = re.search(r"gemm_pp_kernel<(\d+), (\d+), \d+, \d+, (?:true|false), (true|false)>", name)
+    m = re.search(r"gemm_pp_kernel<(\d+), (\d+), \d+, \d+, (?:true|false), (true|false)(?:, \d+)?>", name)   # (+ the epilogue variant)
     if m:
         return f"gemm<{m.group(1)}x{m.group(2)}x64pp,{'conv' if m.group(3) == 'true' else 'linear'}>"
-    m = re.search(r"attn_kernel<(\d+)>", name)
+    m = re.search(r"attn_kernel<(\d+)(?:, (?:true|false))?>", name)
     if m:
         return f"attention<{m.group(1)}>"
+    if "attn64x2_kernel" in name:
+        return "attention<64,64 rows/wave>"
     for k in ("gn_stats", "gn_apply", "ln_kernel", "splitk_reduce", "softmax_rows"):
         if k in name:
             return k

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the committed profile summaries of one workload on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <workload> <batch> <tag>      e.g.  tools/profile_round.sh sdxl 4 r1
+#   tools/profile_round.sh <workload> <batch> <tag>      e.g.  tools/profile_round.sh sdxl 4 r2
 # Writes under gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -u
-WL=${1:-sdxl}; B=${2:-4}; TAG=${3:-r1}
+WL=${1:-sdxl}; B=${2:-4}; TAG=${3:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
@@ -31,3 +31,16 @@ find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collectio
 cd $R
 timeout 600 python3 bench.py --workload $WL --batch-per-gpu $B --kernel-table $OUT/${TAG}_${WL}_b${B}_unet_eval_kernel_table.txt > $OUT/${TAG}_${WL}_b${B}_bench.json 2> $OUT/bench_$WL.log < /dev/null
 tail -1 $OUT/${TAG}_${WL}_b${B}_bench.json
+# per-SHAPE tables (UNet evaluation and VAE / TAE decode) and, for sdxl, the phase stamps of the single-round GEMMs
+case $WL in sdxl) M=sdxl; LAT=128;; sd15) M=sd1; LAT=64;; *) M=$WL; LAT=8;; esac
+timeout 300 python3 tools/shape_table.py $M $LAT $((2*B)) unet > $OUT/${TAG}_${WL}_b${B}_unet_eval_shape_table.txt 2>> $OUT/bench_$WL.log
+timeout 300 python3 tools/shape_table.py $M $LAT $B vae > $OUT/${TAG}_${WL}_b${B}_vae_decode_shape_table.txt 2>> $OUT/bench_$WL.log
+timeout 300 python3 tools/shape_table.py $M $LAT $B tae > $OUT/${TAG}_${WL}_b${B}_tae_decode_shape_table.txt 2>> $OUT/bench_$WL.log
+if [ "$WL" = "sdxl" ]; then
+  for f in f16 f32 f32+res; do timeout 120 python3 tools/gemm_trace.py 8192 1280 1280 18 $f; done > $OUT/${TAG}_gemm_trace_8192x1280x1280.txt 2>> $OUT/bench_$WL.log
+  timeout 120 python3 tools/gemm_trace.py 8192 3840 1280 17 f16 > $OUT/${TAG}_gemm_trace_8192x3840x1280.txt 2>> $OUT/bench_$WL.log
+  timeout 300 python3 tools/gemm_ksweep.py 8192 1280 > $OUT/${TAG}_gemm_ksweep_8192x1280.txt 2>> $OUT/bench_$WL.log
+  timeout 120 python3 tools/attn_bench.py 20 > $OUT/${TAG}_attention_variants.txt 2>> $OUT/bench_$WL.log
+  # BASELINE.json configs[4]: TAE decode instead of the KL-VAE
+  timeout 600 python3 bench.py --workload $WL --batch-per-gpu $B --tae --no-cpu-baseline > $OUT/${TAG}_${WL}_b${B}_tae_bench.json 2>> $OUT/bench_$WL.log < /dev/null
+fi
