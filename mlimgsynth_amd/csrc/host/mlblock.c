@@ -72,6 +72,7 @@ static void ctx_reset_(MLCtx* C)
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
+	memset(&C->epb, 0, sizeof(C->epb));
 	memset(&C->info, 0, sizeof(C->info));
 }
 

@@ -91,6 +91,8 @@ struct MLCtx {
 	void* graph_exec;
 	/* batched cross-attention K/V projection of the (step-constant) context: one GEMM for all layers */
 	struct { MLTensor* ctx; char* wbase; char* out16; int n_in, n_total, n_used; } kvb;
+	/* batched time-embedding projections of the resnets (they all read silu(emb)): one GEMM, row-bias slices for the convs */
+	struct { MLTensor* emb; char* wbase; float* bbase; float* out32; int n_in, n_total, n_used; } epb;
 	int prepared, tuned, n_tune_miss;
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */
@@ -132,3 +134,4 @@ MLTensor* mlb_resnet_ex(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out);
 /* announce that `ctx` feeds cross-attention K/V projections totalling n_total output columns: they are computed by
  * ONE GEMM recorded here; mlb_attn_mhead then only takes column slices (parameters keep their per-layer names) */
 int mlb_cross_kv_batch(MLCtx* C, MLTensor* ctx, int n_total);
+int mlb_emb_proj_batch(MLCtx* C, MLTensor* emb, int n_total);

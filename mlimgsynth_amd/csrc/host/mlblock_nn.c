@@ -101,7 +101,7 @@ MLTensor* mlb_conv2d_ex2(MLCtx* C, MLTensor* x, int ch_out, int k, int s, int p,
 	g->A = xd; g->lda = x->ld16; g->conv = 1; g->n_img = x->n; g->H = H; g->W = W; g->Cin = cpad; g->OH = OH; g->OW = OW;
 	g->KH = k; g->KW = k; g->stride = s; g->pad = p; g->upsample = upsample;
 	g->W_ = wd; g->ldb = (int64_t)k*k*cpad; g->M = x->n*OH*OW; g->N = ch_out; g->K = k*k*cpad;
-	g->bias = bd; g->rowbias = rb; g->rows_per_batch = OH*OW; g->ldrb = ch_out; g->resid = rd; g->ldr = ldr;
+	g->bias = bd; g->rowbias = rb; g->rows_per_batch = OH*OW; g->ldrb = (ep && ep->rowbias) ? ep->rowbias->ld32 : ch_out; g->resid = rd; g->ldr = ldr;
 	g->act = ep ? ep->act : MLSD_ACT_NONE;
 	g->act_after_resid = ep ? ep->act_post : 0;
 	op->flops = 2.0 * g->M * (double)ch_out * k * k * ch_in;
@@ -213,6 +213,28 @@ static void* silu16_of(MLCtx* C, MLTensor* emb)
 	return emb->silu16;
 }
 
+/* Every resnet of a UNet projects the SAME silu(emb) with its own Linear (emb_proj, src/mlblock_nn.c:140-143): 21 (SDXL) /
+ * 22 (SD1.5) launches on 2..8 rows, 13-15 us each, become ONE GEMM [rows x n_total x n_in]; the parameters keep the
+ * reference's names and live in consecutive row blocks of one buffer, each conv1 takes its slice as row bias. */
+int mlb_emb_proj_batch(MLCtx* C, MLTensor* emb, int n_total)
+{
+	if (!emb || n_total <= 0 || C->err) return -1;
+	void *e16 = silu16_of(C, emb);
+	if (!e16) return -1;
+	const int n_in = emb->c;
+	const int64_t rows = rows_of(emb);
+	C->epb.emb = emb; C->epb.n_in = n_in; C->epb.n_total = n_total; C->epb.n_used = 0;
+	C->epb.wbase = (char*)mlctx_dalloc(C, (size_t)n_total * n_in * 2, 1);
+	C->epb.bbase = (float*)mlctx_dalloc(C, (size_t)n_total * 4, 1);
+	C->epb.out32 = (float*)mlctx_dalloc(C, (size_t)rows * n_total * 4, 0);
+	MLOp *op = mlctx_op_new(C, OP_GEMM, "");
+	mlsd_gemm_args *g = &op->u.gemm;
+	g->A = e16; g->lda = n_in; g->W_ = C->epb.wbase; g->ldb = n_in; g->M = (int)rows; g->N = n_total; g->K = n_in;
+	g->bias = C->epb.bbase; g->C32 = C->epb.out32; g->ldc32 = n_total;
+	op->flops = 2.0 * rows * (double)n_total * n_in;
+	return 1;
+}
+
 /* ------------------------------------------------------------------ resnet (src/mlblock_nn.c:129-156) */
 MLTensor* mlb_resnet_ex(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out)
 {
@@ -230,10 +252,22 @@ MLTensor* mlb_resnet_ex(MLCtx* C, MLTensor* x, MLTensor* emb, int ch_out)
 	if (emb) {
 		/* emb_proj = Linear(silu(emb)) (:140-143); sibling scopes may be recorded in any order, it is
 		 * launched before conv1 because conv1's epilogue adds it per image */
-		void *e16 = silu16_of(C, emb);
-		if (!e16) return NULL;
-		MLTensor et = *emb; et.d16 = e16; et.ld16 = emb->c; et.prod = -1;   /* view: silu(emb) in fp16 */
-		ep_t = MLN("emb_proj", mlb_linear_ex(C, &et, ch_out, T, NULL, 0));
+		if (C->epb.emb == emb && emb->c == C->epb.n_in && C->epb.n_used + ch_out <= C->epb.n_total) {
+			/* slice of the batched projection (mlb_emb_proj_batch): parameters at their row block, output columns as a view */
+			const int off = C->epb.n_used;
+			mlctx_block_begin(C);   /* the mlb_nn_linear scope of the reference */
+			mlctx_param_new_at(C, "weight", MLT_F16, emb->c, ch_out, 1, 1, 0, C->epb.wbase + (size_t)off * emb->c * 2);
+			mlctx_param_new_at(C, "bias", MLT_F32, ch_out, 1, 1, 1, 0, C->epb.bbase + off);
+			mlctx_named_op(C, "emb_proj");
+			C->epb.n_used += ch_out;
+			ep_t = mlt_new(C, emb->n, emb->h, emb->w, ch_out);
+			ep_t->d32 = C->epb.out32 + off; ep_t->ld32 = C->epb.n_total; ep_t->sz32 = 0; ep_t->prod = -1;   /* view: not arena owned */
+		} else {
+			void *e16 = silu16_of(C, emb);
+			if (!e16) return NULL;
+			MLTensor et = *emb; et.d16 = e16; et.ld16 = emb->c; et.prod = -1;   /* view: silu(emb) in fp16 */
+			ep_t = MLN("emb_proj", mlb_linear_ex(C, &et, ch_out, T, NULL, 0));
+		}
 		ep1.rowbias = ep_t;
 	}
 	MLTensor *y1 = MLN("conv1", mlb_conv2d_ex(C, h, ch_out, 3, 1, 1, 0, T, &ep1));

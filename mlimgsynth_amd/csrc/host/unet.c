@@ -115,6 +115,17 @@ static int unet_cross_kv_width(const UnetParams* P)
 	return total;
 }
 
+/* total width of the resnets' time-embedding projections (same walk; every resnet projects emb to its ch_out) */
+static int unet_emb_proj_width(const UnetParams* P)
+{
+	int total = 0, im = 0;
+	for (; P->ch_mult[im]; ++im) total += P->n_res_blk * P->n_ch * P->ch_mult[im];       /* in  */
+	im--;
+	total += 2 * P->n_ch * P->ch_mult[im];                                                /* mid */
+	for (; im >= 0; --im) total += (P->n_res_blk + 1) * P->n_ch * P->ch_mult[im];         /* out */
+	return total;
+}
+
 MLB_API MLTensor* mlb_unet_denoise(MLCtx* C, MLTensor* x, MLTensor* time, MLTensor* ctx, MLTensor* label, const UnetParams* P)
 {
 	char name[64];
@@ -122,6 +133,7 @@ MLB_API MLTensor* mlb_unet_denoise(MLCtx* C, MLTensor* x, MLTensor* time, MLTens
 	if (mlb_cross_kv_batch(C, ctx, unet_cross_kv_width(P)) < 0) return NULL;
 	MLTensor *emb = mlb_unet__embed(C, time, label, P);
 	if (!emb) return NULL;
+	if (mlb_emb_proj_batch(C, emb, unet_emb_proj_width(P)) < 0) return NULL;
 
 	/* ---- mlb_unet__in, src/unet.c:167-203 */
 	MLTensor *stack[40]; int ns = 0;
