@@ -52,6 +52,24 @@ GEN_CASES = [("gen_tiny_8_20", "tiny", 8, 20, 42), ("gen_tinyxl_8_6", "tinyxl", 
 VAE_ENC_CASES = [("vaeenc_tiny_64", "tiny", 64), ("vaeenc_sd1_64", "sd1", 64)]
 
 
+# HEADLINE sizes (BASELINE.json configs[1] / [2]): the UNet at the full latent and the decoders at full resolution.  Stored in
+# tests/golden/torch_golden_headline.npz; decoded images are stored REDUCED (reduce_image: 16x16 block means + 4096 sampled
+# pixels) so that a 12 MB image becomes a 65 KB vector.  fp16-operand mode only.
+HEADLINE_UNET_CASES = [("unet_sdxl_128", "sdxl", 128, 1, [3.0]), ("unet_sd1_64", "sd1", 64, 1, [3.0])]
+HEADLINE_VAE_CASES = [("vae_sdxl_128", "sdxl", 128), ("vae_sd1_64", "sd1", 64)]
+HEADLINE_TAE_CASES = [("tae_128", 128)]
+
+
+def reduce_image(img, key):
+    """img [1,3,H,W] -> 1-D vector: means of 16x16 blocks, then 4096 pixels at seeded positions"""
+    a = np.asarray(img, np.float32)[0]
+    c, h, w = a.shape
+    blocks = a.reshape(c, h // 16, 16, w // 16, 16).mean(axis=(2, 4), dtype=np.float64).astype(np.float32).reshape(-1)
+    r = np.random.default_rng(_seed(key) + 1)
+    idx = r.integers(0, c * h * w, 4096)
+    return np.concatenate([blocks, a.reshape(-1)[idx]])
+
+
 def _seed(key):
     return int(np.frombuffer(key.encode().ljust(8, b"_")[:8], np.uint64)[0] % (2 ** 31))
 

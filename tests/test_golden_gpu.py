@@ -73,3 +73,38 @@ def test_hip_generation_vs_independent_golden(key, model, lat, steps, seed):
     e = rel(latent[0], GOLD[key])
     print(key, e)
     assert e < 5e-2          # final latent of a chaotic 20-step loop (per-evaluation bound is the 4e-3 above)
+
+
+# ---- HEADLINE sizes (BASELINE.json configs[1] and [2]): full-latent UNet evaluations and full-resolution decodes against the
+# independent torch vectors of tests/golden/torch_golden_headline.npz (images reduced to block means + sampled pixels)
+HEAD = np.load(os.path.join(ROOT, "tests", "golden", "torch_golden_headline.npz"))
+
+
+@pytest.mark.parametrize("key,model,lat,n,sigmas", G.HEADLINE_UNET_CASES, ids=[c[0] for c in G.HEADLINE_UNET_CASES])
+def test_hip_unet_headline_size_vs_independent_golden(key, model, lat, n, sigmas):
+    from mlimgsynth_amd import engine
+    x, cond, label = G.unet_inputs(key, model, lat, n)
+    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
+    got = un.run(x, cond, label, np.array(sigmas, np.float32))
+    e = rel(got[0], HEAD[key][0])
+    print(key, e)
+    assert e < TOL
+
+
+@pytest.mark.parametrize("key,model,lat", G.HEADLINE_VAE_CASES, ids=[c[0] for c in G.HEADLINE_VAE_CASES])
+def test_hip_vae_decode_full_resolution_vs_independent_golden(key, model, lat):
+    from mlimgsynth_amd import engine
+    got = engine.Decoder(model, lat, lat, 1, seed=G.WEIGHT_SEED).run(G.vae_inputs(key, lat))
+    assert got.shape == (1, 3, 8 * lat, 8 * lat)
+    e = rel(G.reduce_image(got, key) - 0.5, HEAD[key] - 0.5)
+    print(key, e)
+    assert e < TOL
+
+
+@pytest.mark.parametrize("key,lat", G.HEADLINE_TAE_CASES, ids=[c[0] for c in G.HEADLINE_TAE_CASES])
+def test_hip_tae_decode_full_resolution_vs_independent_golden(key, lat):
+    from mlimgsynth_amd import engine
+    got = engine.Decoder("sdxl", lat, lat, 1, tae=True, seed=G.WEIGHT_SEED).run(G.tae_inputs(key, lat))
+    e = rel(G.reduce_image(got, key), HEAD[key])
+    print(key, e)
+    assert e < TOL

@@ -204,10 +204,14 @@ def test_conv2d_every_tile_variant(K, variant):
     assert rel(dC.download((n, h, w, cout), np.float32).transpose(0, 3, 1, 2), ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,Kd", [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320),
-                                    (256, 16640, 256), (8192, 10240, 192), (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640),
-                                    (131072, 320, 320), (192, 960, 1280)])
-@pytest.mark.parametrize("pp", [17, 18])
+PP_SHAPES = [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320), (256, 16640, 256), (8192, 10240, 192),
+             (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640), (131072, 320, 320), (192, 960, 1280)]
+# the ping-pong tiles take whole wave blocks (128x64 of the 256x256 tile / 64x80 of the 128x320 tile): only those combinations are cases
+PP_CASES = [(pp, M, N, Kd) for pp in (17, 18) for (M, N, Kd) in PP_SHAPES
+            if not ((pp == 18 and (N % 80 or M % 64)) or (pp == 17 and (N % 64 or M % 128)))]
+
+
+@pytest.mark.parametrize("pp,M,N,Kd", PP_CASES)
 def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
     """The two-group ping-pong kernel (gemm_pp.hpp) against the 16-wave 256x256 kernel on long K and many tiles,
     repeated: its RAW/WAR ordering rests on counted waits and barrier parity, so a race would show as rare
@@ -223,8 +227,6 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
     ref = d9.download((M, N), np.float32)
     exact = A.astype(np.float32) @ W.astype(np.float32).T
     assert rel(ref, exact) < 2e-5
-    if (pp == 18 and (N % 80 or M % 64)) or (pp == 17 and (N % 64 or M % 128)):
-        pytest.skip("the ping-pong tiles take whole wave blocks (128x64 / 64x80)")
     assert "pp" in kernels.gemm_variant(mk(d17, pp))
     for rep in range(6):
         kernels.gemm(mk(d17, pp))
@@ -233,15 +235,13 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
         assert np.abs(got - ref).max() < 1e-3, rep
 
 
-@pytest.mark.parametrize("pp", [17, 18])
-@pytest.mark.parametrize("mode", ["bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm"])
+@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
+                                     if not (pp == 18 and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
     here -- the multi-tile stream is covered by test_gemm_pingpong_tile_matches_plain_tile."""
     kernels, _lib = K
-    if pp == 18 and mode == "geglu_f16":
-        pytest.skip("GEGLU pairs 32-column blocks: 256-wide tile only")
     M, N, Kd = (1536, 768, 448) if pp == 17 else (1536, 960, 448)
     rng = np.random.default_rng(len(mode))
     A = f16r(rng.standard_normal((M, Kd)))

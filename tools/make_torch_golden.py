@@ -3,6 +3,7 @@ INDEPENDENT torch restatement (tools/torch_ref.py, fp32 CPU, ggml's F16 operand 
 container only (torch CPU); prints, for information, how far the oracle is from each vector.
 
 usage: python3 tools/make_torch_golden.py [--only key_prefix] [--check]     (--check: compare, do not write)
+       python3 tools/make_torch_golden.py --headline [--only key_prefix]   (full-size cases -> torch_golden_headline.npz)
 Shared DATA only: parameter names + the (seed, name, shape) synthetic weight generator, the pinned host scalars
 (sigma<->t table and Philox noise, both pinned against the reference itself: tests/test_oracle_host.py)."""
 import ctypes
@@ -168,6 +169,44 @@ def run_mode(out, want, check, f16_mode):
     O.L().orc_set_act_rounding(1)
 
 
+def run_headline(want):
+    """full-size cases -> tests/golden/torch_golden_headline.npz (fp16-operand mode; images reduced by G.reduce_image)"""
+    path = os.path.join(ROOT, "tests", "golden", "torch_golden_headline.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    O.L().orc_set_act_rounding(1)
+    NetM = lambda: TR.Net(TR.Weights(synth), f16_ops=True)
+    with torch.no_grad():
+        for key, model, lat, n, sigmas in G.HEADLINE_UNET_CASES:
+            if not want(key):
+                continue
+            t0 = time.time()
+            U = G.UNET[model]
+            x, cond, label = G.unet_inputs(key, model, lat, n)
+            s = np.float32(sigmas[0])
+            t = O.L().orc_sigma_to_t(float(s))
+            c_in = np.float32(1) / np.sqrt(s * s + np.float32(1), dtype=np.float32)
+            y = NetM().unet(U, torch.from_numpy(x[:1] * c_in), torch.tensor([t]), torch.from_numpy(cond[:1]),
+                            torch.from_numpy(label[:1]) if label is not None else None)
+            out[key] = y.numpy()
+            print(f"{key}: torch {time.time() - t0:.1f}s", flush=True)
+        for key, model, lat in G.HEADLINE_VAE_CASES:
+            if not want(key):
+                continue
+            t0 = time.time()
+            res = NetM().vae_decode(G.VAE[model], torch.from_numpy(G.vae_inputs(key, lat))).numpy()
+            out[key] = G.reduce_image(res, key)
+            print(f"{key}: torch {time.time() - t0:.1f}s, image {res.shape} -> {out[key].shape}", flush=True)
+        for key, lat in G.HEADLINE_TAE_CASES:
+            if not want(key):
+                continue
+            t0 = time.time()
+            res = NetM().tae_decode(torch.from_numpy(G.tae_inputs(key, lat))).numpy()
+            out[key] = G.reduce_image(res, key)
+            print(f"{key}: torch {time.time() - t0:.1f}s", flush=True)
+    np.savez_compressed(path, **{k: np.asarray(v, np.float32) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "vectors")
+
+
 def main():
     only = None
     for i, a in enumerate(sys.argv):
@@ -176,6 +215,8 @@ def main():
     check = "--check" in sys.argv
     out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
     want = lambda k: only is None or k.startswith(only)
+    if "--headline" in sys.argv:
+        return run_headline(want)
 
     for f16_mode in (True, False):
         run_mode(out, want, check, f16_mode)
