@@ -113,9 +113,16 @@ typedef struct mlsd_gemm_args {
 	int ksplit;
 	void* ws;               /* >= mlsd_gemm_splitk_ws_bytes(M, N, ksplit) bytes, 16-byte aligned */
 	size_t ws_bytes;
+	/* column statistics of the fp32 output for a consuming GroupNorm (its first pass disappears): per block of
+	 * mlsd_gemm_colstats_rows(args) consecutive rows and per column the sum and the sum of squares of C32, written as
+	 * colstats[block][0][n] and colstats[block][1][n] (floats, 2*N per block).  Only the launches for which
+	 * mlsd_gemm_colstats_rows() > 0 honour it (ping-pong tiles, fp32 output without activation); NULL = off. */
+	float* colstats;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
+/* rows per statistics block (64 or 128) if this launch would write a->colstats, 0 if its kernel cannot */
+int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
 /* tile order inside an XCD's range: column panels `mode` tiles wide (default 8; 0 = row-major).  A/B timing knob. */
@@ -172,6 +179,10 @@ typedef struct mlsd_gn_args {
 	void* y16;                            /* fp16 [n_img][HW][C1+C2] */
 	void* raw16;                          /* optional fp16 copy of the un-normalised input, or NULL */
 	void* ws;
+	/* statistics written by the producing GEMMs (mlsd_gemm_args.colstats, [rows / rb_rows][2][C_i]) instead of the first pass
+	 * over x: used when every source has them (rb_rows_i > 0) and HW is a multiple of rb_rows_i */
+	const float *cs1, *cs2;
+	int rb_rows1, rb_rows2;
 } mlsd_gn_args;
 
 size_t mlsd_groupnorm_ws_bytes(int n_img, int HW, int n_grp);

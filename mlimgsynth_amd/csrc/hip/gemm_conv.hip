@@ -71,6 +71,7 @@ struct GemmP {
     long ws_stride;
     int gw;    // tile-order panel width (0: row-major)
     unsigned long long* tbuf;   // diagnostics: per-block cycle stamps of the ping-pong kernels (tools/gemm_trace.py), or null
+    float* colstats;            // ping-pong kernels built with a *_STATS epilogue: [row block][2][N] column sums / sums of squares
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -585,7 +586,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
-    p.dbg = g_gemm_dbg; p.tbuf = nullptr;
+    p.dbg = g_gemm_dbg; p.tbuf = nullptr; p.colstats = nullptr;
     p.gw = g_gemm_panel;
     int kt_per;
     const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
@@ -635,6 +636,20 @@ bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
            (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
 }
 
+// which epilogue body a ping-pong launch of these arguments uses (gemm_pp.hpp PP_EPI_*)
+int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
+{
+    if ((g_gemm_dbg & 2) || a->bias_m) return PP_EPI_GENERIC;
+    if (a->act == MLSD_ACT_NONE) {
+        if (a->C16 && !a->C32 && !a->resid) return PP_EPI_F16;
+        if (a->C32 && !a->C16) {
+            const bool st = a->colstats != nullptr && !((uintptr_t)a->colstats & 15) && !(a->N & 3);
+            return a->resid ? (st ? PP_EPI_F32_RES_STATS : PP_EPI_F32_RES) : (st ? PP_EPI_F32_STATS : PP_EPI_F32);
+        }
+    } else if (a->act == MLSD_ACT_GEGLU && BN == 256 && a->C16 && !a->C32 && !a->resid && !a->conv) return PP_EPI_GEGLU16;
+    return PP_EPI_GENERIC;
+}
+
 // launcher of the ping-pong kernels (gemm_pp.hpp): same argument handling as launch<>
 template <int BM, int BN, int CB0, int CB1, bool RESBATCH>
 int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
@@ -650,7 +665,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = (a->M + BM - 1) / BM; p.nbn = (a->N + BN - 1) / BN;
     p.vec = 1;                                             // pp_eligible() checked the alignment
-    p.dbg = g_gemm_dbg; p.gw = g_gemm_panel; p.tbuf = g_gemm_tbuf;
+    p.dbg = g_gemm_dbg; p.gw = g_gemm_panel; p.tbuf = g_gemm_tbuf; p.colstats = nullptr;
     p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on these tiles
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
@@ -661,17 +676,14 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         return mlsd_check_launch("gemm_pp_kernel");
     };
     // the epilogue the kernel is built with (gemm_pp.hpp): the bulk launches of the UNet / VAE have no activation in the GEMM
-    int epi = PP_EPI_GENERIC;
-    if (!(g_gemm_dbg & 2) && !a->bias_m) {
-        if (a->act == MLSD_ACT_NONE) {
-            if (a->C16 && !a->C32 && !a->resid) epi = PP_EPI_F16;
-            else if (a->C32 && !a->C16) epi = a->resid ? PP_EPI_F32_RES : PP_EPI_F32;
-        } else if (a->act == MLSD_ACT_GEGLU && BN == 256 && a->C16 && !a->C32 && !a->resid && !a->conv) epi = PP_EPI_GEGLU16;
-    }
+    const int epi = pp_epilogue_kind(a, BN);
+    p.colstats = (epi == PP_EPI_F32_STATS || epi == PP_EPI_F32_RES_STATS) ? a->colstats : nullptr;
     if (a->conv) {
         switch (epi) {
         case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32>);
         case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES>);
+        case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_STATS>);
+        case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES_STATS>);
         default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_GENERIC>);
         }
     }
@@ -679,6 +691,8 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     case PP_EPI_F16: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F16>);
     case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32>);
     case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES>);
+    case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_STATS>);
+    case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES_STATS>);
     case PP_EPI_GEGLU16:
         if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16>);
         break;
@@ -792,6 +806,18 @@ MLSD_API void mlsd_gemm_set_trace(void* buf) { g_gemm_tbuf = (unsigned long long
 MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 
 MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
+
+MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
+{
+    if (!a || !a->colstats) return 0;
+    const int v = pick_variant(a);
+    int bm, bn;
+    if (v == 17 && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
+    else if (v == 18 && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+    else return 0;
+    const int e = pp_epilogue_kind(a, bn);
+    return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
+}
 
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {

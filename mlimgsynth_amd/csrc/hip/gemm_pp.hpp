@@ -67,7 +67,8 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
 // EPI selects the epilogue the kernel is BUILT with (launch_pp picks it from the arguments): 0 = generic (any activation,
 // per-row bias, any output combination: decided per element at run time), 1 = fp16 out, 2 = fp32 out, 3 = fp32 out + fp32
 // residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
-enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4 };
+enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6 };
+// *_STATS: additionally the column sums / sums of squares of the wave's rows (GemmP::colstats) for a consuming GroupNorm
 template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
@@ -319,10 +320,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     // the conversion and the store.
     // Residual rows are fetched PF row blocks ahead of their use (all of them on the 128-row tile: 80 registers that the
     // main loop's fragments no longer need; two blocks = 32 registers on the 256-row tile).
-    auto epi_fast = [&](auto S32_, auto S16_, auto RES_, int wrow0, int wcol0) __attribute__((always_inline)) {
-        constexpr bool S32 = decltype(S32_)::value, S16 = decltype(S16_)::value, RES = decltype(RES_)::value;
+    auto epi_fast = [&](auto S32_, auto S16_, auto RES_, auto ST_, int wrow0, int wcol0) __attribute__((always_inline)) {
+        constexpr bool S32 = decltype(S32_)::value, S16 = decltype(S16_)::value, RES = decltype(RES_)::value, ST = decltype(ST_)::value;
         constexpr int NR = 2 * RA;                               // 16-row blocks of the wave's slab: r = qa * RA + i
-        constexpr int PF = (BM == 128) ? NR : 2;
+        constexpr int PF = !ST ? (BM == 128 ? NR : 2) : (BM == 128 ? 2 : 1);   // (the statistics need 2 * NCB * 4 registers of their own)
+        // ST: per column, sum and sum of squares over the wave's WM rows (a lane accumulates its 2*RA rows, the 16 lanes of a
+        // DPP row are the 16 rows of a block) -> one deterministic partial per (tile row, wave row, column): GemmP::colstats
+        f32x4 cs[ST ? NCB : 1], cq[ST ? NCB : 1];
+        if constexpr (ST) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) { cs[c] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
         f32x4 rr[RES ? NR : 1][RES ? NCB : 1];
         const float* rbase = RES ? p.resid + (long)(wrow0 + l15) * p.ldr + wcol0 + 4 * lg : nullptr;
         auto row_of = [&](int r) __attribute__((always_inline)) { return (r / RA) * (WM / 2) + (r % RA) * 16; };
@@ -345,10 +353,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             for (int c = 0; c < NCB; ++c) {
                 f32x4 v = acc[qa][i][c] + cb[c];
                 if constexpr (RES) v += rr[r][c];
+                if constexpr (ST) { cs[c] += v; cq[c] += v * v; }
                 if constexpr (S32) *reinterpret_cast<f32x4*>(c32b + (long)row_of(r) * p.ldc32 + c * 16) = v;
                 if constexpr (S16) {
                     f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                     *reinterpret_cast<f16x4*>(c16b + (long)row_of(r) * p.ldc16 + c * 16) = h;
+                }
+            }
+        }
+        if constexpr (ST) {
+            auto row16_sum = [&](float v) __attribute__((always_inline)) {       // butterfly over the 16 lanes of a DPP row (xor 1, 2, then mirrors)
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+                return v;
+            };
+            const long rb = (long)(tcur.m0 / BM) * 2 + wr;
+            float* st = p.colstats + rb * 2 * p.N + wcol0 + 4 * lg;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[c][e] = row16_sum(cs[c][e]); cq[c][e] = row16_sum(cq[c][e]); }
+                if (l15 == 0) {
+                    *reinterpret_cast<f32x4*>(st + c * 16) = cs[c];
+                    *reinterpret_cast<f32x4*>(st + p.N + c * 16) = cq[c];
                 }
             }
         }
@@ -387,9 +416,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         using std::integral_constant;
         using T = std::true_type;
         using F = std::false_type;
-        if constexpr (EPI == PP_EPI_F16) { epi_fast(F{}, T{}, F{}, wrow0, wcol0); return; }
-        if constexpr (EPI == PP_EPI_F32) { epi_fast(T{}, F{}, F{}, wrow0, wcol0); return; }
-        if constexpr (EPI == PP_EPI_F32_RES) { epi_fast(T{}, F{}, T{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F16) { epi_fast(F{}, T{}, F{}, F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32) { epi_fast(T{}, F{}, F{}, F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_RES) { epi_fast(T{}, F{}, T{}, F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_STATS) { epi_fast(T{}, F{}, F{}, T{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_RES_STATS) { epi_fast(T{}, F{}, T{}, T{}, wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_GEGLU16) { epi_fast_geglu(wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_GENERIC) {
         if constexpr (RESBATCH) {

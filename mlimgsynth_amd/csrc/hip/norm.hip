@@ -34,6 +34,11 @@ struct GnP {
     _Float16* y16;
     _Float16* raw16;
     float* ws;  // [n_img][nchunk][G][2]
+    // producer statistics (column sums / sums of squares per block of rb rows, written by the GEMM epilogues): when set, pass 1
+    // is gn_finalize over these few KB..MB instead of gn_stats over the whole fp32 map
+    const float *cs1, *cs2;
+    int rb1, rb2;
+    const float* mr;  // [n_img][G][2] mean, rstd (gn_finalize -> gn_apply), or null
 };
 
 __device__ __forceinline__ const float* gn_src(const GnP& p, int img, int pix, int c)
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
     float* sc = sm;
     float* sh = sm + p.C;
     const int img = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    {
+    if (p.mr) {
+        if (tid < p.G) { g_mean[tid] = p.mr[((long)img * p.G + tid) * 2]; g_rstd[tid] = p.mr[((long)img * p.G + tid) * 2 + 1]; }
+    } else {
         // partial sums of the image's chunks: 8 stripes of chunks per group in parallel, then a fixed-order
         // combine (deterministic; a serial walk over up to 256 chunks was most of this kernel at batch 1)
         const int g = tid & 31, st = tid >> 5;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
         r1[st][g] = t1; r2[st][g] = t2;
     }
     __syncthreads();
-    if (tid < p.G) {
+    if (!p.mr && tid < p.G) {
         double t1 = 0, t2 = 0;
 #pragma unroll
         for (int st = 0; st < 8; ++st) { t1 += r1[st][tid]; t2 += r2[st][tid]; }
@@ -225,6 +232,45 @@ __global__ __launch_bounds__(256) void gn_apply(const GnP p)
                 }
             }
         }
+    }
+}
+
+// Mean / rstd of one (image, group) from the producers' column statistics: sums over the image's row blocks and the
+// group's channels, in double, fixed order (thread t takes items t, t+256, ..; then a fixed tree).  Unshifted sums: the
+// partials are fp32 sums of 64..128 values, the cancellation in E[x^2] - mean^2 happens in double.
+__global__ __launch_bounds__(256) void gn_finalize(const GnP p, float* __restrict__ mr)
+{
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    double s = 0, q = 0;
+    const int c0 = g * p.cg, c1 = c0 + p.cg;
+    // the group's channels may straddle the two sources of a virtual concat
+    for (int src = 0; src < 2; ++src) {
+        const int lo = src ? max(c0, p.C1) : c0, hi = src ? c1 : min(c1, p.C1);
+        if (lo >= hi) continue;
+        const float* cs = src ? p.cs2 : p.cs1;
+        const int Ci = src ? p.C2 : p.C1, rb = src ? p.rb2 : p.rb1, off = src ? p.C1 : 0;
+        const int nrb = p.HW / rb, ncc = hi - lo;
+        const float* base = cs + (long)img * nrb * 2 * Ci + (lo - off);
+        for (int idx = tid; idx < nrb * ncc; idx += 256) {
+            const int k = idx / ncc, cc = idx - k * ncc;
+            const float* e = base + (long)k * 2 * Ci + cc;
+            s += (double)e[0]; q += (double)e[Ci];
+        }
+    }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { rs[tid] += rs[tid + w]; rq[tid] += rq[tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)p.cg * p.HW;
+        const double mu = rs[0] / cnt;
+        double var = rq[0] / cnt - mu * mu;
+        if (var < 0) var = 0;
+        mr[((long)img * p.G + g) * 2] = (float)mu;
+        mr[((long)img * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
 }
 
@@ -386,8 +432,18 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
     p.pix_per_chunk = (a->HW + p.nchunk - 1) / p.nchunk;
     p.nchunk = (a->HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
     const dim3 grid(p.nchunk, a->n_img);
-    hipLaunchKernelGGL(gn_stats, grid, dim3(256), 0, (hipStream_t)stream, p);
-    int rc = mlsd_check_launch("gn_stats");
+    p.cs1 = a->cs1; p.cs2 = a->cs2; p.rb1 = a->rb_rows1; p.rb2 = a->rb_rows2; p.mr = nullptr;
+    const bool from_producers = a->cs1 && a->rb_rows1 > 0 && !(a->HW % a->rb_rows1) &&
+                                (a->C2 == 0 || (a->cs2 && a->rb_rows2 > 0 && !(a->HW % a->rb_rows2)));
+    int rc;
+    if (from_producers) {
+        hipLaunchKernelGGL(gn_finalize, dim3(p.G, a->n_img), dim3(256), 0, (hipStream_t)stream, p, p.ws);
+        rc = mlsd_check_launch("gn_finalize");
+        p.mr = p.ws;
+    } else {
+        hipLaunchKernelGGL(gn_stats, grid, dim3(256), 0, (hipStream_t)stream, p);
+        rc = mlsd_check_launch("gn_stats");
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(gn_apply, grid, dim3(256), (size_t)C * 2 * sizeof(float), (hipStream_t)stream, p);
     return mlsd_check_launch("gn_apply");

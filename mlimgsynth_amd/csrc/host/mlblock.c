@@ -619,6 +619,57 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 }
 
 
+/* GroupNorm statistics from the producers: when every source of a GroupNorm is the fp32 output of a
+ * ping-pong GEMM / conv launch that can emit column statistics (mlsd_gemm_colstats_rows > 0: fp32 output, no activation),
+ * that launch gets a statistics buffer and the GroupNorm's first pass over the fp32 map is replaced by gn_finalize over the
+ * statistics.  The choice is a pure function of the plan (tile table + shapes); MLSD_GN_TWO_PASS=1 keeps the two-pass form
+ * (A/B timing, and the reference for the parity test). */
+static MLOp* gn_producer(MLCtx* C, int before, const float* x, int64_t ld, int Ci, int64_t rows)
+{
+	for (int j=before-1; j>=0; --j) {
+		MLOp *o = &C->ops[j];
+		if (o->kind == OP_GEMM && o->u.gemm.C32 == x && o->u.gemm.ldc32 == ld && o->u.gemm.N == Ci && o->u.gemm.M == rows &&
+		    o->u.gemm.act != MLSD_ACT_GEGLU) return o;
+	}
+	return NULL;
+}
+
+static int gn_producer_rows(MLOp* o)
+{	/* rows per statistics block this producer's kernel would use, 0 if it cannot emit statistics (no side effect) */
+	mlsd_gemm_args *g = &o->u.gemm;
+	float *keep = g->colstats;
+	if (!keep) g->colstats = (float*)(uintptr_t)64;                  /* probe value: alignment is part of the test */
+	const int r = mlsd_gemm_colstats_rows(g);
+	g->colstats = keep;
+	return (r > 0 && !(g->M % r)) ? r : 0;
+}
+
+static void wire_gn_stats(MLCtx* C)
+{
+	const char *e = getenv("MLSD_GN_TWO_PASS");
+	if (e && *e && *e != '0') return;
+	for (int i=0;i<C->n_ops;++i) {
+		if (C->ops[i].kind != OP_GN) continue;
+		mlsd_gn_args *g = &C->ops[i].u.gn;
+		const int64_t rows = (int64_t)g->n_img * g->HW;
+		MLOp *p1 = gn_producer(C, i, g->x1, g->ld1, g->C1, rows);
+		MLOp *p2 = g->C2 ? gn_producer(C, i, g->x2, g->ld2, g->C2, rows) : NULL;
+		if (!p1 || (g->C2 && !p2)) continue;
+		const int r1 = gn_producer_rows(p1), r2 = p2 ? gn_producer_rows(p2) : 0;
+		if (r1 <= 0 || (g->HW % r1) || (p2 && (r2 <= 0 || (g->HW % r2)))) continue;
+		MLOp *pr[2] = { p1, p2 };
+		int ok = 1;
+		for (int k=0;k<2 && ok;++k) if (pr[k] && !pr[k]->u.gemm.colstats) {     /* one buffer per producer, shared by its consumers */
+			mlsd_gemm_args *pg = &pr[k]->u.gemm;
+			pg->colstats = (float*)mlctx_dalloc(C, (size_t)(pg->M / (k ? r2 : r1)) * 2 * pg->N * sizeof(float), 1);
+			if (!pg->colstats) ok = 0;
+		}
+		if (!ok) continue;
+		g->cs1 = p1->u.gemm.colstats; g->rb_rows1 = r1;
+		g->cs2 = p2 ? p2->u.gemm.colstats : NULL; g->rb_rows2 = r2;
+	}
+}
+
 MLB_API int mlctx_prep(MLCtx* C)
 {
 	if (C->err) return C->err;
@@ -636,6 +687,7 @@ MLB_API int mlctx_prep(MLCtx* C)
 		}
 		fl += op->flops;
 	}
+	if (!autotune_on()) wire_gn_stats(C);   /* (needs the tiles: the offline tuning mode runs the two-pass form) */
 	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;
 	C->info.mem_params = C->mem_params; C->info.mem_compute = C->mem_compute; C->info.mem_total = C->mem_params + C->mem_compute;
 	if (C->err) return C->err;
@@ -719,7 +771,8 @@ MLB_API int mlctx_op_info(const MLCtx* C, int i, const char** label, double* flo
 			*label = buf;
 		} else if (op->kind == OP_GN && (C->flags & MLB_F_OPSHAPES)) {
 			const mlsd_gn_args *a = &op->u.gn;
-			snprintf(buf, sizeof(buf), "%s n%d hw%d c%d+%d%s", op->label, a->n_img, a->HW, a->C1, a->C2, a->raw16 ? " +raw" : "");
+			snprintf(buf, sizeof(buf), "%s n%d hw%d c%d+%d%s%s", op->label, a->n_img, a->HW, a->C1, a->C2, a->raw16 ? " +raw" : "",
+				a->cs1 ? " stats" : "");   /* "stats": first pass replaced by the producers' column statistics */
 			*label = buf;
 		} else *label = op->label;
 	}

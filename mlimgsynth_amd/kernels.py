@@ -16,7 +16,7 @@ class GemmArgs(ctypes.Structure):
                 ("K", c_int), ("bias", vp), ("rowbias", vp), ("rows_per_batch", c_int), ("ldrb", c_i64),
                 ("resid", vp), ("ldr", c_i64), ("act", c_int), ("C32", vp), ("ldc32", c_i64), ("C16", vp),
                 ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int), ("tile_variant", c_int),
-                ("ksplit", c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t)]
+                ("ksplit", c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("colstats", vp)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -28,7 +28,7 @@ class AttnArgs(ctypes.Structure):
 class GnArgs(ctypes.Structure):
     _fields_ = [("x1", vp), ("x2", vp), ("ld1", c_i64), ("ld2", c_i64), ("C1", c_int), ("C2", c_int),
                 ("n_img", c_int), ("HW", c_int), ("n_grp", c_int), ("eps", c_f), ("gamma", vp), ("beta", vp),
-                ("silu", c_int), ("y16", vp), ("raw16", vp), ("ws", vp)]
+                ("silu", c_int), ("y16", vp), ("raw16", vp), ("ws", vp), ("cs1", vp), ("cs2", vp), ("rb_rows1", c_int), ("rb_rows2", c_int)]
 
 
 def gemm(args, stream=None):

@@ -649,3 +649,107 @@ def oracle_key(name, seed):
     z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M
     z ^= z >> 31
     return z
+
+
+@pytest.mark.parametrize("pp,conv,res", [(17, False, False), (17, False, True), (18, False, True), (18, True, False), (17, True, True), (18, False, False)])
+def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
+    """mlsd_gemm_args.colstats: the ping-pong kernels built with a *_STATS epilogue also write, per block of
+    mlsd_gemm_colstats_rows() rows and per column, the sum and the sum of squares of the fp32 output they store (the first
+    pass of the consuming GroupNorm).  Checked against the kernel's own output, bit-repeatable, output unchanged."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    L.mlsd_gemm_colstats_rows.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(pp + 2 * conv + res)
+    if conv:
+        n, h, w, cin, cout, k = 2, 32, 16, 64, 640, 3
+        M, N, Kd = n * h * w, cout, k * k * cin
+        A = rng.standard_normal((n, h, w, cin)).astype(np.float16)
+        W = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(Kd)).astype(np.float32)
+        dW = dev(_lib, repack_conv_w(W, cin).astype(np.float16))
+    else:
+        M, N, Kd = 2048, 1280, 448
+        A = rng.standard_normal((M, Kd)).astype(np.float16)
+        dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+    bias = rng.standard_normal(N).astype(np.float32) * 3          # a non-zero mean per column
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dB, dR = dev(_lib, A), dev(_lib, bias), dev(_lib, R)
+    dC, dC0 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+
+    def args(dst, stats):
+        a = kernels.GemmArgs(A=dA.ptr, lda=cin if conv else Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=pp + 1)
+        if conv:
+            a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, n, h, w, cin, h, w, k, k, 1, 1
+        if res:
+            a.resid, a.ldr = dR.ptr, N
+        if stats is not None:
+            a.colstats = stats.ptr
+        return a
+    a0 = args(dC0, None)
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a0)) == 0
+    kernels.gemm(a0)
+    plain = dC0.download((M, N), np.float32)
+    rows = 128 if pp == 17 else 64
+    dS = _lib.DeviceBuffer(M // rows * 2 * N * 4)
+    a1 = args(dC, dS)
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a1)) == rows
+    outs = []
+    for rep in range(2):
+        _lib.check(L.mlsd_memset(vp(dS.ptr), 0xFF, ctypes.c_size_t(dS.nbytes), None))
+        kernels.gemm(a1)
+        outs.append(dS.download((M // rows, 2, N), np.float32))
+    got = dC.download((M, N), np.float32)
+    assert np.array_equal(got, plain)                                            # the output itself is untouched
+    assert np.array_equal(outs[0], outs[1])                                      # fixed reduction order
+    blk = got.astype(np.float64).reshape(M // rows, rows, N)
+    s, q = blk.sum(1), (blk * blk).sum(1)
+    assert np.abs(outs[0][:, 0] - s).max() < 2e-3 and np.abs(outs[0][:, 1] - q).max() / q.max() < 1e-5
+    # GELU in the epilogue, fp16 output or a per-row bias: those launches do not produce statistics
+    a2 = args(dC, dS); a2.act = kernels.ACT_GELU
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
+
+
+@pytest.mark.parametrize("two_sources", [False, True])
+def test_groupnorm_from_producer_statistics(K, two_sources):
+    """GroupNorm whose first pass is replaced by the producers' column statistics (gn_finalize): same result as the two-pass
+    form on the same fp32 maps (virtual concat of two producers included, groups straddling the boundary), and vs numpy."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    rng = np.random.default_rng(5 + two_sources)
+    n_img, HW, Kd = 2, 1024, 192
+    Cs = [640, 320] if two_sources else [320]
+    M = n_img * HW
+    maps, stats, keep = [], [], []
+    for i, Cn in enumerate(Cs):
+        A = rng.standard_normal((M, Kd)).astype(np.float16)
+        W = (rng.standard_normal((Cn, Kd)) / np.sqrt(Kd)).astype(np.float16)
+        bias = (rng.standard_normal(Cn) * 4).astype(np.float32)
+        dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, bias)
+        dC, dS = _lib.DeviceBuffer(M * Cn * 4), _lib.DeviceBuffer(M // 64 * 2 * Cn * 4)
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=Cn, K=Kd, bias=dB.ptr, C32=dC.ptr, ldc32=Cn, tile_variant=19, colstats=dS.ptr)
+        L.mlsd_gemm_colstats_rows.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+        assert L.mlsd_gemm_colstats_rows(ctypes.byref(a)) == 64
+        kernels.gemm(a)
+        maps.append(dC); stats.append(dS); keep += [dA, dW, dB]
+    C = sum(Cs)
+    gamma, beta = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    dG, dBt = dev(_lib, gamma), dev(_lib, beta)
+    ws = _lib.DeviceBuffer(kernels.groupnorm_ws_bytes(n_img, HW, 32))
+    outs = []
+    for use_stats in (False, True):
+        dY = _lib.DeviceBuffer(M * C * 2)
+        g = kernels.GnArgs(x1=maps[0].ptr, ld1=Cs[0], C1=Cs[0], n_img=n_img, HW=HW, n_grp=32, eps=1e-6, gamma=dG.ptr, beta=dBt.ptr, silu=1, y16=dY.ptr, ws=ws.ptr)
+        if two_sources:
+            g.x2, g.ld2, g.C2 = maps[1].ptr, Cs[1], Cs[1]
+        if use_stats:
+            g.cs1, g.rb_rows1 = stats[0].ptr, 64
+            if two_sources:
+                g.cs2, g.rb_rows2 = stats[1].ptr, 64
+        kernels.groupnorm(g)
+        outs.append(dY.download((n_img, HW, C), np.float16).astype(np.float32))
+    x = np.concatenate([m.download((n_img, HW, c), np.float32) for m, c in zip(maps, Cs)], axis=2).astype(np.float64)
+    xg = x.reshape(n_img, HW, 32, C // 32)
+    mu, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+    y = ((xg - mu) / np.sqrt(var + 1e-6)).reshape(n_img, HW, C) * gamma + beta
+    want = y / (1 + np.exp(-y))
+    assert np.abs(outs[1] - outs[0]).max() <= 4e-3          # one fp16 ulp at |y| < 4
+    assert rel(outs[1], want) < 1e-3 and rel(outs[0], want) < 1e-3

@@ -136,3 +136,26 @@ def test_unet_sdxl_headline_size_parity():
     print("sdxl 128x128 rel-L2:", err)
     assert np.isfinite(got).all()
     assert err < TOL
+
+
+def test_groupnorm_statistics_from_producers_equal_two_pass(monkeypatch):
+    """the plan wires GroupNorm statistics from the producing GEMM / conv epilogues (mlblock.c wire_gn_stats); with
+    MLSD_GN_TWO_PASS=1 the same plan runs the two-pass GroupNorm.  The statistics differ in the last fp32 bits (unshifted
+    per-64-row partial sums against shifted per-chunk sums), which flips fp16 roundings of normalised activations here and there:
+    the two evaluations agree at the same ~1e-3 level as any two equivalent fp16-operand implementations (tests/test_golden_cpu.py),
+    well inside the 4e-3 parity bound both hold against the oracle and the torch vectors."""
+    from mlimgsynth_amd import engine
+    import golden_cases as G
+    # the headline plan (batch 4 => 8 UNet inputs at the 128x128 latent): its producers run on the ping-pong tiles
+    x, cond, label = G.unet_inputs("gn_ab", "sdxl", 128, 8)
+    sig = np.array([14.6, 9.0, 5.0, 3.0, 1.5, 0.7, 0.2, 0.03], np.float32)
+    un = engine.Unet("sdxl", 128, 128, 8, flags=16)
+    a = un.run(x, cond, label, sig)
+    n_fused = sum(1 for lab, _ in un.ctx.op_list() if lab.startswith("groupnorm") and "stats" in lab)
+    un.ctx.destroy()
+    monkeypatch.setenv("MLSD_GN_TWO_PASS", "1")
+    un2 = engine.Unet("sdxl", 128, 128, 8, flags=16)
+    b = un2.run(x, cond, label, sig)
+    un2.ctx.destroy()
+    assert np.isfinite(a).all() and rel(a, b) < 3e-3, rel(a, b)
+    assert n_fused >= 30, n_fused                          # most of the 46 GroupNorms of the SDXL UNet take the fused form
