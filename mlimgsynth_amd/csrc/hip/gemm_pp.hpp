@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     auto epi_fast = [&](auto S32_, auto S16_, auto RES_, auto ST_, int wrow0, int wcol0) __attribute__((always_inline)) {
         constexpr bool S32 = decltype(S32_)::value, S16 = decltype(S16_)::value, RES = decltype(RES_)::value, ST = decltype(ST_)::value;
         constexpr int NR = 2 * RA;                               // 16-row blocks of the wave's slab: r = qa * RA + i
-        constexpr int PF = !ST ? (BM == 128 ? NR : 2) : (BM == 128 ? 2 : 1);   // (the statistics need 2 * NCB * 4 registers of their own)
+        constexpr int PF = !ST ? (BM == 128 ? NR : 2) : (BM == 128 ? NR : 1);  // (the statistics need 2 * NCB * 4 registers of their own)
         // ST: per column, sum and sum of squares over the wave's WM rows (a lane accumulates its 2*RA rows, the 16 lanes of a
         // DPP row are the 16 rows of a block) -> one deterministic partial per (tile row, wave row, column): GemmP::colstats
         f32x4 cs[ST ? NCB : 1], cq[ST ? NCB : 1];
