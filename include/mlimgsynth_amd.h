@@ -123,10 +123,19 @@ typedef struct {
 	int want_feat;
 	char prefix[16];
 	float* text_proj_host;
+	MLTensor* t_tap;          /* init_ex with tap_skip > 0: copy of the hidden state clip_skip = tap_skip layers from the end (no norm) */
+	void* tap_dev;
 } ClipEncoder;
 int clip_encoder_init(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
 	int clip_skip, bool norm, bool want_feat);         /* then load weights: mlctx_params_synth / mlctx_param_set */
 int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks, float* embed, float* feat);
+/* one pass for both things SDXL wants from open_clip bigG (src/mlimgsynth.c:1517-1543 runs the tower twice): the whole stack
+ * with final norm (pooled feature) AND the un-normed hidden state `tap_skip` layers from the end (the embedding), tapped by a
+ * device copy; and prompts of different lengths in one run (prompt + negative prompt): n_tok[p], toks[p] for p < n_used
+ * (<= the n_prompt the encoder was built for).  embed / tap out [n_used][77][d], feat out [n_used][d]; any may be NULL. */
+int clip_encoder_init_ex(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
+	int clip_skip, bool norm, bool want_feat, int tap_skip);
+int clip_encoder_run_ex(ClipEncoder* E, unsigned n_used, const int* n_tok, const int32_t* const* toks, float* embed, float* tap, float* feat);
 void clip_encoder_free(ClipEncoder* E);
 /* SDXL vector conditioning (src/mlimgsynth.c:1542-1557): [pooled | emb(h,w) | emb(0,0) | emb(h,w)], 256 dims each */
 int sdxl_label_build(const float* feat, int n_feat, int width, int height, float* label, int n_label);

@@ -71,18 +71,26 @@ static MLTensor* mlb_clip_layer(MLCtx* C, MLTensor* x, int d_model, int n_head, 
 }
 
 /* mlb_clip_text, src/clip.c:395-416 */
-static MLTensor* mlb_clip_text(MLCtx* C, MLTensor* tokens, const ClipParams* P, int clip_skip, bool norm)
+static MLTensor* mlb_clip_text(MLCtx* C, MLTensor* tokens, const ClipParams* P, int clip_skip, bool norm, int tap_skip, void** tap_dev)
 {
 	char name[64];
 	mlctx_block_begin(C);
 	MLTensor *x = MLN("embed", mlb_clip_embeddings(C, tokens, P->d_embed, P->n_vocab, P->n_token));
 	int n_layer = P->n_layer;
 	if (clip_skip > 1) n_layer -= clip_skip - 1;
+	const int tap_after = (tap_dev && tap_skip > 0) ? P->n_layer - (tap_skip - 1) : -1;   /* layers run before the tap */
 	mlctx_block_begin(C);   /* mlb_clip_encoder :380-393 */
 	for (int i=0; i<n_layer; ++i) {
 		sprintf(name, "layers.%d", i);
 		x = MLN(name, mlb_clip_layer(C, x, P->d_embed, P->n_head, P->n_interm, true));
 		if (!x) return NULL;
+		if (i + 1 == tap_after) {   /* the next layer consumes x: keep a copy (77 x d floats per prompt) */
+			const size_t nb = (size_t)x->n * x->h * x->w * x->c * sizeof(float);
+			if (!mlt_need32(C, x) || x->ld32 != x->c) { mlctx_fail(C, "clip tap: unexpected layout"); return NULL; }
+			*tap_dev = mlctx_dalloc(C, nb, 1);
+			MLOp *op = mlctx_op_new(C, OP_COPY_F32, "clip_tap_copy");
+			op->u.copy.src = x->d32; op->u.copy.dst = *tap_dev; op->u.copy.nbytes = nb;
+		}
 	}
 	MLN("encoder", x);
 	if (norm) {
@@ -105,49 +113,60 @@ static int param_to_host(MLCtx* C, const char* key, float* out, size_t n)
 }
 
 /* ------------------------------------------------------------------ resident encoder */
-MLB_API int clip_encoder_init(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
-	int clip_skip, bool norm, bool want_feat)
+MLB_API int clip_encoder_init_ex(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
+	int clip_skip, bool norm, bool want_feat, int tap_skip)
 {
 	memset(E, 0, sizeof(*E));
 	if (want_feat) { clip_skip = -1; norm = true; }          /* src/clip.c:446 */
+	if (tap_skip > 0 && (clip_skip > 1 || tap_skip > P->n_layer)) return mlsd_set_error(-1, "clip_encoder_init_ex: a tap needs the whole stack");
 	E->C = C; E->P = *P; E->n_prompt = n_prompt; E->want_feat = want_feat;
 	snprintf(E->prefix, sizeof(E->prefix), "%s", tprefix);
 	mlctx_begin(C, "CLIP text encode");
 	mlctx_set_tprefix(C, tprefix);
 	E->t_tokens = mlctx_input_new_seq(C, "tokens", MLT_I32, P->n_token, n_prompt, 1);
-	E->t_embed = mlb_clip_text(C, E->t_tokens, P, clip_skip, norm);
+	E->t_embed = mlb_clip_text(C, E->t_tokens, P, clip_skip, norm, tap_skip, tap_skip > 0 ? &E->tap_dev : NULL);
 	if (!E->t_embed) return -1;
 	if (want_feat) mlctx_param_new(C, "text_proj", MLT_F32, P->d_embed, P->d_embed, 1, 1, 0, 0, 0);   /* mlb_clip_text_proj :418-427 */
 	mlctx_tensor_add(C, "text", E->t_embed);
 	return mlctx_prep(C);
 }
 
+MLB_API int clip_encoder_init(ClipEncoder* E, MLCtx* C, const ClipParams* P, const char* tprefix, unsigned n_prompt,
+	int clip_skip, bool norm, bool want_feat)
+{
+	return clip_encoder_init_ex(E, C, P, tprefix, n_prompt, clip_skip, norm, want_feat, 0);
+}
+
 MLB_API void clip_encoder_free(ClipEncoder* E) { if (E) { free(E->text_proj_host); E->text_proj_host = NULL; } }
 
-MLB_API int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks, float* embed, float* feat)
+MLB_API int clip_encoder_run_ex(ClipEncoder* E, unsigned n_used, const int* n_tok, const int32_t* const* toks, float* embed, float* tap, float* feat)
 {
 	MLCtx *C = E->C;
 	const ClipParams *P = &E->P;
-	if (n_tok + 2 > (unsigned)P->n_token) return mlsd_set_error(-1, "prompt too long (max: %d)", P->n_token - 2);   /* :449-450 */
-	if (feat && !E->want_feat) return mlsd_set_error(-1, "clip_encoder_run: encoder built without the pooled feature");
 	const int NT = P->n_token, d = P->d_embed;
 	const unsigned n_prompt = E->n_prompt;
+	if (n_used < 1 || n_used > n_prompt) return mlsd_set_error(-1, "clip_encoder_run_ex: %u prompts, encoder built for %u", n_used, n_prompt);
+	for (unsigned p=0;p<n_used;++p) if (n_tok[p] < 0 || n_tok[p] + 2 > NT) return mlsd_set_error(-1, "prompt too long (max: %d)", NT - 2);   /* :449-450 */
+	if (feat && !E->want_feat) return mlsd_set_error(-1, "clip_encoder_run: encoder built without the pooled feature");
+	if (tap && !E->tap_dev) return mlsd_set_error(-1, "clip_encoder_run: encoder built without a tap");
 	int32_t *tokens = (int32_t*)malloc(sizeof(int32_t) * NT * n_prompt);
-	for (unsigned p=0; p<n_prompt; ++p) {                    /* :451-455 */
+	for (unsigned p=0; p<n_prompt; ++p) {                    /* :451-455; slots past n_used repeat prompt 0 (their output is unused) */
+		const unsigned q = p < n_used ? p : 0;
 		int32_t *t = tokens + (size_t)p*NT;
 		t[0] = P->tok_start;
-		memcpy(t+1, toks + (size_t)p*n_tok, sizeof(int32_t)*n_tok);
-		t[n_tok+1] = P->tok_end;
-		for (int i=n_tok+2; i<NT; ++i) t[i] = P->tok_pad;
+		if (n_tok[q]) memcpy(t+1, toks[q], sizeof(int32_t)*n_tok[q]);
+		t[n_tok[q]+1] = P->tok_end;
+		for (int i=n_tok[q]+2; i<NT; ++i) t[i] = P->tok_pad;
 	}
 	int R = 1;
 	float *tmp = NULL;
-	const size_t ne = (size_t)n_prompt * NT * d;
+	const size_t ne = (size_t)n_used * NT * d;
 	if (mlctx_input_set(C, E->t_tokens, tokens, sizeof(int32_t)*NT*n_prompt) < 0) { R = -1; goto end; }
 	if (mlctx_compute(C) < 0) { R = -1; goto end; }
-	tmp = (float*)malloc(ne * 4);
-	if (mlctx_output_get(C, E->t_embed, tmp, ne*4) < 0) { R = -1; goto end; }
+	tmp = (float*)malloc((size_t)n_prompt * NT * d * 4);
+	if (mlctx_output_get(C, E->t_embed, tmp, (size_t)n_prompt*NT*d*4) < 0) { R = -1; goto end; }
 	if (embed) memcpy(embed, tmp, ne*4);
+	if (tap && (mlsd_memcpy(tap, E->tap_dev, ne*4, 1, C->stream) || mlsd_stream_sync(C->stream))) { R = -1; goto end; }
 	if (feat) {
 		/* feat = text_proj^T . x[EOS]  (:428-434): F32 weights and activations in the reference; done on the
 		 * host in double (d*d MACs per prompt) */
@@ -157,14 +176,22 @@ MLB_API int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks
 			if (param_to_host(C, key, E->text_proj_host, (size_t)d*d) < 0) { free(E->text_proj_host); E->text_proj_host = NULL; R = -1; goto end; }
 		}
 		const float *tp = E->text_proj_host;
-		for (unsigned p=0; p<n_prompt; ++p) {
-			const float *xe = tmp + ((size_t)p*NT + n_tok + 1) * d;
+		for (unsigned p=0; p<n_used; ++p) {
+			const float *xe = tmp + ((size_t)p*NT + n_tok[p] + 1) * d;
 			for (int j=0;j<d;++j) { double s=0; for (int i=0;i<d;++i) s += (double)tp[j + (size_t)d*i] * xe[i]; feat[(size_t)p*d + j] = (float)s; }
 		}
 	}
 end:
 	free(tokens); free(tmp);
 	return R;
+}
+
+MLB_API int clip_encoder_run(ClipEncoder* E, unsigned n_tok, const int32_t* toks, float* embed, float* feat)
+{	/* all n_prompt prompts, same length */
+	const int32_t *tp[16]; int nt[16];
+	if (E->n_prompt > 16) return mlsd_set_error(-1, "clip_encoder_run: more than 16 prompts");
+	for (unsigned p=0;p<E->n_prompt;++p) { tp[p] = toks + (size_t)p*n_tok; nt[p] = (int)n_tok; }
+	return clip_encoder_run_ex(E, E->n_prompt, nt, tp, embed, NULL, feat);
 }
 
 /* clip_text_encode, src/clip.c:439-488 (one-shot: build, load, run, free), for n_prompt prompts */

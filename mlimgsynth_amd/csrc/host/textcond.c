@@ -16,7 +16,7 @@ struct MLIS_AmdTextCond {
 	int width, height, xl;
 	int n_enc;
 	MLCtx* ctx[3];
-	ClipEncoder enc[3];     /* SD1: [0] ; SDXL: [0] CLIP-L embed, [1] bigG embed (skip 2), [2] bigG pooled feature */
+	ClipEncoder enc[3];     /* SD1: [0] ; SDXL: [0] CLIP-L embed, [1] bigG: embed (tap at clip_skip) + pooled feature in one run */
 	int n_ctx, n_label;
 	float *e1, *e2, *feat;
 };
@@ -40,7 +40,9 @@ static int tower_add(MLIS_AmdTextCond* T, const char* tower, const char* prefix,
 	T->ctx[i] = mlctx_new(stream);
 	if (!T->ctx[i]) return mlsd_set_error(-1, "textcond: mlctx_new failed");
 	T->n_enc = i + 1;
-	if (clip_encoder_init(&T->enc[i], T->ctx[i], &P, prefix, 1, clip_skip, norm, want_feat) < 0) return -1;
+	/* built for TWO prompts (prompt + negative prompt go through a tower in one run); want_feat towers also tap the un-normed
+	 * hidden state clip_skip layers from the end, so SDXL's bigG runs once for embedding and pooled feature */
+	if (clip_encoder_init_ex(&T->enc[i], T->ctx[i], &P, prefix, 2, want_feat ? 1 : clip_skip, norm, want_feat, want_feat ? clip_skip : 0) < 0) return -1;
 	if (!g_defer && mlctx_params_synth(T->ctx[i], seed) < 0) return -1;
 	return 1;
 }
@@ -70,8 +72,7 @@ MLB_API MLIS_AmdTextCond* mlis_amd_textcond_create_ex(const char* model, int wid
 		const int skip = clip_skip > 0 ? clip_skip : 2;
 		T->xl = 1;
 		rc = tower_add(T, t1, "clip", skip, false, false, weight_seed, stream);
-		if (rc > 0) rc = tower_add(T, t2, "clip2", skip, false, false, weight_seed, stream);
-		if (rc > 0) rc = tower_add(T, t2, "clip2", 1, true, true, weight_seed, stream);
+		if (rc > 0) rc = tower_add(T, t2, "clip2", skip, true, true, weight_seed, stream);   /* embedding (tap, clip_skip, no norm) + pooled feature */
 	} else mlsd_set_error(-1, "textcond: unknown model '%s'", T->model);
 	g_defer = 0;
 	if (rc < 0) { mlis_amd_textcond_destroy(T); return NULL; }
@@ -120,32 +121,57 @@ MLB_API int mlis_amd_textcond_encode_w(MLIS_AmdTextCond* T, const int32_t* toks,
 	return 1;
 }
 
+/* n (1 or 2) prompts through every tower in ONE run each; cond[p] [77][n_ctx], label[p] [n_label] */
+static int encode_n(MLIS_AmdTextCond* T, int n, const int32_t* const* toks, const int* n_tok, float* const* cond, float* const* label)
+{
+	static const int32_t none = 0;
+	const int32_t *tp[2]; int nt[2];
+	for (int p=0;p<n;++p) {
+		if (!cond[p] || n_tok[p] < 0 || (n_tok[p] && !toks[p])) return mlsd_set_error(-1, "textcond_encode: bad arguments");
+		tp[p] = toks[p] ? toks[p] : &none; nt[p] = n_tok[p];
+	}
+	const int d1 = T->enc[0].P.d_embed, NT = T->enc[0].P.n_token;
+	if (!T->xl) {
+		if (n == 1) return clip_encoder_run_ex(&T->enc[0], 1, nt, tp, cond[0], NULL, NULL);
+		float *e = (float*)malloc(sizeof(float) * 2 * NT * (size_t)d1);
+		int r = e ? clip_encoder_run_ex(&T->enc[0], 2, nt, tp, e, NULL, NULL) : mlsd_set_error(-1, "textcond: out of memory");
+		if (r > 0) for (int p=0;p<2;++p) memcpy(cond[p], e + (size_t)p*NT*d1, sizeof(float)*NT*(size_t)d1);
+		free(e);
+		return r;
+	}
+	const int d2 = T->enc[1].P.d_embed;
+	for (int p=0;p<n;++p) if (!label[p]) return mlsd_set_error(-1, "textcond_encode: SDXL needs a label output");
+	float *e1 = (float*)malloc(sizeof(float) * n * NT * (size_t)(d1 + d2) + sizeof(float) * n * (size_t)d2);
+	if (!e1) return mlsd_set_error(-1, "textcond: out of memory");
+	float *e2 = e1 + (size_t)n*NT*d1, *ft = e2 + (size_t)n*NT*d2;
+	int r = clip_encoder_run_ex(&T->enc[0], (unsigned)n, nt, tp, e1, NULL, NULL);
+	if (r > 0) r = clip_encoder_run_ex(&T->enc[1], (unsigned)n, nt, tp, NULL, e2, ft);      /* tap = embedding, final = pooled feature */
+	for (int p=0; p<n && r>0; ++p) {
+		for (int t=0;t<NT;++t) {   /* concat along the embedding axis, src/mlimgsynth.c:1530-1539 */
+			memcpy(cond[p] + (size_t)t * (d1 + d2), e1 + ((size_t)p*NT + t) * d1, sizeof(float) * d1);
+			memcpy(cond[p] + (size_t)t * (d1 + d2) + d1, e2 + ((size_t)p*NT + t) * d2, sizeof(float) * d2);
+		}
+		if (!strcmp(T->model, "sdxl")) r = sdxl_label_build(ft + (size_t)p*d2, d2, T->width, T->height, label[p], T->n_label);
+		else { memcpy(label[p], ft + (size_t)p*d2, sizeof(float) * d2); memset(label[p] + d2, 0, sizeof(float) * (size_t)(T->n_label - d2)); }
+	}
+	free(e1);
+	return r;
+}
+
 MLB_API int mlis_amd_textcond_encode(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, float* cond, float* label)
 {
-	if (!T || !cond || n_tok < 0 || (n_tok && !toks)) return mlsd_set_error(-1, "textcond_encode: bad arguments");
-	static const int32_t none = 0;
-	if (!toks) toks = &none;
-	if (!T->xl) return clip_encoder_run(&T->enc[0], (unsigned)n_tok, toks, cond, NULL);
-	if (!label) return mlsd_set_error(-1, "textcond_encode: SDXL needs a label output");
-	const int d1 = T->enc[0].P.d_embed, d2 = T->enc[1].P.d_embed, nt = T->enc[0].P.n_token;
-	if (clip_encoder_run(&T->enc[0], (unsigned)n_tok, toks, T->e1, NULL) < 0) return -1;
-	if (clip_encoder_run(&T->enc[1], (unsigned)n_tok, toks, T->e2, NULL) < 0) return -1;
-	if (clip_encoder_run(&T->enc[2], (unsigned)n_tok, toks, NULL, T->feat) < 0) return -1;
-	for (int t=0;t<nt;++t) {   /* concat along the embedding axis, src/mlimgsynth.c:1530-1539 */
-		memcpy(cond + (size_t)t * (d1 + d2), T->e1 + (size_t)t * d1, sizeof(float) * d1);
-		memcpy(cond + (size_t)t * (d1 + d2) + d1, T->e2 + (size_t)t * d2, sizeof(float) * d2);
-	}
-	if (!strcmp(T->model, "sdxl")) return sdxl_label_build(T->feat, d2, T->width, T->height, label, T->n_label);
-	memcpy(label, T->feat, sizeof(float) * d2);
-	memset(label + d2, 0, sizeof(float) * (size_t)(T->n_label - d2));
-	return 1;
+	if (!T) return mlsd_set_error(-1, "textcond_encode: bad arguments");
+	const int32_t *tp[1] = { toks }; float *c[1] = { cond }, *l[1] = { label };
+	return encode_n(T, 1, tp, &n_tok, c, l);
 }
 
 MLB_API int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg,
 	float* cond, float* label, float* ncond, float* nlabel)
 {
-	if (mlis_amd_textcond_encode(T, toks, n_tok, cond, label) < 0) return -1;
-	if (mlis_amd_textcond_encode(T, neg, n_neg, ncond, nlabel) < 0) return -1;
+	if (!T) return mlsd_set_error(-1, "textcond_encode: bad arguments");
+	const int32_t *tp[2] = { toks, neg }; const int nt[2] = { n_tok, n_neg };
+	float *c[2] = { cond, ncond }, *l[2] = { label, nlabel };
+	if (encode_n(T, 2, tp, nt, c, l) < 0) return -1;
 	if (T->xl && n_neg == 0) memset(ncond, 0, sizeof(float) * 77 * (size_t)T->n_ctx);
 	return 1;
 }

@@ -10,7 +10,7 @@ from .engine import ClipParams, FP, MLCtx, _proto2, c_int, fptr
 
 class ClipEncoderS(ctypes.Structure):
     _fields_ = [("C", vp), ("P", ClipParams), ("t_tokens", vp), ("t_embed", vp), ("n_prompt", ctypes.c_uint),
-                ("want_feat", c_int), ("prefix", ctypes.c_char * 16), ("text_proj_host", vp)]
+                ("want_feat", c_int), ("prefix", ctypes.c_char * 16), ("text_proj_host", vp), ("t_tap", vp), ("tap_dev", vp)]
 
 
 def _l():
