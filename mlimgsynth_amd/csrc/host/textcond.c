@@ -18,14 +18,12 @@ struct MLIS_AmdTextCond {
 	MLCtx* ctx[3];
 	ClipEncoder enc[3];     /* SD1: [0] ; SDXL: [0] CLIP-L embed, [1] bigG: embed (tap at clip_skip) + pooled feature in one run */
 	int n_ctx, n_label;
-	float *e1, *e2, *feat;
 };
 
 MLB_API void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T)
 {
 	if (!T) return;
 	for (int i=0;i<T->n_enc;++i) { clip_encoder_free(&T->enc[i]); if (T->ctx[i]) mlctx_destroy(T->ctx[i]); }
-	free(T->e1); free(T->e2); free(T->feat);
 	free(T);
 }
 
@@ -80,10 +78,6 @@ MLB_API MLIS_AmdTextCond* mlis_amd_textcond_create_ex(const char* model, int wid
 	T->n_ctx = d1 + d2;
 	/* tinyxl: adm = 64 + 32 (shrunken size embedding, zeros) so the UNet's label width stays a multiple of 32 */
 	T->n_label = !T->xl ? 0 : (!strcmp(T->model, "sdxl") ? d2 + 1536 : d2 + 32);
-	T->e1 = malloc(sizeof(float) * 77 * (size_t)d1);
-	T->e2 = T->xl ? malloc(sizeof(float) * 77 * (size_t)d2) : NULL;
-	T->feat = T->xl ? malloc(sizeof(float) * (size_t)d2) : NULL;
-	if (!T->e1 || (T->xl && (!T->e2 || !T->feat))) { mlis_amd_textcond_destroy(T); mlsd_set_error(-1, "textcond: out of memory"); return NULL; }
 	return T;
 }
 
