@@ -30,6 +30,28 @@ for (pp, M, N, K, act) in cases:
                 bad += 1
                 print("MISMATCH", pp, M, N, K, "at launch", r)
     print(f"gemm pp{pp} {M}x{N}x{K} act{act}: {reps} launches ok" if not bad else "...")
+# compiled-in epilogue bodies (round 2): fp32 + residual with column statistics (output AND statistics must repeat), fp16 fast path
+for (pp, M, N, K) in [(18, 8192, 1280, 1280), (17, 8192, 3840, 1280), (18, 32768, 640, 2560)]:
+    dA = _lib.from_numpy(rng.standard_normal((M, K)).astype(np.float16))
+    dW = _lib.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
+    dR = _lib.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    dC32, dC16, dS = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M // 64 * 2 * N * 4)
+    for kind in ("f32+res+stats", "f16"):
+        a = kernels.GemmArgs(A=dA.ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K, tile_variant=pp + 1)
+        if kind == "f16":
+            a.C16, a.ldc16 = dC16.ptr, N
+        else:
+            a.C32, a.ldc32, a.resid, a.ldr, a.colstats = dC32.ptr, N, dR.ptr, N, dS.ptr
+        kernels.gemm(a)
+        get = (lambda: dC16.download((M, N), np.float16).view(np.uint16).copy()) if kind == "f16" else \
+              (lambda: np.concatenate([dC32.download((M * N,), np.float32).view(np.uint32), dS.download((M // (64 if pp == 18 else 128) * 2 * N,), np.float32).view(np.uint32)]))
+        first = get()
+        for r in range(reps // 2):
+            kernels.gemm(a)
+            if r % 100 == 99 or r == reps // 2 - 1:
+                if not np.array_equal(get(), first):
+                    bad += 1; print("MISMATCH", kind, pp, M, N, K, "at launch", r)
+        print(f"gemm pp{pp} {M}x{N}x{K} {kind}: {reps // 2} launches ok")
 # conv case
 n, h, w, cin, cout = 8, 32, 32, 1280, 1280
 x = _lib.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float16))
@@ -59,5 +81,17 @@ for e in range(evals):
     if not np.array_equal(un.run(xx, cond, label, sigma).view(np.uint32), first.view(np.uint32)):
         bad += 1; print("MISMATCH unet eval", e)
 print(f"sdxl plan 64x64 N=4: {evals} evaluations ok" if not bad else "...")
+# the headline plan (producer statistics, batched projections, compiled-in tile table): fewer evaluations, it is 8x the work
+un.ctx.destroy()
+un = engine.Unet("sdxl", 128, 128, 8)
+xx = rng.standard_normal((8, 4, 128, 128)).astype(np.float32) * 3
+cond = rng.standard_normal((8, 77, P.n_ctx)).astype(np.float32)
+label = rng.standard_normal((8, P.ch_adm_in)).astype(np.float32)
+sigma = np.array([7.0, 0.5, 2.0, 14.0, 1.0, 3.0, 0.1, 9.0], np.float32)
+first = un.run(xx, cond, label, sigma)
+for e in range(max(evals // 4, 10)):
+    if not np.array_equal(un.run(xx, cond, label, sigma).view(np.uint32), first.view(np.uint32)):
+        bad += 1; print("MISMATCH headline unet eval", e)
+print(f"sdxl plan 128x128 N=8: {max(evals // 4, 10)} evaluations ok" if not bad else "...")
 print("SOAK", "FAILED" if bad else "PASSED", f"({time.time() - t0:.0f} s)")
 sys.exit(1 if bad else 0)
