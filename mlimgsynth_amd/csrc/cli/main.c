@@ -512,9 +512,9 @@ int main(int argc, char** argv)
 	else if (!strcmp(C.cmd, "clip-encode")) r = cmd_text(&C, 1);
 	else if (!strcmp(C.cmd, "tokenize")) r = cmd_text(&C, 0);
 	else if (!strcmp(C.cmd, "convert")) {          /* image I/O only: --input (PNG / PNM) -> --output (PNG / PNM by extension) */
-		Img im; r = (C.in_img && C.out_img) ? img_read(C.in_img, &im) : -1;
-		if (r < 0) fprintf(stderr, "error: convert needs --input and --output\n");
-		else { r = img_write(C.out_img, im.d, im.w, im.h, im.c, NULL); free(im.d); }
+		Img im; r = -1;
+		if (!C.in_img || !C.out_img) fprintf(stderr, "error: convert needs --input and --output\n");
+		else if ((r = img_read(C.in_img, &im)) > 0) { r = img_write(C.out_img, im.d, im.w, im.h, im.c, NULL); free(im.d); }
 	}
 	else if (!strcmp(C.cmd, "check")) { fprintf(stderr, "error: 'check' is not implemented (neither in the reference: main_mlimgsynth.c:605-611)\n"); r = -1; }
 	else { fprintf(stderr, "error: Unknown command '%s'\n", C.cmd); r = -1; }

@@ -145,6 +145,19 @@ static void dequant_blocks(int t, const unsigned char* b, int64_t n, float* o)
 	}
 }
 
+/* element count of a shape read from a file, or -1 if a dimension or the product is out of range (corrupt headers must not
+ * overflow the size arithmetic: no tensor of a checkpoint has more than 2^40 elements) */
+static int64_t shape_count(const uint64_t* dims, int nd)
+{
+	uint64_t n = 1;
+	for (int i=0;i<nd;++i) {
+		if (dims[i] > 0xffffffffull) return -1;
+		if (dims[i] && n > ((uint64_t)1 << 40) / dims[i]) return -1;
+		n *= dims[i];
+	}
+	return (int64_t)n;
+}
+
 static MLTSEntry* ts_add(MLTStore* S, const char* name, const MLTSEntry* src)
 {
 	for (int i=0;i<S->n;++i) if (!strcmp(S->e[i].name, name)) {   /* tstore_tensor_add replaces an existing key */
@@ -259,6 +272,7 @@ static int parse_safetensors(MLTStore* S, const char* path, int mode)
 		} while (j_eat(&c, ','));
 		if (!j_eat(&c, '}') || have != 7) goto bad;
 		if (nd > 4) return mlsd_set_error(-1, "safetensors tensor '%s': %d dimensions", name, nd);
+		if (shape_count(shp, nd) < 0) return mlsd_set_error(-1, "safetensors tensor '%s': shape out of range", name);
 		if (off1 < off0 || off1 > data_size) return mlsd_set_error(-1, "safetensors tensor '%s': invalid offsets", name);
 		e.n_dim = nd;
 		for (int i=0;i<4;++i) e.shape[i] = 1;
@@ -334,6 +348,8 @@ static int parse_gguf(MLTStore* S, const char* path, int mode)
 		if (g_string(&c, names[i], 512, 256) < 0 || !names[i][0] || g_take(&c, &nd, 4) < 0 || nd > 4 || g_take(&c, dims, 8*(size_t)nd) < 0 ||
 		    g_take(&c, &gt, 4) < 0 || g_take(&c, &off, 8) < 0) { R = mlsd_set_error(-1, "'%s': malformed GGUF tensor entry %llu", path, (unsigned long long)i); break; }
 		for (int d=0;d<4;++d) if (dims[d] > 0xffffff) R = mlsd_set_error(-1, "gguf tensor '%s': dimension overflow", names[i]);
+		if (R > 0 && shape_count(dims, 4) < 0) R = mlsd_set_error(-1, "gguf tensor '%s': shape out of range", names[i]);
+		if (R < 0) break;
 		MLTSEntry *e = &tmp[i];
 		e->dtype = gguf_dtype(gt);
 		if (e->dtype < 0) { R = mlsd_set_error(-1, "gguf tensor '%s': unknown tensor type %u", names[i], gt); break; }
