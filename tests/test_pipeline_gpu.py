@@ -263,3 +263,32 @@ def test_bench_two_gpu_smoke_when_available():
     import json
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
+
+
+def test_bench_json_contract_on_tiny_workload():
+    """bench.py prints ONE JSON line with the driver's contract keys plus the `roofline` and `cpu_baseline` objects (run on the
+    tiny workload so that the CPU leg takes a second); values are sane and the metric / config follow BASELINE.json's wording"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "tiny"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert "vs_baseline" in d and d["vs_baseline"] is None                     # BASELINE.md publishes no number for this metric
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "images/s" and d["value"] > 0 and d["dtype"] == "f16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] in (8000.0, 2500.0)
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "kernel" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] and c["value"] > 0 and c["unit"] == "images/s" and "oracle" in c["sample"]
+    assert d["value"] > 50 * c["value"]                                          # a GPU against a CPU port, even on the tiny model
