@@ -155,6 +155,8 @@ MLCtx* mlis_amd_textcond_ctx(MLIS_AmdTextCond* T, int i);
 int mlis_amd_textcond_set_size(MLIS_AmdTextCond* T, int width, int height);     /* SDXL size embeddings of the label */
 /* with per-token weights (prompt emphasis, src/mlimgsynth.c:1457-1463); weights NULL = all 1 */
 int mlis_amd_textcond_encode_w(MLIS_AmdTextCond* T, const int32_t* toks, const float* weights, int n_tok, float* cond, float* label);
+int mlis_amd_textcond_encode_pair_w(MLIS_AmdTextCond* T, const int32_t* toks, const float* w, int n_tok,
+	const int32_t* neg, const float* nw, int n_neg, float* cond, float* label, float* ncond, float* nlabel);   /* both prompts, one run per tower */
 void mlis_amd_textcond_destroy(MLIS_AmdTextCond* T);
 int mlis_amd_textcond_dims(const MLIS_AmdTextCond* T, int* n_ctx, int* n_label);
 double mlis_amd_textcond_flops(const MLIS_AmdTextCond* T);

@@ -754,28 +754,42 @@ MLB_API int mlis_clip_text_encode(MLIS_Ctx* S, const char* text, MLIS_Tensor* em
 	return r < 0 ? r : 1;
 }
 
-/* mlis_text_cond_encode :1501-1563 for the prompt (neg = 0) or the negative prompt */
-static int text_cond_encode(MLIS_Ctx* S, int neg, MLIS_Tensor* cond, MLIS_Tensor* label, int w, int h)
+/* tokens + emphasis weights of the prompt (neg = 0) or the negative prompt: explicit ids or the parsed prompt text */
+static int prompt_tokens(MLIS_Ctx* S, int neg, int32_t** ptok, float** ptw)
 {
-	int32_t *tok = NULL; float *tw = NULL; int n;
 	if (S->have_ptok[neg]) {
-		n = S->n_ptok[neg];
-		tok = (int32_t*)malloc(sizeof(int32_t)*(n ? n : 1)); tw = (float*)malloc(sizeof(float)*(n ? n : 1));
-		memcpy(tok, S->ptok[neg], sizeof(int32_t)*n); memcpy(tw, S->ptokw[neg], sizeof(float)*n);
-	} else {
-		MLISPrompt *P = neg ? &S->nprompt : &S->prompt;
-		if (!P->n_chunk) mlis_prompt_set_raw(P, "");
-		n = prompt_tokenize(S, P, &tok, &tw);
-		if (n < 0) return n;
+		const int n = S->n_ptok[neg];
+		*ptok = (int32_t*)malloc(sizeof(int32_t)*(n ? n : 1)); *ptw = (float*)malloc(sizeof(float)*(n ? n : 1));
+		memcpy(*ptok, S->ptok[neg], sizeof(int32_t)*n); memcpy(*ptw, S->ptokw[neg], sizeof(float)*n);
+		return n;
 	}
-	if (textcond_get(S, w, h) < 0) { free(tok); free(tw); return -1; }
+	MLISPrompt *P = neg ? &S->nprompt : &S->prompt;
+	if (!P->n_chunk) mlis_prompt_set_raw(P, "");
+	return prompt_tokenize(S, P, ptok, ptw);
+}
+
+/* mlis_text_cond_encode :1501-1563 for the prompt and (with_neg) the negative prompt: one run per tower for both */
+static int text_cond_encode(MLIS_Ctx* S, int with_neg, int w, int h)
+{
+	int32_t *tok[2] = {NULL, NULL}; float *tw[2] = {NULL, NULL}; int n[2] = {0, 0};
+	int r = -1;
+	if ((n[0] = prompt_tokens(S, 0, &tok[0], &tw[0])) < 0) { r = n[0]; goto end; }
+	if (with_neg && (n[1] = prompt_tokens(S, 1, &tok[1], &tw[1])) < 0) { r = n[1]; goto end; }
+	if (textcond_get(S, w, h) < 0) goto end;
 	int n_ctx = 0, n_label = 0;
 	mlis_amd_textcond_dims(S->tc, &n_ctx, &n_label);
-	mlis_tensor_resize(cond, n_ctx, 77, 1, 1);
-	if (n_label) mlis_tensor_resize(label, n_label, 1, 1, 1);
-	int r = mlis_amd_textcond_encode_w(S->tc, tok, tw, n, cond->d, n_label ? label->d : NULL);
-	free(tok); free(tw);
-	return r < 0 ? api_error_lib(S, MLIS_E_UNKNOWN) : 1;
+	mlis_tensor_resize(&S->cond, n_ctx, 77, 1, 1);
+	if (n_label) mlis_tensor_resize(&S->label, n_label, 1, 1, 1);
+	if (with_neg) {
+		mlis_tensor_resize(&S->ncond, n_ctx, 77, 1, 1);
+		if (n_label) mlis_tensor_resize(&S->nlabel, n_label, 1, 1, 1);
+		r = mlis_amd_textcond_encode_pair_w(S->tc, tok[0], tw[0], n[0], tok[1], tw[1], n[1], S->cond.d, n_label ? S->label.d : NULL,
+			S->ncond.d, n_label ? S->nlabel.d : NULL);
+	} else r = mlis_amd_textcond_encode_w(S->tc, tok[0], tw[0], n[0], S->cond.d, n_label ? S->label.d : NULL);
+	if (r < 0) r = api_error_lib(S, MLIS_E_UNKNOWN);
+end:
+	free(tok[0]); free(tw[0]); free(tok[1]); free(tw[1]);
+	return r < 0 ? r : 1;
 }
 
 /* ------------------------------------------------------------------ codec */
@@ -947,9 +961,8 @@ MLB_API int mlis_generate(MLIS_Ctx* S)
 
 	/* conditioning (:1688-1707) */
 	if (!(S->tuflags & MLIS_TUF_CONDITIONING)) {
-		if ((r = text_cond_encode(S, 0, &S->cond, &S->label, w_img, h_img)) < 0) return r;
+		if ((r = text_cond_encode(S, S->cfg_scale > 1, w_img, h_img)) < 0) return r;
 		if (S->cfg_scale > 1) {
-			if ((r = text_cond_encode(S, 1, &S->ncond, &S->nlabel, w_img, h_img)) < 0) return r;
 			UnetParams U; unet_params_get(S->mname, &U);
 			const int neg_empty = S->have_ptok[1] ? S->n_ptok[1] == 0 : str_empty(S->nprompt_raw);
 			if (U.uncond_empty_zero && neg_empty) memset(S->ncond.d, 0, mlis_tensor_count(&S->ncond) * 4);   /* :1702-1703 */

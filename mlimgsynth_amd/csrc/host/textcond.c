@@ -170,6 +170,19 @@ MLB_API int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* to
 	return 1;
 }
 
+/* the pair with token weights (prompt emphasis) on both prompts: what mlis_generate needs, one run per tower */
+MLB_API int mlis_amd_textcond_encode_pair_w(MLIS_AmdTextCond* T, const int32_t* toks, const float* w, int n_tok,
+	const int32_t* neg, const float* nw, int n_neg, float* cond, float* label, float* ncond, float* nlabel)
+{
+	if (!T) return mlsd_set_error(-1, "textcond_encode: bad arguments");
+	const int32_t *tp[2] = { toks, neg }; const int nt[2] = { n_tok, n_neg };
+	float *c[2] = { cond, ncond }, *l[2] = { label, nlabel };
+	if (encode_n(T, 2, tp, nt, c, l) < 0) return -1;
+	apply_token_weights(cond, T->n_ctx, n_tok, w);
+	apply_token_weights(ncond, T->n_ctx, n_neg, nw);
+	return 1;
+}
+
 /* mlis_text_cond_encode for prompt + negative prompt straight into an engine's conditioning inputs (no caller-side staging):
  * what mlis_generate does between :1688 and :1707, as one library call for launchers (bench.py, multi-GPU rank 0) */
 MLB_API int mlis_amd_textcond_apply(MLIS_AmdTextCond* T, MLIS_AmdCtx* E, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg)
