@@ -192,6 +192,7 @@ int mlsd_groupnorm(const mlsd_gn_args* a, void* stream);
  * y fp16 [rows][d] (and/or y32 fp32 [rows][d]) */
 int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float eps, const float* gamma,
                    const float* beta, void* y16, float* y32, void* stream);
+void mlsd_layernorm_stream_blocks(int n);   /* diagnostics / A-B timing: blocks of the streaming form (default 1024), 0 = one row per wave */
 
 /* ---------------------------------------------------------------- small ops */
 /* NCHW fp32 [n_src][C][HW] -> NHWC fp16 [n_dst][HW][Cpad] (channels >= C zero-filled);

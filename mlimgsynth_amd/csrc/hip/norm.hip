@@ -15,6 +15,7 @@
 // LayerNorm (reference: ggml_norm + mul + add, src/mlblock_nn.c:58-75): one wavefront per row,
 //   row held in registers, two-pass mean/variance, fp16 (and/or fp32) output.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "mlsd_kernels.h"
 
@@ -335,6 +336,70 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, lo
     }
 }
 
+// Streaming form for many rows: a wave walks rows w, w + W, w + 2W, ... and fetches its next row before it reduces the current
+// one.  With one row per wave (ln_kernel at 8192 rows = exactly one resident round) the whole chip first reads, then reduces,
+// then writes, in step; here reads of row i+1 overlap the statistics and the stores of row i.  NQ = float4 per lane.
+int g_ln_stream_blocks = 1024;  // blocks of 4 waves (4 per CU): measured best of 256..2048 at 8192 x 1280 and 32768 x 640
+
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_stream_kernel(const float* __restrict__ x, long ldx, int rows, int d, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        _Float16* __restrict__ y16, float* __restrict__ y32)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int Q = d >> 2;
+    float4 g[NQ], b[NQ], cur[NQ], nxt[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = lane + i * 64;
+        const bool in = q < Q;
+        g[i] = in ? *reinterpret_cast<const float4*>(gamma + q * 4) : make_float4(0, 0, 0, 0);
+        b[i] = (in && beta) ? *reinterpret_cast<const float4*>(beta + q * 4) : make_float4(0, 0, 0, 0);
+        cur[i] = in ? *reinterpret_cast<const float4*>(x + (long)row * ldx + q * 4) : make_float4(0, 0, 0, 0);
+    }
+    for (; row < rows; row += nw) {
+        const int nrow = row + nw;
+        if (nrow < rows) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int q = lane + i * 64;
+                nxt[i] = q < Q ? *reinterpret_cast<const float4*>(x + (long)nrow * ldx + q * 4) : make_float4(0, 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) s += (cur[i].x + cur[i].y) + (cur[i].z + cur[i].w);
+        const float mean = wave_sum(s) / (float)d;            // (the same operations as ln_kernel: bit-identical results)
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (lane + i * 64 < Q) {
+                cur[i].x -= mean; cur[i].y -= mean; cur[i].z -= mean; cur[i].w -= mean;
+                s2 += (cur[i].x * cur[i].x + cur[i].y * cur[i].y) + (cur[i].z * cur[i].z + cur[i].w * cur[i].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lane + i * 64;
+            if (q < Q) {
+                const float y0 = cur[i].x * rstd * g[i].x + b[i].x, y1 = cur[i].y * rstd * g[i].y + b[i].y;
+                const float y2 = cur[i].z * rstd * g[i].z + b[i].z, y3 = cur[i].w * rstd * g[i].w + b[i].w;
+                if (y16) {
+                    f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+                    *reinterpret_cast<f16x4*>(y16 + (long)row * d + q * 4) = h;
+                }
+                if (y32) *reinterpret_cast<float4*>(y32 + (long)row * d + q * 4) = make_float4(y0, y1, y2, y3);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) cur[i] = nxt[i];
+    }
+}
+
 // ---------------------------------------------------------------- row softmax (VAE mid attention)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, long ld_in, _Float16* __restrict__ out,
                                                            long ld_out, int rows, int cols, float scale)
@@ -454,10 +519,22 @@ MLSD_API int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float 
 {
     if ((d & 3) || d > 64 * 4 * LN_MAXQ || (ldx & 3)) return mlsd_set_error(-1, "mlsd_layernorm: unsupported d=%d ldx=%ld", d, (long)ldx);
     if (rows <= 0) return 0;
+    const int nq = (d / 4 + 63) / 64;
+    static const int env_blocks = [] { const char* e = getenv("MLSD_LN_STREAM_BLOCKS"); return e && *e ? atoi(e) : -1; }();   // A/B timing of whole plans
+    if (env_blocks >= 0) g_ln_stream_blocks = env_blocks;
+    if (g_ln_stream_blocks > 0 && rows > 4 * g_ln_stream_blocks && nq >= 2 && nq <= 5) {       // several rows per wave: the streaming form
+        const dim3 grid(g_ln_stream_blocks), block(256);
+#define MLSD_LN_STREAM(NQ) hipLaunchKernelGGL(ln_stream_kernel<NQ>, grid, block, 0, (hipStream_t)stream, x, (long)ldx, rows, d, eps, gamma, beta, (_Float16*)y16, y32)
+        switch (nq) { case 2: MLSD_LN_STREAM(2); break; case 3: MLSD_LN_STREAM(3); break; case 4: MLSD_LN_STREAM(4); break; default: MLSD_LN_STREAM(5); break; }
+#undef MLSD_LN_STREAM
+        return mlsd_check_launch("ln_stream_kernel");
+    }
     hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, d, eps, gamma,
                        beta, (_Float16*)y16, y32);
     return mlsd_check_launch("ln_kernel");
 }
+
+MLSD_API void mlsd_layernorm_stream_blocks(int n) { g_ln_stream_blocks = n; }   /* diagnostics / A-B timing: 0 = one row per wave always */
 
 MLSD_API int mlsd_softmax_rows(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
                                float scale, void* stream)
