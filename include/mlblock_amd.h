@@ -33,6 +33,7 @@ enum MLCtxFlags {           /* src/mlblock.h:29-36 */
 	MLB_F_DUMP = 4,
 	MLB_F_HIPGRAPH = 8,     /* new: capture the plan into a hipGraph at prep and replay it */
 	MLB_F_OPSHAPES = 16,    /* diagnostics: mlctx_op_info labels GEMMs with their MxNxK */
+	MLB_F_SYNTH_PARAMS = 32,/* mlctx_run_ fills the parameters with the deterministic synthetic weights (seed 1234) when no tensor store is attached */
 };
 
 /* ---- context lifecycle (mlctx_begin/end/prep/compute: src/mlblock.c:54-345) */
@@ -67,6 +68,31 @@ void mlctx_free(MLCtx* C);                /* reference name of mlctx_destroy (sr
  * Host data is in the reference layout (ne[0] fastest: NCHW fp32 for images). */
 int mlctx_input_set(MLCtx* C, MLTensor* t, const void* host_data, size_t nbytes);
 int mlctx_output_get(MLCtx* C, MLTensor* t, float* host_out, size_t nbytes);
+/* LocalTensor: the reference's host fp32 tensor (src/localtensor.h:16-27) and the calls the model drivers make on it
+ * (ltensor_to_backend / ltensor_from_backend :96-106, ltensor_finite_check src/localtensor.c:63-69, resize / free :46-58,
+ * shape check :113-120).  n[0] is the fastest dimension (images: n = {W, H, C, N}, data NCHW; sequences: {C, T, N, 1}). */
+typedef struct LocalTensor {
+	float* d;
+	int n[4];
+	int flags;
+} LocalTensor;
+enum { LT_F_OWNMEM = 1, LT_F_READY = 2 };
+size_t ltensor_nelements(const LocalTensor* S);
+size_t ltensor_nbytes(const LocalTensor* S);
+void   ltensor_resize(LocalTensor* S, int n0, int n1, int n2, int n3);   /* owns (re)allocated memory afterwards */
+void   ltensor_free(LocalTensor* S);
+int    ltensor_shape_check(const LocalTensor* S, int n0, int n1, int n2, int n3);   /* n# <= 0: any; 1 ok, -1 mismatch */
+int    ltensor_finite_check(const LocalTensor* S);                                    /* 1 all finite, -1 otherwise */
+int    ltensor_to_backend(MLCtx* C, const LocalTensor* S, MLTensor* input);           /* sizes must agree (the reference asserts) */
+int    ltensor_from_backend(MLCtx* C, LocalTensor* S, MLTensor* t);                   /* resizes S to t's reference shape */
+/* "all in one" of the reference (src/mlblock.c:324-345): prep, upload the NULL-terminated inputs in the order the plan
+ * declared them, compute, read the result (the last tensor) into `out` (may be NULL), then release the plan's memory
+ * (mlctx_end).  Parameters must be loadable at prep time: they are taken from the tensor store given to mlctx_tstore_set,
+ * or synthesised when MLB_F_SYNTH_PARAMS is set (tests). */
+int mlctx_run_(MLCtx* C, LocalTensor* out, const LocalTensor** inputs);
+struct MLTStore;
+void mlctx_set_tstore(MLCtx* C, const struct MLTStore* S);   /* C->tstore of the reference (src/mlblock.h:58): where mlctx_run_ takes the parameters from */
+#define mlctx_run(C,O,...) mlctx_run_((C), (O), (const LocalTensor*[]){ __VA_ARGS__, NULL })
 /* device-side access for callers that keep data resident (the sampler): pointer to the input's staging
  * buffer in the reference layout (fp32 NCHW / int32) */
 void* mlctx_input_device_ptr(MLTensor* t);

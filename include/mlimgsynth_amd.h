@@ -48,9 +48,8 @@ typedef struct {
 	MLTensor *t_x, *t_t, *t_c, *t_l, *t_out;
 } UnetState;
 
-/* host tensor of the reference's boundary (LocalTensor, src/localtensor.h:16-27 == MLIS_Tensor, include/mlimgsynth.h:409-413):
- * fp32, shape n[0] fastest, flags LT_F_OWNMEM = 1 / LT_F_READY = 2 */
-typedef struct LocalTensor { float* d; int n[4]; int flags; } LocalTensor;
+/* (LocalTensor, the host tensor of the reference's boundary == MLIS_Tensor of include/mlimgsynth.h:409-413, and its ltensor_*
+ * calls are declared in mlblock_amd.h) */
 
 /* the reference's own entry points, same signatures (src/unet.h:55-62): batch 1, graph built at init, weights loaded afterwards
  * (mlctx_params_synth / mlctx_tstore_load on C).  `split` (--unet-split weight streaming, src/unet.c:390-458) is accepted and

@@ -379,6 +379,74 @@ MLB_API int mlctx_input_set(MLCtx* C, MLTensor* t, const void* host, size_t nbyt
 	return 1;
 }
 
+/* ------------------------------------------------------------------ LocalTensor (src/localtensor.h) and the all-in-one run */
+MLB_API size_t ltensor_nelements(const LocalTensor* S) { return (size_t)S->n[0] * S->n[1] * S->n[2] * S->n[3]; }
+MLB_API size_t ltensor_nbytes(const LocalTensor* S) { return sizeof(float) * ltensor_nelements(S); }
+
+MLB_API void ltensor_free(LocalTensor* S)
+{
+	if (!S) return;
+	if (S->flags & LT_F_OWNMEM) free(S->d);
+	memset(S, 0, sizeof(*S));
+}
+
+MLB_API void ltensor_resize(LocalTensor* S, int n0, int n1, int n2, int n3)
+{
+	float *keep = (S->flags & LT_F_OWNMEM) ? S->d : NULL;        /* borrowed memory is let go, never reallocated */
+	S->n[0] = n0; S->n[1] = n1; S->n[2] = n2; S->n[3] = n3;
+	const size_t nb = ltensor_nbytes(S);
+	S->d = (float*)realloc(keep, nb ? nb : 4);
+	S->flags |= LT_F_OWNMEM;
+}
+
+MLB_API int ltensor_shape_check(const LocalTensor* S, int n0, int n1, int n2, int n3)
+{
+	const int want[4] = { n0, n1, n2, n3 };
+	for (int i=0;i<4;++i) if (want[i] > 0 && want[i] != S->n[i]) return -1;
+	return 1;
+}
+
+MLB_API int ltensor_finite_check(const LocalTensor* S)
+{
+	const size_t n = ltensor_nelements(S);
+	for (size_t i=0;i<n;++i) if (!isfinite(S->d[i])) return -1;
+	return 1;
+}
+
+MLB_API int ltensor_to_backend(MLCtx* C, const LocalTensor* S, MLTensor* t)
+{
+	if (!S || !S->d || !t) return mlctx_fail(C, "ltensor_to_backend: null tensor");
+	if (t->in_type != MLT_F32) return mlctx_fail(C, "ltensor_to_backend(%s): the plan input is not fp32", t->name);
+	return mlctx_input_set(C, t, S->d, ltensor_nbytes(S));      /* (refuses a size mismatch: the reference asserts) */
+}
+
+MLB_API int ltensor_from_backend(MLCtx* C, LocalTensor* S, MLTensor* t)
+{
+	if (!S || !t) return mlctx_fail(C, "ltensor_from_backend: null tensor");
+	if (!mlt_need32(C, t)) return -1;
+	ltensor_resize(S, (int)t->ne[0], (int)t->ne[1], (int)t->ne[2], (int)t->ne[3]);
+	return mlctx_output_get(C, t, S->d, ltensor_nbytes(S));
+}
+
+MLB_API void mlctx_set_tstore(MLCtx* C, const struct MLTStore* S) { C->tstore = S; }
+
+int mlctx_tstore_load(MLCtx* C, const struct MLTStore* S);
+
+MLB_API int mlctx_run_(MLCtx* C, LocalTensor* out, const LocalTensor** inputs)
+{
+	int R = 1;
+	if (mlctx_prep(C) < 0) { R = -1; goto end; }
+	if (C->tstore) { if (mlctx_tstore_load(C, C->tstore) < 0) { R = -1; goto end; } }
+	else if (C->flags & MLB_F_SYNTH_PARAMS) { if (mlctx_params_synth(C, 1234) < 0) { R = -1; goto end; } }
+	for (int i=0; i<C->n_inputs && inputs && inputs[i]; ++i)
+		if (ltensor_to_backend(C, inputs[i], C->inputs[i]) < 0) { R = -1; goto end; }
+	if (mlctx_compute(C) < 0) { R = -1; goto end; }
+	if (out && ltensor_from_backend(C, out, C->result) < 0) { R = -1; goto end; }
+end:
+	mlctx_end(C);               /* the reference frees the context's graph and buffers here (mlctx_free: the MLCtx object itself stays usable) */
+	return R;
+}
+
 MLB_API const float* mlctx_tensor_device_f32(MLCtx* C, MLTensor* t, int64_t* ld)
 {
 	(void)C;

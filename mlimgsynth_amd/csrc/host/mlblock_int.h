@@ -93,6 +93,7 @@ struct MLCtx {
 	struct { MLTensor* ctx; char* wbase; char* out16; int n_in, n_total, n_used; } kvb;
 	/* batched time-embedding projections of the resnets (they all read silu(emb)): one GEMM, row-bias slices for the convs */
 	struct { MLTensor* emb; char* wbase; float* bbase; float* out32; int n_in, n_total, n_used; } epb;
+	const struct MLTStore* tstore;   /* parameters for mlctx_run_ (mlctx_set_tstore) */
 	int prepared, tuned, n_tune_miss;
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */

@@ -352,11 +352,6 @@ MLB_API int unet_denoise_run(UnetState* S, const LocalTensor* x, const LocalTens
 		return mlsd_set_error(-1, "unet_denoise_run: x shape does not match the initialised graph");
 	if (cond->n[0] != P->n_ctx || cond->n[1] != 77) return mlsd_set_error(-1, "unet_denoise_run: cond must be [%d,77]", P->n_ctx);
 	if (P->ch_adm_in && (!label || label->n[0] != P->ch_adm_in)) return mlsd_set_error(-1, "unet_denoise_run: label must be [%d]", P->ch_adm_in);
-	const size_t n = (size_t)x->n[0]*x->n[1]*x->n[2];
-	if (dx != x) {   /* ltensor_resize_like(dx, x) (:466) */
-		if (!(dx->flags & 1)) dx->d = NULL;
-		dx->d = (float*)realloc(dx->d, n * sizeof(float));
-		memcpy(dx->n, x->n, sizeof(dx->n)); dx->flags |= 1;
-	}
+	if (dx != x) ltensor_resize(dx, x->n[0], x->n[1], x->n[2], x->n[3]);   /* ltensor_resize_like(dx, x) (:466) */
 	return unet_denoise_run_n(S, x->d, cond->d, label ? label->d : NULL, &sigma, dx->d);
 }

@@ -356,3 +356,70 @@ def test_python_wrapper_generates_like_the_ffi_table(lib):
         assert again.n == (8, 8, 4, 1)
         with pytest.raises(RuntimeError, match="vocabulary"):
             w.text_tokenize("no vocabulary file in this container")
+
+
+def test_builder_all_in_one_run_with_local_tensors():
+    """mlctx_run_ (src/mlblock.c:324-345) on LocalTensor inputs / output (src/localtensor.h:96-106): prep, upload the inputs in
+    declaration order, compute, read the last tensor, release the plan -- against the same graph driven step by step."""
+    import ctypes
+    from mlimgsynth_amd import _lib, engine
+    L = engine.L()
+    vp, c_int, c_bool = ctypes.c_void_p, ctypes.c_int, ctypes.c_bool
+
+    class LT(ctypes.Structure):
+        _fields_ = [("d", ctypes.POINTER(ctypes.c_float)), ("n", ctypes.c_int * 4), ("flags", ctypes.c_int)]
+    L.mlctx_begin.argtypes = [vp, ctypes.c_char_p]
+    L.mlctx_input_new.restype = vp
+    L.mlctx_input_new.argtypes = [vp, ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int]
+    L.mlb_nn_conv2d.restype = vp
+    L.mlb_nn_conv2d.argtypes = [vp, vp, c_int] + [c_int] * 8 + [c_bool]
+    L.mlb_nn_groupnorm.restype = vp
+    L.mlb_nn_groupnorm.argtypes = [vp, vp, c_int, c_bool, ctypes.c_float]
+    L.mlctx_tensor_add.restype = vp
+    L.mlctx_tensor_add.argtypes = [vp, ctypes.c_char_p, vp]
+    L.mlctx_run_.argtypes = [vp, ctypes.POINTER(LT), ctypes.POINTER(ctypes.POINTER(LT))]
+    L.mlctx_prep.argtypes = [vp]
+    L.mlctx_input_set.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.mlctx_output_get.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.mlctx_result.restype = vp
+    L.mlctx_result.argtypes = [vp]
+    L.ltensor_free.restype = None
+    L.ltensor_free.argtypes = [ctypes.POINTER(LT)]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 8, 16, 16)).astype(np.float32)          # NCHW: LocalTensor n = {W, H, C, N}
+
+    def build(C):
+        L.mlctx_begin(C.h, b"runtest")
+        xi = L.mlctx_input_new(C.h, b"x", 0, 16, 16, 8, 1)
+        h = L.mlctx_tensor_add(C.h, b"conv1", L.mlb_nn_conv2d(C.h, xi, 64, 3, 3, 1, 1, 1, 1, 1, 1, True))
+        h = L.mlctx_tensor_add(C.h, b"norm", L.mlb_nn_groupnorm(C.h, h, 32, True, 1e-6))
+        L.mlctx_tensor_add(C.h, b"conv2", L.mlb_nn_conv2d(C.h, h, 16, 3, 3, 2, 2, 1, 1, 1, 1, True))
+        return xi
+    # step by step
+    C = engine.MLCtx()
+    xi = build(C)
+    engine.check1(L.mlctx_prep(C.h), "prep")
+    C.params_synth(1234)
+    engine.check1(L.mlctx_input_set(C.h, xi, x.ctypes.data_as(vp), x.nbytes), "input_set")
+    C.compute()
+    ref = np.empty((1, 16, 8, 8), np.float32)
+    engine.check1(L.mlctx_output_get(C.h, L.mlctx_result(C.h), ref.ctypes.data_as(vp), ref.nbytes), "output_get")
+    C.destroy()
+    # all in one
+    C = engine.MLCtx(flags=32)                                           # MLB_F_SYNTH_PARAMS
+    build(C)
+    tin = LT(x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), (ctypes.c_int * 4)(16, 16, 8, 1), 0)
+    out = LT()
+    arr = (ctypes.POINTER(LT) * 2)(ctypes.pointer(tin), None)
+    engine.check1(L.mlctx_run_(C.h, ctypes.byref(out), arr), "mlctx_run_")
+    assert list(out.n) == [8, 8, 16, 1] and out.flags & 1
+    got = np.ctypeslib.as_array(out.d, shape=(1, 16, 8, 8)).copy()
+    L.ltensor_free(ctypes.byref(out))
+    assert np.isfinite(got).all() and np.array_equal(got, ref)
+    assert C.info().n_ops == 0                                           # the plan was released (mlctx_free of the reference)
+    # a LocalTensor of the wrong size is refused, not truncated
+    build(C)
+    bad = LT(x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), (ctypes.c_int * 4)(16, 8, 8, 1), 0)
+    arr = (ctypes.POINTER(LT) * 2)(ctypes.pointer(bad), None)
+    assert L.mlctx_run_(C.h, None, arr) < 0
+    C.destroy()

@@ -203,3 +203,39 @@ def test_mlb_add_refuses_late_second_operand(dry):
     C, y, rc = build("early")
     assert y and rc >= 1
     C.destroy()
+
+
+def test_local_tensor_host_functions():
+    """LocalTensor (src/localtensor.h:16-58,113-120, src/localtensor.c:63-69): resize owns memory and lets borrowed memory go,
+    free resets, shape check treats n <= 0 as "any", finite check flags NaN / Inf.  Pure host code: runs without a GPU."""
+    from mlimgsynth_amd import _lib
+    L = _lib.lib()
+
+    class LT(ctypes.Structure):
+        _fields_ = [("d", ctypes.POINTER(ctypes.c_float)), ("n", ctypes.c_int * 4), ("flags", ctypes.c_int)]
+    P = ctypes.POINTER(LT)
+    L.ltensor_nelements.restype = ctypes.c_size_t; L.ltensor_nelements.argtypes = [P]
+    L.ltensor_nbytes.restype = ctypes.c_size_t; L.ltensor_nbytes.argtypes = [P]
+    L.ltensor_resize.restype = None; L.ltensor_resize.argtypes = [P] + [ctypes.c_int] * 4
+    L.ltensor_free.restype = None; L.ltensor_free.argtypes = [P]
+    L.ltensor_shape_check.argtypes = [P] + [ctypes.c_int] * 4
+    L.ltensor_finite_check.argtypes = [P]
+    borrowed = (ctypes.c_float * 6)(1, 2, 3, 4, 5, 6)
+    t = LT(ctypes.cast(borrowed, ctypes.POINTER(ctypes.c_float)), (ctypes.c_int * 4)(3, 2, 1, 1), 0)
+    assert L.ltensor_nelements(ctypes.byref(t)) == 6 and L.ltensor_nbytes(ctypes.byref(t)) == 24
+    assert L.ltensor_shape_check(ctypes.byref(t), 3, 2, 0, -1) == 1 and L.ltensor_shape_check(ctypes.byref(t), 3, 3, 0, 0) == -1
+    assert L.ltensor_finite_check(ctypes.byref(t)) == 1
+    borrowed[4] = float("inf")
+    assert L.ltensor_finite_check(ctypes.byref(t)) == -1
+    L.ltensor_resize(ctypes.byref(t), 4, 4, 2, 1)                  # borrowed memory is not reallocated: a fresh owned block
+    assert t.flags & 1 and list(t.n) == [4, 4, 2, 1] and ctypes.addressof(t.d.contents) != ctypes.addressof(borrowed)
+    for i in range(32):
+        t.d[i] = float(i)
+    L.ltensor_resize(ctypes.byref(t), 8, 8, 1, 1)                  # owned memory grows in place (realloc): the old values survive
+    assert [t.d[i] for i in range(32)] == [float(i) for i in range(32)]
+    t.d[40] = float("nan")
+    for i in list(range(32, 40)) + list(range(41, 64)):
+        t.d[i] = 0.0
+    assert L.ltensor_finite_check(ctypes.byref(t)) == -1
+    L.ltensor_free(ctypes.byref(t))
+    assert not t.d and list(t.n) == [0, 0, 0, 0] and t.flags == 0

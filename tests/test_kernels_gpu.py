@@ -540,6 +540,34 @@ def test_layernorm(K, rows, d):
     assert rel(dy16.download((rows, d), np.float16).astype(np.float32), ref) < 1e-3
 
 
+@pytest.mark.parametrize("rows,d,ldx", [(8200, 1280, 1280), (4100, 640, 704), (16385, 320, 320), (9000, 768, 768), (5000, 1024, 1024)])
+def test_layernorm_streaming_form_is_bit_identical(K, rows, d, ldx):
+    """rows > 4096 take ln_stream_kernel (a wave walks several rows, next row prefetched): same operations as the one-row-per-wave
+    kernel, so the outputs must be bit-identical whatever the grid (ragged row counts, strided input, every float4-per-lane
+    count 2..5), and match the oracle."""
+    kernels, _lib = K
+    L = _lib.lib()
+    rng = np.random.default_rng(rows + d)
+    xs = (rng.standard_normal((rows, ldx)) * 3 - 2).astype(np.float32)
+    gamma, beta = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+    dx, dg, db = dev(_lib, xs), dev(_lib, gamma), dev(_lib, beta)
+    dy16, dy32 = _lib.DeviceBuffer(rows * d * 2), _lib.DeviceBuffer(rows * d * 4)
+    outs = []
+    try:
+        for blocks in (0, 1024, 300, 1):
+            L.mlsd_layernorm_stream_blocks(blocks)
+            _lib.check(L.mlsd_memset(_lib.vp(dy32.ptr), 0xFF, ctypes.c_size_t(dy32.nbytes), None))
+            kernels.layernorm(dx.ptr, ldx, rows, d, 1e-5, dg.ptr, db.ptr, dy16.ptr, dy32.ptr)
+            outs.append((dy32.download((rows, d), np.float32), dy16.download((rows, d), np.float16)))
+    finally:
+        L.mlsd_layernorm_stream_blocks(1024)
+    for o32, o16 in outs[1:]:
+        assert np.array_equal(o32, outs[0][0]) and np.array_equal(o16, outs[0][1])
+    xd = xs[:, :d].astype(np.float64)
+    ref = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-5) * gamma + beta
+    assert rel(outs[1][0], ref) < 2e-6
+
+
 # ------------------------------------------------------------------ small ops
 def test_layout_and_small_ops(K):
     kernels, _lib = K
