@@ -63,6 +63,8 @@ MLTensor* mlctx_result(MLCtx* C);
 /* graph-split marker of the reference (src/mlblock.h:133-139, used by --unet-split): no-op here, returns its argument */
 MLTensor* mlctx_split_add(MLCtx* C, MLTensor* t);
 void mlctx_free(MLCtx* C);                /* reference name of mlctx_destroy (src/mlblock.h:82) */
+int  mlctx_build_alloc(MLCtx* C, MLTensor* result);                 /* step-by-step interface (src/mlblock.h:103): = mlctx_prep for `result` */
+int  mlctx_block_graph_dump_path(const MLCtx* C, const char* path); /* the block tree as text (src/mlblock.h:100-101, MLIS_DUMP_GRAPH) */
 
 /* ---- inputs / outputs at the host boundary (ltensor_to/from_backend, src/localtensor.h:96-106).
  * Host data is in the reference layout (ne[0] fastest: NCHW fp32 for images). */

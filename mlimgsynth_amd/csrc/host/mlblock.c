@@ -249,20 +249,59 @@ MLB_API void mlb_release(MLCtx* C, MLTensor* t)
 MLB_API void mlctx_block_begin(MLCtx* C)
 {
 	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
-	r->kind = 0; r->name = NULL; r->param = -1;
+	memset(r, 0, sizeof(*r)); r->param = -1;
 }
 
 void mlctx_named_op(MLCtx* C, const char* name)
 {
 	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
-	r->kind = 1; r->name = strdup(name); r->param = -1;
+	memset(r, 0, sizeof(*r)); r->kind = 1; r->name = strdup(name); r->param = -1;
 }
 
 MLB_API MLTensor* mlctx_tensor_add(MLCtx* C, const char* name, MLTensor* t)
 {
 	mlctx_named_op(C, name);
-	if (t) { snprintf(t->name, sizeof(t->name), "%s", name); C->result = t; }
+	if (t) {
+		snprintf(t->name, sizeof(t->name), "%s", name); C->result = t;
+		memcpy(C->names[C->n_names-1].ne, t->ne, sizeof(t->ne));
+	}
 	return t;
+}
+
+/* mlctx_build_alloc (src/mlblock.h:103, src/mlblock.c:161-176): finish the plan for `result` without loading parameters */
+MLB_API int mlctx_build_alloc(MLCtx* C, MLTensor* result)
+{
+	if (result) C->result = result;
+	return mlctx_prep(C);
+}
+
+/* mlctx_block_graph_dump(_path) (src/mlblock.c:347-388, MLIS_DUMP_GRAPH): the block tree, one line per named tensor, indented by
+ * scope, walked backwards like the name resolution; "name: KIND TYPE [ne0,ne1,ne2,ne3]" with KIND = PARAM or BLOCK (a named
+ * block output; the reference prints the ggml op that produced it, here a block is a group of fused launches). */
+MLB_API int mlctx_block_graph_dump_path(const MLCtx* C, const char* path)
+{
+	FILE *f = fopen(path, "w");
+	if (!f) return mlsd_set_error(-1, "could not open '%s'", path);
+	int depth = 0, R = 1;
+	for (int i=C->n_names-1; i>=0; --i) {
+		const MLNameRec *r = &C->names[i];
+		if (r->kind == 0) {
+			if (!depth) { fputs("ERROR INVALID ML BLOCK GRAPH\n", f); R = -1; break; }
+			--depth;
+			continue;
+		}
+		for (int k=0;k<depth;++k) fputs("  ", f);
+		if (r->kind == 2) {
+			const MLParam *p = &C->params[r->param];
+			fprintf(f, "%s: PARAM %s [%lld,%lld,%lld,%lld]\n", r->name, p->type == MLT_F16 ? "f16" : "f32",
+				(long long)p->ne[0], (long long)p->ne[1], (long long)p->ne[2], (long long)p->ne[3]);
+		} else {
+			fprintf(f, "%s: BLOCK f32 [%lld,%lld,%lld,%lld]\n", r->name, (long long)r->ne[0], (long long)r->ne[1], (long long)r->ne[2], (long long)r->ne[3]);
+			++depth;
+		}
+	}
+	fclose(f);
+	return R;
 }
 
 MLParam* mlctx_param_new(MLCtx* C, const char* name, int type, int64_t n0, int64_t n1, int64_t n2, int64_t n3,
@@ -754,6 +793,10 @@ MLB_API int mlctx_prep(MLCtx* C)
 			if (!autotune_on()) { int r = select_gemm(C, op); if (r < 0) return -1; if (!r) { C->n_tune_miss++; g_tune_miss++; } }
 		}
 		fl += op->flops;
+	}
+	if (C->flags & MLB_F_DUMP) {            /* src/mlblock.c:111-116 */
+		char path[96]; snprintf(path, sizeof(path), "dump-graph-%s.txt", C->name[0] ? C->name : "ctx");
+		if (mlctx_block_graph_dump_path(C, path) < 0) return -1;
 	}
 	if (!autotune_on()) wire_gn_stats(C);   /* (needs the tiles: the offline tuning mode runs the two-pass form) */
 	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;

@@ -65,7 +65,7 @@ typedef struct MLParam {
 	int loaded;
 } MLParam;
 
-typedef struct { int kind; char* name; int param; } MLNameRec;  /* kind: 0 block begin, 1 named op, 2 param */
+typedef struct { int kind; char* name; int param; int64_t ne[4]; } MLNameRec;  /* kind: 0 block begin, 1 named op (ne = its shape, 0 if unknown), 2 param */
 
 typedef struct { void* ptr; size_t size; int rel_op; } MLFreeBlk;   /* rel_op: ops recorded at release time */
 

@@ -651,6 +651,10 @@ static int engine_get(MLIS_Ctx* S, int lw, int lh)
 		mlctx_set_wtype(mlis_amd_unet_ctx(S->eng), S->wtype);
 		if (ctx_weights(S, mlis_amd_unet_ctx(S->eng), 0) < 0 || ctx_weights(S, mlis_amd_decoder_ctx(S->eng), tae) < 0) { engine_drop(S); return -1; }
 		snprintf(S->eng_key, sizeof(S->eng_key), "%s", key);
+		if (S->dump_flags & 4) {   /* MLIS_DUMP_GRAPH (src/mlimgsynth.c:432,1298 -> MLB_F_DUMP -> "dump-graph-<name>.txt", src/mlblock.c:111-116) */
+			mlctx_block_graph_dump_path(mlis_amd_unet_ctx(S->eng), "dump-graph-unet.txt");
+			mlctx_block_graph_dump_path(mlis_amd_decoder_ctx(S->eng), tae ? "dump-graph-tae.txt" : "dump-graph-vae.txt");
+		}
 	}
 	if (mlis_amd_set_sampler(S->eng, n_step, method, sched, S->cfg_scale, S->s_ancestral, S->s_noise, S->f_t_ini, S->f_t_end) < 0)
 		return api_error_lib(S, MLIS_E_OPT_VALUE);

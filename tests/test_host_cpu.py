@@ -239,3 +239,45 @@ def test_local_tensor_host_functions():
     assert L.ltensor_finite_check(ctypes.byref(t)) == -1
     L.ltensor_free(ctypes.byref(t))
     assert not t.d and list(t.n) == [0, 0, 0, 0] and t.flags == 0
+
+
+def test_block_graph_dump_reproduces_the_parameter_names(dry, tmp_path):
+    """mlctx_block_graph_dump_path (src/mlblock.c:347-388): the indented block tree, walked backwards like the name resolution.
+    Joining every PARAM line with the names of its enclosing blocks must give exactly the parameter keys mlctx_prep derived
+    (src/mlblock.c:67-105), with the same types and shapes; mlctx_build_alloc is the step-by-step name of prep."""
+    L = dry.L()
+    L.mlctx_block_graph_dump_path.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    for model in ("tinyxl", "sd1"):
+        un = dry.Unet(model, 8, 8, 1, synth=False)
+        path = str(tmp_path / f"{model}.txt")
+        assert L.mlctx_block_graph_dump_path(un.ctx.h, path.encode()) == 1
+        keys, stack = {}, []
+        for line in open(path):
+            depth = (len(line) - len(line.lstrip(" "))) // 2
+            name, rest = line.strip().split(": ", 1)
+            kind, typ, shape = rest.split(" ")
+            del stack[depth:]
+            if kind == "PARAM":
+                keys[".".join(stack + [name])] = (typ, [int(v) for v in shape.strip("[]").split(",")])
+            else:
+                assert kind == "BLOCK"
+                stack.append(name)
+        want = {k: ("f16" if t == 1 else "f32", ne) for k, t, ne in un.ctx.param_list()}
+        assert keys == want and len(keys) > 100
+        un.ctx.destroy()
+    # step-by-step interface name
+    L.mlctx_build_alloc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.mlctx_begin.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.mlctx_input_new.restype = ctypes.c_void_p
+    L.mlctx_input_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.c_int] * 5
+    L.mlb_nn_linear.restype = ctypes.c_void_p
+    L.mlb_nn_linear.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_bool]
+    L.mlctx_tensor_add.restype = ctypes.c_void_p
+    L.mlctx_tensor_add.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+    C = dry.MLCtx()
+    L.mlctx_begin(C.h, b"ba")
+    x = L.mlctx_input_new(C.h, b"x", 0, 64, 4, 1, 1)
+    y = L.mlctx_tensor_add(C.h, b"fc", L.mlb_nn_linear(C.h, x, 32, True))
+    assert L.mlctx_build_alloc(C.h, y) == 1
+    assert [k for k, _, _ in C.param_list()] == ["fc.bias", "fc.weight"] or sorted(k for k, _, _ in C.param_list()) == ["fc.bias", "fc.weight"]
+    C.destroy()
