@@ -25,6 +25,8 @@ g.set_cond(cond, label, uncond, unlabel)
 got, _ = g.generate([42], want_images=False)
 t_gpu = time.time() - t0
 t0 = time.time()
+threads = min(os.cpu_count() or 1, 64)          # the oracle's OpenMP loops stop scaling (and then slow down) past the physical cores of a socket
+O.L().orc_set_threads(threads)
 P = O.Params(1234)
 out = np.empty((4, lat, lat), np.float32)
 tu = ctypes.c_double()
@@ -35,4 +37,4 @@ nfe = O.L().orc_generate_latent(P.h, b"unet", U, lat, lat, O.to_ot(cond[None, No
 t_cpu = time.time() - t0
 print(f"{model} latent {lat}x{lat}, {steps}-step Euler-a, cfg 7, seed 42, {nfe} UNet evaluations: final latent rel-L2 (HIP fp16 MFMA vs fp32 CPU oracle) = "
       f"{rel(got[0], out.astype(np.float64)):.3e}; max |latent| {np.abs(out).max():.2f}; finite {bool(np.isfinite(got).all())}; "
-      f"engine incl. setup {t_gpu:.1f} s, oracle {t_cpu:.1f} s ({os.cpu_count()} host cores)")
+      f"engine incl. setup {t_gpu:.1f} s, oracle {t_cpu:.1f} s ({threads} OpenMP threads)")
