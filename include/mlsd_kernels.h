@@ -156,6 +156,7 @@ int mlsd_attention(const mlsd_attn_args* a, void* stream);
 /* diagnostics / A-B timing: 1 = the d_head 64 problems also run on the general kernel instead of the 64-rows-per-wave one */
 void mlsd_attention_force_old(int on);
 void mlsd_attention_x2_min_tq(int tq);     /* smallest Tq (multiple of 256) the 64-rows-per-wave kernel takes (default 2048) */
+void mlsd_attention_wide_stores(int on);  /* diagnostics / A-B timing: 0 = the output in 8-byte pieces per lane */
 void mlsd_attention_vsum(int on);         /* diagnostics / A-B timing: 1 = row sums of the 64-rows-per-wave kernel on the VALU instead of ones.P MFMAs */
 
 /* row softmax over fp32 scores -> fp16 probabilities (VAE mid attention, d=512 single head,

@@ -50,6 +50,7 @@ struct AttnP {
     long ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
     int n_head, Tq, Tk, causal;
     int nq, G;  // query blocks per (batch, head) group; number of groups
+    int wide_o; // output rows are 16-byte aligned: lane pairs exchange halves and store 16 bytes each (T21)
     float sc;  // 1/sqrt(d_head) * log2(e)
 };
 
@@ -292,15 +293,29 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) __attribute__((amdgpu_wave
     const float inv = 1.0f / l_fin;
     if (qrow < p.Tq) {
         _Float16* og = p.o + (long)b * p.bso + (long)qrow * p.ldo + (long)head * DH;
+        auto piece = [&](int d, int eg) __attribute__((always_inline)) {
+            const f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
+                             (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
+            return __builtin_bit_cast(u32x2, h);
+        };
 #pragma unroll
         for (int d = 0; d < NDV; ++d)
 #pragma unroll
-            for (int eg = 0; eg < 4; ++eg) {
-                const int dbase = 32 * d + 8 * eg + 4 * lh;
-                if (dbase < DH) {
-                    f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
-                               (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
-                    *reinterpret_cast<f16x4*>(og + dbase) = h;
+            for (int eg = 0; eg < 4; eg += 2) {
+                // a row's 8 columns 32d + 8eg .. +7 sit as two 8-byte pieces in lanes q and q + 32: pairs of them swap halves
+                // (v_permlane32_swap) so that every lane stores 16 contiguous bytes -- the tail is store-issue bound
+                // (cdna_hip_programming.md T21); needs both column groups inside d_head and 16-byte aligned rows
+                if (p.wide_o && 32 * d + 8 * eg + 16 <= DH) {
+                    u32x2 a = piece(d, eg), c = piece(d, eg + 1);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                    *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                } else {
+#pragma unroll
+                    for (int e2 = eg; e2 < eg + 2; ++e2) {
+                        const int dbase = 32 * d + 8 * e2 + 4 * lh;
+                        if (dbase < DH) *reinterpret_cast<u32x2*>(og + dbase) = piece(d, e2);
+                    }
                 }
             }
     }
@@ -490,13 +505,24 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
     auto store = [&](const f32x16* oacc, float l_run, int sb) __attribute__((always_inline)) {
         const float inv = 1.0f / l_run;                 // the MFMA row sum already covers all 64 keys of every tile (both lane halves)
         _Float16* og = p.o + (long)b * p.bso + (long)(qw + 32 * sb + lr) * p.ldo + (long)head * DH;
+        auto piece = [&](int d, int eg) __attribute__((always_inline)) {
+            const f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
+                             (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
+            return __builtin_bit_cast(u32x2, h);
+        };
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int eg = 0; eg < 4; ++eg) {
-                f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
-                           (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
-                *reinterpret_cast<f16x4*>(og + 32 * d + 8 * eg + 4 * lh) = h;
+            for (int eg = 0; eg < 4; eg += 2) {
+                if (p.wide_o) {             // 16 bytes per lane (see attn_kernel's epilogue)
+                    u32x2 a = piece(d, eg), c = piece(d, eg + 1);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                    *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                } else {
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * eg + 4 * lh) = piece(d, eg);
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * (eg + 1) + 4 * lh) = piece(d, eg + 1);
+                }
             }
     };
     if constexpr (VSUM) {
@@ -513,6 +539,7 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
+int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
@@ -524,6 +551,7 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
     p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = 0;
     p.sc = (float)(1.4426950408889634 / sqrt(64.0));
     p.nq = a->Tq / 256; p.G = a->n_head * a->n_batch;
+    p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
     if (g_attn_vsum) hipLaunchKernelGGL(attn64x2_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn64x2_kernel<false>, grid, dim3(256), 0, st, p);
@@ -540,6 +568,7 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
     p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = a->causal;
     p.sc = (float)(1.4426950408889634 / sqrt((double)a->d_head));
     p.nq = (a->Tq + 127) / 128; p.G = a->n_head * a->n_batch;
+    p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
     if (g_attn_vsum) hipLaunchKernelGGL((attn_kernel<DH, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_kernel<DH, false>), grid, dim3(256), 0, st, p);
@@ -573,5 +602,6 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
 MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
+MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
 
 }  // extern "C"

@@ -640,13 +640,14 @@ bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 {
     if ((g_gemm_dbg & 2) || a->bias_m) return PP_EPI_GENERIC;
+    const bool c16_wide = a->C16 && !(a->ldc16 & 7) && !((uintptr_t)a->C16 & 15);     // the fp16 fast paths store 16 bytes per lane
     if (a->act == MLSD_ACT_NONE) {
-        if (a->C16 && !a->C32 && !a->resid) return PP_EPI_F16;
+        if (a->C16 && !a->C32 && !a->resid) return c16_wide ? PP_EPI_F16 : PP_EPI_GENERIC;
         if (a->C32 && !a->C16) {
             const bool st = a->colstats != nullptr && !((uintptr_t)a->colstats & 15) && !(a->N & 3);
             return a->resid ? (st ? PP_EPI_F32_RES_STATS : PP_EPI_F32_RES) : (st ? PP_EPI_F32_STATS : PP_EPI_F32);
         }
-    } else if (a->act == MLSD_ACT_GEGLU && BN == 256 && a->C16 && !a->C32 && !a->resid && !a->conv) return PP_EPI_GEGLU16;
+    } else if (a->act == MLSD_ACT_GEGLU && BN == 256 && c16_wide && !a->C32 && !a->resid && !a->conv) return PP_EPI_GEGLU16;
     return PP_EPI_GENERIC;
 }
 

@@ -349,6 +349,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         for (int r = 0; r < NR; ++r) {
             if (r + PF < NR) fetch(r + PF);
             const int qa = r / RA, i = r % RA;
+            if constexpr (S16 && !S32 && !RES && !ST) {
+                // fp16 only: the row's 16 columns of a block sit in 4 lanes (lg) as 8-byte pieces.  The tail is store-ISSUE bound
+                // (~34 clocks per wave store, gemm_trace; tools/store_ab.py measured 8192x3840x1280 84.2 -> 75.9 us), so pairs of column blocks exchange halves between lane groups 0<->1 and
+                // 2<->3 (v_permlane16_swap) and every lane stores 16 contiguous bytes: half the store instructions, same bytes
+                // (cdna_hip_programming.md T21).  lg 0/2 end up with block c, lg 1/3 with block c+1, columns 8 (lg >> 1) .. +7.
+                _Float16* rowp = p.C16 + (long)(wrow0 + l15 + row_of(r)) * p.ldc16 + wcol0 + 8 * (lg >> 1) + 16 * (lg & 1);
+#pragma unroll
+                for (int c = 0; c + 1 < NCB; c += 2) {
+                    const f32x4 v0 = acc[qa][i][c] + cb[c], v1 = acc[qa][i][c + 1] + cb[c + 1];
+                    const f16x4 h0 = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3]};
+                    const f16x4 h1 = {(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                    u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1);
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    *reinterpret_cast<u32x4*>(rowp + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+                if constexpr (NCB & 1) {        // odd block count (128x320 tile): the last block keeps its 8-byte pieces
+                    const f32x4 v = acc[qa][i][NCB - 1] + cb[NCB - 1];
+                    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<f16x4*>(c16b + (long)row_of(r) * p.ldc16 + (NCB - 1) * 16) = h;
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 f32x4 v = acc[qa][i][c] + cb[c];
@@ -359,6 +381,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                     f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                     *reinterpret_cast<f16x4*>(c16b + (long)row_of(r) * p.ldc16 + c * 16) = h;
                 }
+            }
             }
         }
         if constexpr (ST) {
@@ -391,13 +414,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             for (int r = 0; r < 2 * RA; ++r) {
                 const int qa = r / RA, i = r % RA;
                 _Float16* cp = c16b + (long)(qa * (WM / 2) + i * 16) * p.ldc16;
+                u32x2 hh[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const f32x4 a4 = acc[qa][i][j] + cb[j], g4 = acc[qa][i][2 + j] + cb[2 + j];
-                    f16x4 h = {(_Float16)(a4[0] * gelu_tanh_f(g4[0])), (_Float16)(a4[1] * gelu_tanh_f(g4[1])),
-                               (_Float16)(a4[2] * gelu_tanh_f(g4[2])), (_Float16)(a4[3] * gelu_tanh_f(g4[3]))};
-                    *reinterpret_cast<f16x4*>(cp + j * 16) = h;
+                    const f16x4 h = {(_Float16)(a4[0] * gelu_tanh_f(g4[0])), (_Float16)(a4[1] * gelu_tanh_f(g4[1])),
+                                     (_Float16)(a4[2] * gelu_tanh_f(g4[2])), (_Float16)(a4[3] * gelu_tanh_f(g4[3]))};
+                    hh[j] = __builtin_bit_cast(u32x2, h);
                 }
+                // the two 16-column blocks of the row as ONE 16-byte store per lane (see epi_fast)
+                const auto r0 = __builtin_amdgcn_permlane16_swap(hh[0][0], hh[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(hh[0][1], hh[1][1], false, false);
+                *reinterpret_cast<u32x4*>(cp - 4 * lg + 8 * (lg >> 1) + 16 * (lg & 1)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
             }
         }
     };

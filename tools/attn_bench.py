@@ -30,4 +30,14 @@ for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)
         outs[name] = do.download((nb, tq, D), np.float16).astype(np.float32)
         err = np.abs(outs[name] - outs["general kernel "]).max()
         print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s   max|diff vs general| {err:.2e}")
+        if vsum:           # the same kernel with the output in 8-byte pieces (before the 16-byte stores)
+            L.mlsd_attention_wide_stores(0)
+            for _ in range(3): kernels.attention(a)
+            L.mlsd_event_record(ev[0], None)
+            for _ in range(reps): kernels.attention(a)
+            L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
+            ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
+            o8 = do.download((nb, tq, D), np.float16).astype(np.float32)
+            print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}, 8-byte output stores: {ms.value/reps*1e3:8.1f} us   identical output: {np.array_equal(o8, outs[name])}")
+            L.mlsd_attention_wide_stores(1)
 L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048)
