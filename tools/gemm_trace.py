@@ -1,6 +1,6 @@
 """Where a ping-pong GEMM launch spends its time, from s_memtime stamps written by thread 0 of every block
 (mlsd_gemm_set_trace): prologue, main loop, epilogue issue, store drain.
-usage: python3 tools/gemm_trace.py M N K [variant] [flavour: f16|f32|f32+res]"""
+usage: python3 tools/gemm_trace.py M N K [variant] [flavour: f16|f32|f32+res|geglu]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +19,9 @@ dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
 a = kernels.GemmArgs(A=dA.ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K)
 if flav.startswith("f32"):
     a.C32, a.ldc32 = dC32.ptr, N
+elif flav == "geglu":
+    dBias = _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
+    a.C16, a.ldc16, a.act, a.bias = dC16.ptr, N // 2, kernels.ACT_GEGLU, dBias.ptr
 else:
     a.C16, a.ldc16 = dC16.ptr, N
 if flav == "f32+res":
