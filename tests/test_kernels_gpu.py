@@ -736,6 +736,44 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
 
 
+@pytest.mark.parametrize("pp,geglu", [(17, False), (18, False), (17, True)])
+@pytest.mark.parametrize("misalign", ["none", "base+8B", "ld%8=4"])
+def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
+    """The fp16 fast epilogues store 16 bytes per lane (v_permlane16_swap pairs of column blocks): they need 16-byte aligned
+    rows.  An output whose base is only 8-byte aligned, or whose row stride is 4 mod 8 halfs, must take the generic epilogue
+    and give the same numbers; every output element is written exactly once and nothing outside the rows' N columns."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    rng = np.random.default_rng(pp + geglu)
+    M, Kd = 512, 256
+    N = 1024 if pp == 17 else 960
+    nout = N // 2 if geglu else N
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, bias)
+    ld = nout + (4 if misalign == "ld%8=4" else 0)
+    off = 4 if misalign == "base+8B" else 0                                  # halfs
+    buf = _lib.DeviceBuffer((M * ld + 16) * 2)
+    _lib.check(L.mlsd_memset(vp(buf.ptr), 0x7C, ctypes.c_size_t(buf.nbytes), None))     # 0x7C7C = a large fp16 sentinel
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C16=buf.ptr + 2 * off, ldc16=ld,
+                         act=kernels.ACT_GEGLU if geglu else kernels.ACT_NONE, tile_variant=pp + 1)
+    assert "pp" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    raw = buf.download((M * ld + 16,), np.float16)
+    got = raw[off:off + M * ld].reshape(M, ld)
+    y = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if geglu:
+        gelu = lambda v: 0.5 * v * (1 + np.tanh(0.7978845608028654 * v * (1 + 0.044715 * v * v)))
+        v = y.reshape(M, N // 64, 2, 32)
+        y = (v[:, :, 0] * gelu(v[:, :, 1])).reshape(M, nout)
+    assert rel(got[:, :nout].astype(np.float32), y) < 1e-3
+    sentinel = np.frombuffer(np.array([0x7C7C], np.uint16).tobytes(), np.float16)[0]
+    pad = np.concatenate([raw[:off], got[:, nout:].ravel(), raw[off + M * ld:]])
+    assert pad.size == 0 or (pad.view(np.uint16) == 0x7C7C).all()                 # nothing written outside the output columns
+    assert not (got[:, :nout].view(np.uint16) == 0x7C7C).any()                     # every output element written
+
+
 @pytest.mark.parametrize("two_sources", [False, True])
 def test_groupnorm_from_producer_statistics(K, two_sources):
     """GroupNorm whose first pass is replaced by the producers' column statistics (gn_finalize): same result as the two-pass
