@@ -451,6 +451,35 @@ def test_attention(K, nb, heads, dh, tq, tk, causal):
     assert rel(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize("dh,tq,tk", [(64, 256, 77), (64, 200, 130), (40, 192, 77), (80, 130, 77), (160, 64, 64)])
+def test_attention_output_store_width(K, dh, tq, tk):
+    """The attention epilogues store 16 bytes per lane (v_permlane32_swap of column-group pairs) when the output rows are
+    16-byte aligned, 8-byte pieces otherwise (and for column groups that end past d_head: 40, 80): bit-identical results, every
+    element written once, nothing outside the rows."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    rng = np.random.default_rng(dh + tk)
+    nb, heads = 2, 3
+    D = heads * dh
+    q, k, v = (rng.standard_normal((nb, t, D)).astype(np.float16) for t in (tq, tk, tk))
+    dq, dk, dv = dev(_lib, q), dev(_lib, k), dev(_lib, v)
+    outs = []
+    for ldo, off in ((D, 0), (D + 4, 0), (D + 8, 4), (D, 0)):                    # aligned | row stride 4 mod 8 | base + 8 bytes | aligned
+        buf = _lib.DeviceBuffer((nb * tq * ldo + 16) * 2)
+        _lib.check(L.mlsd_memset(vp(buf.ptr), 0x7C, ctypes.c_size_t(buf.nbytes), None))
+        a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=buf.ptr + 2 * off, ldq=D, ldk=D, ldv=D, ldo=ldo, bsq=tq * D, bsk=tk * D,
+                             bsv=tk * D, bso=tq * ldo, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
+        kernels.attention(a)
+        raw = buf.download((nb * tq * ldo + 16,), np.float16)
+        got = raw[off:off + nb * tq * ldo].reshape(nb * tq, ldo)
+        pad = np.concatenate([raw[:off], got[:, D:].ravel(), raw[off + nb * tq * ldo:]])
+        assert (pad.view(np.uint16) == 0x7C7C).all()
+        assert not (got[:, :D].view(np.uint16) == 0x7C7C).any()
+        outs.append(got[:, :D].copy())
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
 def test_attention_fused_qkv_strides(K):
     """q/k/v as column slices of one [T][3*D] projection output (how the UNet self-attention feeds it)."""
     kernels, _lib = K
