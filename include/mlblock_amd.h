@@ -52,6 +52,8 @@ int    mlctx_sync(MLCtx* C);
  * runs the same kernels in the same summation order.  mlctx_set_autotune(1) (or MLSD_AUTOTUNE=1) turns on the OFFLINE
  * timing mode used by tools/tune_all.py to produce that table; mlsd_tune_dump writes the shapes timed in this process. */
 void   mlctx_set_autotune(int on);
+void   mlctx_set_hoist(int on);             /* 0: run the step-invariant ops (cross-attention K/V of the context) in every evaluation, like the reference's graph */
+int    mlctx_once_ops(const MLCtx* C);      /* number of step-invariant ops of the plan */
 int    mlctx_tune_misses(void);           /* GEMM shapes prepared so far that the table does not list (static choice used) */
 int    mlsd_tune_dump(const char* path);
 

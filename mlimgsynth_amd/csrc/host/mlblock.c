@@ -70,7 +70,7 @@ static void ctx_reset_(MLCtx* C)
 	if (C->splitk_ws) { mlsd_free(C->splitk_ws); C->splitk_ws = NULL; C->splitk_ws_bytes = 0; }
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
-	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0;
+	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->epb, 0, sizeof(C->epb));
 	memset(&C->info, 0, sizeof(C->info));
@@ -407,12 +407,17 @@ MLB_API int mlctx_input_bind(MLTensor* t, const float* dev_src, int n_src, const
 	return 1;
 }
 
-MLB_API void* mlctx_input_device_ptr(MLTensor* t) { return t ? t->in_stage : NULL; }
+MLB_API void* mlctx_input_device_ptr(MLTensor* t)
+{	/* whoever asks for the staging buffer is about to write it: step-invariant ops fed by it run again */
+	if (t && t->dirty) *t->dirty = 0;
+	return t ? t->in_stage : NULL;
+}
 
 MLB_API int mlctx_input_set(MLCtx* C, MLTensor* t, const void* host, size_t nbytes)
 {
 	if (!t || !t->is_input) return mlctx_fail(C, "mlctx_input_set: not an input tensor");
 	if (nbytes != t->in_bytes) return mlctx_fail(C, "mlctx_input_set(%s): size %zu != %zu", t->name, nbytes, t->in_bytes);
+	if (t->dirty) *t->dirty = 0;
 	if (mlsd_memcpy(t->in_stage, host, nbytes, 0, C->stream)) return -1;
 	if (mlsd_stream_sync(C->stream)) return -1;
 	return 1;
@@ -806,6 +811,16 @@ MLB_API int mlctx_prep(MLCtx* C)
 	return 1;
 }
 
+/* step-invariant ops (MLOp.once) run once per conditioning; MLSD_NO_HOIST=1 / mlctx_set_hoist(0) runs them every time (A/B, parity test) */
+static int g_hoist = -1;
+static int hoist_on(void)
+{
+	if (g_hoist < 0) { const char *e = getenv("MLSD_NO_HOIST"); g_hoist = (e && *e && *e != '0') ? 0 : 1; }
+	return g_hoist;
+}
+MLB_API void mlctx_set_hoist(int on) { g_hoist = on ? 1 : 0; }
+MLB_API int mlctx_once_ops(const MLCtx* C) { return C->n_once; }
+
 MLB_API int mlctx_compute(MLCtx* C)
 {
 	if (!C->prepared) return mlctx_fail(C, "mlctx_compute before mlctx_prep");
@@ -827,19 +842,24 @@ MLB_API int mlctx_compute(MLCtx* C)
 		C->info.n_compute++;
 		return 1;
 	}
+	int hoist = C->n_once > 0 && hoist_on();
 	if (C->flags & MLB_F_HIPGRAPH) {
+		if (C->graph_exec) hoist = C->graph_hoisted;     /* what the captured graph leaves out */
+		if (hoist && !C->static_valid)          /* the step-invariant ops stay outside the captured graph */
+			for (int i=0;i<C->n_ops;++i) if (C->ops[i].once && run_op(C, &C->ops[i])) return mlctx_fail(C, "op %d (%s) failed", i, C->ops[i].label);
 		if (!C->graph_exec) {
 			if (mlsd_capture_begin(C->stream)) return -1;
 			int rc = 0;
-			for (int i=0;i<C->n_ops && !rc;++i) rc = run_op(C, &C->ops[i]);
+			for (int i=0;i<C->n_ops && !rc;++i) if (!(hoist && C->ops[i].once)) rc = run_op(C, &C->ops[i]);
 			void *ge = NULL;
 			int rc2 = mlsd_capture_end(C->stream, &ge);
 			if (rc || rc2) return mlctx_fail(C, "hipGraph capture failed");
-			C->graph_exec = ge;
+			C->graph_exec = ge; C->graph_hoisted = hoist;
 		}
 		if (mlsd_graph_launch(C->graph_exec, C->stream)) return -1;
 	} else {
 		for (int i=0;i<C->n_ops;++i) {
+			if (hoist && C->static_valid && C->ops[i].once) continue;
 			int rc = run_op(C, &C->ops[i]);
 			if (rc) {
 				char why[300]; snprintf(why, sizeof(why), "%s", mlsd_last_error());
@@ -848,6 +868,7 @@ MLB_API int mlctx_compute(MLCtx* C)
 			}
 		}
 	}
+	C->static_valid = 1;
 	C->info.t_compute = now_s() - t0;   /* enqueue time: the stream is asynchronous */
 	C->info.n_compute++;
 	return 1;

@@ -19,6 +19,8 @@ typedef struct MLOp {
 	MLOpKind kind;
 	double flops;
 	char label[56];
+	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
+	                         * re-runs it only after such an input was written (mlctx_input_set / mlctx_input_device_ptr) */
 	union {
 		mlsd_gemm_args gemm;
 		mlsd_attn_args attn;
@@ -51,6 +53,7 @@ struct MLTensor {
 	/* optional override of the NCHW source of an image input (sampler keeps the latent resident) */
 	const float* in_src; int in_src_n; const float* in_scale; float in_scale0; int in_mode;
 	int released;
+	int* dirty;             /* inputs feeding step-invariant ops: points at the owning context's static_valid (cleared on every write) */
 	char name[48];
 };
 
@@ -95,6 +98,8 @@ struct MLCtx {
 	struct { MLTensor* emb; char* wbase; float* bbase; float* out32; int n_in, n_total, n_used; } epb;
 	const struct MLTStore* tstore;   /* parameters for mlctx_run_ (mlctx_set_tstore) */
 	int prepared, tuned, n_tune_miss;
+	int static_valid;       /* the outputs of the `once` ops are current (no static_src input was written since they last ran) */
+	int n_once, graph_hoisted;
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */
 	MLCtxInfo info;

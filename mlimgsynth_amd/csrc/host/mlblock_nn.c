@@ -358,6 +358,7 @@ int mlb_cross_kv_batch(MLCtx* C, MLTensor* ctx, int n_total)
 	 * become one 616 x n_total x 2048 launch that fills the chip. */
 	if (!ctx || n_total <= 0 || C->err) return -1;
 	const int n_in = ctx->c;
+	const int op0 = C->n_ops;
 	const void *xd = mlt_need16(C, ctx);
 	if (!xd) return -1;
 	const int64_t rows = rows_of(ctx);
@@ -369,6 +370,14 @@ int mlb_cross_kv_batch(MLCtx* C, MLTensor* ctx, int n_total)
 	g->A = xd; g->lda = ctx->ld16; g->W_ = C->kvb.wbase; g->ldb = n_in; g->M = (int)rows; g->N = n_total; g->K = n_in;
 	g->C16 = C->kvb.out16; g->ldc16 = n_total;
 	op->flops = 2.0 * rows * (double)n_total * n_in;
+	/* The context is also the same for every STEP of a generation (src/mlimgsynth.c:1707-1719 sets it once before the
+	 * sampling loop): the ops recorded here (fp16 conversion of the context + this GEMM) depend on nothing else, their outputs
+	 * are never recycled (dalloc without release), so mlctx_compute runs them once per conditioning instead of once per
+	 * evaluation (the reference's graph recomputes them 40 times per image).  MLSD_NO_HOIST=1 switches this off. */
+	if (ctx->is_input) {
+		for (int i=op0; i<C->n_ops; ++i) { C->ops[i].once = 1; C->n_once++; }
+		ctx->dirty = &C->static_valid;
+	}
 	return 1;
 }
 

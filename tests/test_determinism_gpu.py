@@ -62,3 +62,62 @@ def test_autotune_env_is_the_only_way_to_time_tiles():
     a = run_child("tinyxl", 64, 64, 4, env)
     b = run_child("tinyxl", 64, 64, 4, env)
     assert a == b and a["misses"] > 0
+
+
+# ---- results do not depend on the batch slot (and therefore not on the rank / GPU count an image lands on): DESIGN.md section 6.
+# The pool has 1-GPU boxes, so this is the on-hardware evidence for the image-sharded multi-GPU claim: the images with seeds 44
+# and 45 sit in slots 2,3 of one batch and in slots 0,1 of another (what ranks 0 and 1 of a 2-GPU job with batch 2 would hold
+# against one GPU with batch 4) and must come out BIT-identical.
+@pytest.mark.parametrize("model,side,steps", [("tinyxl", 64, 20), ("sdxl", 1024, 20)])
+def test_image_bits_do_not_depend_on_batch_slot(model, side, steps):
+    import numpy as np
+    from mlimgsynth_amd import engine
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_cases as G
+    cond, uncond, label, unlabel = G.gen_inputs("gen_tinyxl_8_6", model)
+    g = engine.Generator(model, side, side, 4, n_step=steps, cfg_scale=7.0, s_ancestral=1.0, weight_seed=1234)
+    g.set_cond(cond, label, uncond, unlabel)
+    a, _ = g.generate([42, 43, 44, 45], want_images=False)
+    b, _ = g.generate([44, 45, 46, 47], want_images=False)
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.array_equal(a[2], b[0]) and np.array_equal(a[3], b[1])
+    assert not np.array_equal(a[0], b[0])
+    g.destroy()
+    # and a batch-2 engine (other tile-table rows: M halves) agrees with the batch-4 one to the per-evaluation tolerance
+    g2 = engine.Generator(model, side, side, 2, n_step=steps, cfg_scale=7.0, s_ancestral=1.0, weight_seed=1234)
+    g2.set_cond(cond, label, uncond, unlabel)
+    c, _ = g2.generate([44, 45], want_images=False)
+    err = np.linalg.norm(c.astype(np.float64) - b[:2]) / np.linalg.norm(b[:2])
+    print(model, "batch-2 vs batch-4 engine, same seeds: rel-L2", err)
+    assert err < 5e-2
+
+
+def test_step_invariant_ops_hoisting_is_bit_identical():
+    """The cross-attention K/V projections of the text context run once per conditioning (MLOp.once); running them in every
+    evaluation like the reference's graph gives the same bits, and a changed conditioning is picked up."""
+    import numpy as np
+    from mlimgsynth_amd import engine, _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_cases as G
+    import ctypes
+    L = _lib.lib()
+    L.mlctx_once_ops.argtypes = [ctypes.c_void_p]
+    L.mlctx_set_hoist.argtypes = [ctypes.c_int]
+    cond, uncond, label, unlabel = G.gen_inputs("gen_tinyxl_8_6", "tinyxl")
+    out = {}
+    for hoist in (1, 0):
+        L.mlctx_set_hoist(hoist)
+        for graph in (False, True):
+            g = engine.Generator("tinyxl", 64, 64, 2, n_step=6, cfg_scale=7.0, s_ancestral=1.0, use_hipgraph=graph)
+            assert L.mlctx_once_ops(g.unet_ctx().h) >= 2
+            g.set_cond(cond, label, uncond, unlabel)
+            a, _ = g.generate([7, 8], want_images=False)
+            g.set_cond(uncond, unlabel, cond, label)          # new conditioning: the hoisted ops must run again
+            b, _ = g.generate([7, 8], want_images=False)
+            out[(hoist, graph)] = (a, b)
+            g.destroy()
+    L.mlctx_set_hoist(1)
+    ref = out[(0, False)]
+    assert not np.array_equal(ref[0], ref[1])
+    for k, v in out.items():
+        assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]), k

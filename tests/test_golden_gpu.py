@@ -108,3 +108,46 @@ def test_hip_tae_decode_full_resolution_vs_independent_golden(key, lat):
     e = rel(G.reduce_image(got, key), HEAD[key])
     print(key, e)
     assert e < TOL
+
+
+# ---- The BENCHMARK'S OWN PLANS against the independent vectors: bench.py's SDXL workload runs the
+# batch-8 plan (4 images x cond/uncond: M = 8192 / 32768 / 131072 rows, i.e. other tile-table rows than the batch-1 plan the
+# cases above build) and its SD1.5 workload the batch-2 plan replayed as a hipGraph.  The stored golden input goes into slot
+# k, the other slots hold unrelated random inputs; slot k must match the torch vector like the batch-1 plan does.
+@pytest.mark.parametrize("slot", [0, 3, 7])
+def test_hip_unet_bench_plan_sdxl_batch8_vs_independent_golden(slot):
+    from mlimgsynth_amd import engine
+    key, model, lat, n = "unet_sdxl_128", "sdxl", 128, 8
+    x1, c1, l1 = G.unet_inputs(key, model, lat, 1)
+    r = np.random.default_rng(1000 + slot)
+    x = (r.standard_normal((n, 4, lat, lat)) * 3).astype(np.float32)
+    cond = r.standard_normal((n, 77, c1.shape[2])).astype(np.float32)
+    label = r.standard_normal((n, l1.shape[1])).astype(np.float32)
+    sig = r.uniform(0.1, 14.0, n).astype(np.float32)
+    x[slot], cond[slot], label[slot], sig[slot] = x1[0], c1[0], l1[0], 3.0
+    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
+    print("tile-table misses so far:", engine.L().mlctx_tune_misses())
+    got = un.run(x, cond, label, sig)
+    assert np.isfinite(got).all()
+    e = rel(got[slot], HEAD[key][0])
+    print(key, "batch 8, slot", slot, e)
+    assert e < TOL
+
+
+@pytest.mark.parametrize("slot", [0, 1])
+def test_hip_unet_bench_plan_sd15_batch2_hipgraph_vs_independent_golden(slot):
+    from mlimgsynth_amd import engine
+    key, model, lat, n = "unet_sd1_64", "sd1", 64, 2
+    x1, c1, _ = G.unet_inputs(key, model, lat, 1)
+    r = np.random.default_rng(2000 + slot)
+    x = (r.standard_normal((n, 4, lat, lat)) * 3).astype(np.float32)
+    cond = r.standard_normal((n, 77, c1.shape[2])).astype(np.float32)
+    sig = r.uniform(0.1, 14.0, n).astype(np.float32)
+    x[slot], cond[slot], sig[slot] = x1[0], c1[0], 3.0
+    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED, flags=8)      # MLB_F_HIPGRAPH: what bench.py --workload sd15 replays
+    got = un.run(x, cond, None, sig)
+    again = un.run(x, cond, None, sig)                                      # second call = graph replay
+    assert np.array_equal(got, again)
+    e = rel(got[slot], HEAD[key][0])
+    print(key, "batch 2 hipGraph, slot", slot, e)
+    assert e < TOL
