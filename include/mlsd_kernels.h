@@ -43,6 +43,8 @@ int mlsd_host_free(void* p);
 int mlsd_memset(void* dst, int value, size_t nbytes, void* stream);
 int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind /*0 h2d,1 d2h,2 d2d*/, void* stream);
 int mlsd_stream_create(void** out);
+int mlsd_stream_create_masked(void** out, const uint32_t* cu_mask, int n_words);   /* kernels of this stream run on the masked CUs only */
+int mlsd_cu_census(unsigned* out_dev, int n_blocks, int spin_cycles, void* stream); /* diagnostics: out[block] = (XCC id << 16) | HW_ID[15:0] */
 int mlsd_stream_destroy(void* s);
 int mlsd_stream_sync(void* s);
 int mlsd_device_sync(void);
@@ -134,6 +136,7 @@ int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
 /* timing-only builds of the main loop (needs -DMLSD_GEMM_EXPERIMENTS; otherwise ignored) */
 void mlsd_gemm_set_debug(int d);
+void mlsd_gemm_set_cus(int n);      /* CUs a persistent GEMM launch occupies (default 256; 128 for half-chip partitions) */
 void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */
 size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit);
 

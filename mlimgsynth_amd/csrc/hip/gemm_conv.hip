@@ -563,6 +563,7 @@ int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
     return (nkt + per - 1) / per;
 }
 
+int g_gemm_ncu = 256;   // CUs a persistent launch may occupy (mlsd_gemm_set_cus: half-chip partitions run 128-block grids)
 int g_gemm_dbg = 0;
 unsigned long long* g_gemm_tbuf = nullptr;   // device buffer of 8 stamps per block (mlsd_gemm_set_trace)
 int g_gemm_panel = 8;   // tile-order panel width in tiles (0: row-major)
@@ -670,7 +671,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on these tiles
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
-    const dim3 grid(ntiles < 256 ? ntiles : 256), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
+    const dim3 grid(ntiles < g_gemm_ncu ? ntiles : g_gemm_ncu), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
     auto go = [&](auto kfn) -> int {
         MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
@@ -799,6 +800,7 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+MLSD_API void mlsd_gemm_set_cus(int n) { g_gemm_ncu = n > 0 && n <= 256 ? n : 256; }
 /* diagnostics: device buffer of 8 x uint64 per block (256 blocks) that the ping-pong kernels fill with s_memtime stamps:
  * [0] kernel entry, [1] prologue done, [2] first epilogue begins, [3] first epilogue issued, [4] last epilogue begins,
  * [5] last epilogue issued, [6] block exit (after the final wait), [7] tiles walked; NULL switches it off */

@@ -130,6 +130,33 @@ MLSD_API int mlsd_stream_create(void** out)
     return 0;
 }
 
+/* A stream whose kernels may only run on a subset of the CUs (hipExtStreamCreateWithCUMask): `mask` holds n_words x 32 bits.
+ * Used to run two independent sub-batches side by side on two halves of the chip (DESIGN.md "two partitions"). */
+MLSD_API int mlsd_stream_create_masked(void** out, const uint32_t* mask, int n_words)
+{
+    hipStream_t s;
+    MLSD_HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+    *out = (void*)s;
+    return 0;
+}
+
+/* census: which XCD (HW_REG_XCC_ID) and CU the blocks of a launch on `stream` land on; out[block] = (xcc << 16) | (se << 8) | cu */
+__global__ void census_kernel(unsigned* out, int spin)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));     /* HW_REG_XCC_ID bits [3:0] */
+        unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    /* HW_REG_HW_ID */
+        out[blockIdx.x] = (xcc << 16) | (hwid & 0xffff);
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < spin) { }
+    }
+}
+MLSD_API int mlsd_cu_census(unsigned* out_dev, int n_blocks, int spin_cycles, void* stream)
+{
+    hipLaunchKernelGGL(census_kernel, dim3(n_blocks), dim3(64), 65536, (hipStream_t)stream, out_dev, spin_cycles);
+    return mlsd_check_launch("census_kernel");
+}
+
 MLSD_API int mlsd_stream_destroy(void* s)
 {
     if (s) MLSD_HIP_TRY(hipStreamDestroy((hipStream_t)s));
