@@ -50,7 +50,136 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-nfe", type=int, default=1, help="UNet evaluations timed for the CPU baseline sample")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel time table of one UNet evaluation to this file")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (sd15, sdxl + TAESD) reported beside the headline")
+    ap.add_argument("--extra-steps", type=int, default=3)
     return ap.parse_args()
+
+
+def kernel_roofline(g, workload, B):
+    """Roofline of the dominant kernel of one UNet evaluation: per-launch HIP-event timing on the engine's stream.
+    Returns (roofline dict, per-label aggregate {label: [launches, ms, flop, bytes]}, per-op ms)."""
+    uc = g.unet_ctx()
+    ops = uc.op_list()
+    nbytes = uc.op_bytes()
+    ms = uc.profile_ops()
+    agg = {}
+    for (lab, fl), t, nb in zip(ops, ms, nbytes):
+        lab = re.sub(r",k/\d+>", ">", lab)       # split-K launches run the same kernel instantiation
+        e = agg.setdefault(lab, [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += float(t); e[2] += fl; e[3] += nb
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    lab, (cnt, tms, fl, nb) = dom
+    tflops = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+    gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+    # the bound is the roof the kernel is closer to (GEMM/attention: MFMA; norms and short split-K GEMMs: HBM)
+    if tflops / PEAK_MFMA_F16_TFLOPS >= gbs / PEAK_HBM_GBS:
+        roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / PEAK_MFMA_F16_TFLOPS, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    # HBM-side traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same plan
+    # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
+    traffic, traffic_src, mfma_busy = None, None, None
+    for kind in ("traffic", "mfma"):
+        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r3", "r2", "r1")) if os.path.exists(p_)), "")
+        if not pmc:
+            continue
+        try:
+            with open(pmc) as fh:
+                k = json.load(fh)["kernels"].get(lab)
+            if k and kind == "traffic":
+                traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
+            elif k:
+                mfma_busy = k["mfma_busy_frac"]      # matrix-pipe utilisation from a SQ counter pass (tools/pmc_mfma_summary.py)
+        except Exception:
+            pass
+    roof = {**roof, "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
+            "algorithmic_gb_per_eval": round(nb / 1e9, 3), "algorithmic_tflop_per_eval": round(fl / 1e12, 3),
+            "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_frac_pmc": mfma_busy,
+            "share_of_eval_time": round(tms / float(ms.sum()), 3)}
+    return roof, agg, ms
+
+
+def eval_mfma(agg):
+    """TIME-WEIGHTED matrix-pipe fraction of one whole UNet evaluation (sum of algorithmic FLOP of every launch / sum of launch
+    durations / dense fp16 peak) and the same per kernel family, so that no bucket hides behind the best label."""
+    tot_ms = sum(v[1] for v in agg.values())
+    tot_fl = sum(v[2] for v in agg.values())
+    fam = {}
+    for lab, (c, t, fl, nb) in agg.items():
+        key = ("gemm " + lab[lab.index("<") + 1:lab.index(",")] if lab.startswith("gemm<") else lab.split(" ")[0])
+        e = fam.setdefault(key, [0.0, 0.0])
+        e[0] += t; e[1] += fl
+    top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:6]
+    return {"sum_launch_ms": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+            "frac_of_mfma_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
+            "by_family": {k: {"share": round(t / tot_ms, 3), "tflops": round(fl / (t * 1e-3) / 1e12, 1)} for k, (t, fl) in top}}
+
+
+def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps):
+    """A secondary workload of the BASELINE metric on the same GPU (after the headline's timed region): `steps` timed steps
+    (text encode + denoise + decode) after one warm-up; returns {value, ms_per_step, unet_eval_ms, roofline, ...}."""
+    import numpy as np
+    import torch
+    model, width, height, B = WORKLOADS[workload]
+    g = engine.Generator(model, width, height, B, n_step=denoise_steps, cfg_scale=cfg, s_ancestral=1.0, use_tae=tae,
+                         use_hipgraph=(workload == "sd15"), weight_seed=1234)
+    tc = text.TextConditioner(model, width, height, seed=1234)
+    prompt = np.random.default_rng(7).integers(0, 49405, 8).astype(np.int32)
+    pp = prompt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+    def step(i):
+        engine.check1(Lh.mlis_amd_textcond_apply(tc.h, g.h, pp, prompt.size, None, 0), "mlis_amd_textcond_apply")
+        g.generate([42 + i * B + b for b in range(B)], want_latents=False, want_images=False)
+
+    step(steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    um = 0.0
+    for i in range(steps):
+        step(i)
+        um += g.last_unet_ms()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    info = g.info()
+    flop_per_img = (info["unet_flops"] / B) * denoise_steps + info["decode_flops"] / B
+    value = steps * B / el
+    roof, agg, _ = kernel_roofline(g, workload, B)
+    res = {"config": f"{workload}-{width}x{height}-euler_a-{denoise_steps}-cfg{cfg:g}-b{B}-{'tae' if tae else 'vae'}",
+           "value": round(value, 4), "unit": "images/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 2),
+           "unet_eval_ms": round(um / (steps * denoise_steps), 3), "tflop_per_image": round(flop_per_img / 1e12, 3),
+           "job_tflops": round(value * flop_per_img / 1e12, 1),
+           "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
+           "roofline": roof, "unet_eval_mfma": eval_mfma(agg)}
+    aux = {"plist": g.unet_ctx().param_list(), "unet_flops_b1": info["unet_flops"] / (2 * B if cfg > 1 else B), "flop_per_img": flop_per_img}
+    g.destroy()
+    return res, aux
+
+
+def cpu_sample(model, width, height, cfg, denoise_steps, threads, nfe, plist):
+    """One bounded sample of the oracle (CPU restatement of the reference path): `nfe` batch-1 UNet evaluations of `model`,
+    weights pre-synthesised.  Returns seconds per evaluation."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.L().orc_set_threads(threads)
+    U = O.unet_params(model)
+    OP = O.Params(1234)
+    lw, lh = width // 8, height // 8
+    rng = np.random.default_rng(7)
+    cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
+    lab_ = rng.standard_normal(max(U.ch_adm_in, 1)).astype(np.float32)
+    ot = lambda x: O.to_ot(x)
+    lat = np.empty((4, lh, lw), np.float32)
+    tu = ctypes.c_double()
+    # synthesise the oracle's weights up front (same (seed, name, shape) rule as the engine) so that the
+    # timed sample contains UNet arithmetic only
+    for key, typ, ne in plist:
+        OP.get(key, typ == 1, [d for d in ne[::-1]])
+    n = O.L().orc_generate_latent(OP.h, b"unet", U, lw, lh, ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
+                                  ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
+                                  cfg, denoise_steps, 1.0, 42, nfe, O.fptr(lat), ctypes.byref(tu))
+    return tu.value / max(n, 1), n
 
 
 def main():
@@ -103,16 +232,14 @@ def main():
     t_setup = time.time() - t_setup
 
     def one_step(idx, want_images=False):
-        if rank == 0:     # CLIP towers are resident on rank 0: encode prompt + (empty) negative prompt straight into the plan's inputs
-            engine.check1(Lh.mlis_amd_textcond_apply(tc.h, g.h, pp, prompt.size, None, 0), "mlis_amd_textcond_apply")
-        if world > 1:     # ~1.3 MB once per batch, device to device, no host hop
-            engine.check1(Lh.mlis_amd_bcast_cond(g.h, comm, 0), "mlis_amd_bcast_cond")
-        # independent Philox stream per image (seed 42 + global image index): results do not depend on the GPU count
-        out = g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=want_images)   # syncs its stream
-        if world > 1:     # all-gather of the final latents: 256 KiB per SDXL image
-            engine.check1(Lh.mlis_amd_gather_results(g.h, comm, 0, _lib.vp(d_gather.ptr)), "mlis_amd_gather_results")
-            engine.check1(Lh.mlis_amd_sync(g.h), "mlis_amd_sync")
-        return out
+        # rank 0: encode prompt + (empty) negative prompt straight into the plan's inputs (resident CLIP towers); N>1: ~1.3 MB
+        # broadcast once per batch, device to device; every rank: its own images (independent Philox stream per image, seed 42 +
+        # global image index: results do not depend on the GPU count); N>1: all-gather of the final latents (256 KiB per image)
+        return mdist.job_step(
+            Lh, engine.check1, g.h, comm, world, rank,
+            lambda: engine.check1(Lh.mlis_amd_textcond_apply(tc.h, g.h, pp, prompt.size, None, 0), "mlis_amd_textcond_apply"),
+            lambda: g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=want_images),   # syncs its stream
+            _lib.vp(d_gather.ptr) if d_gather else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -166,53 +293,9 @@ def main():
         "images_per_s_with_d2h_of_fp32_images": round(B * world / el_host, 4),
     }
 
-    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the engine's stream, one UNet evaluation
-    uc = g.unet_ctx()
-    ops = uc.op_list()
-    nbytes = uc.op_bytes()
-    ms = uc.profile_ops()
-    agg = {}
-    for (lab, fl), t, nb in zip(ops, ms, nbytes):
-        lab = re.sub(r",k/\d+>", ">", lab)       # split-K launches run the same kernel instantiation
-        e = agg.setdefault(lab, [0, 0.0, 0.0, 0.0])
-        e[0] += 1; e[1] += float(t); e[2] += fl; e[3] += nb
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    lab, (cnt, tms, fl, nb) = dom
-    tflops = fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
-    gbs = nb / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-    # the bound is the roof the kernel is closer to (GEMM/attention: MFMA; norms and short split-K GEMMs: HBM)
-    if tflops / PEAK_MFMA_F16_TFLOPS >= gbs / PEAK_HBM_GBS:
-        roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / PEAK_MFMA_F16_TFLOPS, 4)}
-    else:
-        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
-    # HBM-side traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
-    traffic, traffic_src = None, None
-    pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{a.workload}_b{B}_pmc_traffic.json") for r_ in ("r2", "r1")) if os.path.exists(p_)), "")
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as fh:
-                k = json.load(fh)["kernels"].get(lab)
-            if k:
-                traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
-        except Exception:
-            pass
-    # matrix-pipe utilisation of that kernel from a SQ counter pass (tools/pmc_mfma_summary.py), same provenance
-    mfma_busy = None
-    pmc2 = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{a.workload}_b{B}_pmc_mfma.json") for r_ in ("r2", "r1")) if os.path.exists(p_)), "")
-    if os.path.exists(pmc2):
-        try:
-            with open(pmc2) as fh:
-                k2 = json.load(fh)["kernels"].get(lab)
-            if k2:
-                mfma_busy = k2["mfma_busy_frac"]
-        except Exception:
-            pass
-    out["roofline"] = {**roof, "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
-                       "algorithmic_gb_per_eval": round(nb / 1e9, 3), "algorithmic_tflop_per_eval": round(fl / 1e12, 3),
-                       "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_frac_pmc": mfma_busy,
-                       "share_of_eval_time": round(tms / float(ms.sum()), 3)}
+    roof, agg, ms = kernel_roofline(g, a.workload, B)
+    out["roofline"] = roof
+    out["unet_eval_mfma"] = eval_mfma(agg)
     if a.kernel_table:
         with open(a.kernel_table, "w") as f:
             f.write(f"# one UNet evaluation, {a.workload} batch {B} (N={2 * B if a.cfg > 1 else B}); per-launch HIP events\n")
@@ -220,30 +303,26 @@ def main():
             for k, (c, t, fl_, nb_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{k:46s} {c:8d} {t:10.3f} {fl_ / 1e12:9.3f} {fl_ / max(t, 1e-9) / 1e9:9.1f} {nb_ / 1e9:9.3f} {nb_ / max(t, 1e-9) / 1e6:9.1f}\n")
 
-    # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded sample
+    # ---- secondary workloads of the BASELINE metric (N=1 only, after the headline's timed region; the headline `value` is
+    # untouched): SD1.5 512x512 batch 1 (configs[1]) and SDXL with the TAESD decoder (configs[4] without weight streaming)
+    plist = g.unet_ctx().param_list()
+    extras = world == 1 and not a.no_extras and a.workload == "sdxl" and not a.tae
+    aux15 = None
+    if extras:
+        g.destroy()
+        for key, wl, tae_ in (("sd15", "sd15", False), ("sdxl_tae", "sdxl", True)):
+            try:
+                out[key], aux = run_extra(engine, text, Lh, _lib, wl, tae_, a.extra_steps, a.cfg, a.denoise_steps)
+                if key == "sd15":
+                    aux15 = aux
+            except Exception as e:
+                out[key] = {"value": None, "error": str(e)}
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded samples
     if world == 1 and not a.no_cpu_baseline:
+        threads = a.cpu_threads or min(os.cpu_count() or 1, 64)
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as O
-            threads = a.cpu_threads or min(os.cpu_count() or 1, 64)
-            O.L().orc_set_threads(threads)
-            U = O.unet_params(model)
-            OP = O.Params(1234)
-            lw, lh = width // 8, height // 8
-            rng = np.random.default_rng(7)
-            cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
-            lab_ = rng.standard_normal(max(U.ch_adm_in, 1)).astype(np.float32)
-            ot = lambda x: O.to_ot(x)
-            lat = np.empty((4, lh, lw), np.float32)
-            tu = ctypes.c_double()
-            # synthesise the oracle's weights up front (same (seed, name, shape) rule as the engine) so that the
-            # timed sample contains UNet arithmetic only
-            for key, typ, ne in uc.param_list():
-                OP.get(key, typ == 1, [d for d in ne[::-1]])
-            nfe = O.L().orc_generate_latent(OP.h, b"unet", U, lw, lh, ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
-                                            ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
-                                            a.cfg, a.denoise_steps, 1.0, 42, a.cpu_nfe, O.fptr(lat), ctypes.byref(tu))
-            s_per_nfe = tu.value / max(nfe, 1)
+            s_per_nfe, nfe = cpu_sample(model, width, height, a.cfg, a.denoise_steps, threads, a.cpu_nfe, plist)
             unet_flops_1 = info["unet_flops"] / (2 * B if a.cfg > 1 else B)
             s_per_img = s_per_nfe * (flop_per_img / unet_flops_1)      # decode priced at the UNet's measured FLOP rate
             out["cpu_baseline"] = {"value": round(1.0 / s_per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
@@ -253,6 +332,17 @@ def main():
                                              f"extrapolated to a whole image by algorithmic FLOPs"}
         except Exception as e:  # the baseline is a report, never the product path
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        # BASELINE.md section 3 / configs[0] name SD1.5 fp32 512x512 on the CPU: one SD1.5 evaluation as a second sample
+        if aux15:
+            try:
+                s15, n15 = cpu_sample("sd1", 512, 512, a.cfg, a.denoise_steps, threads, 1, aux15["plist"])
+                s_img15 = s15 * (aux15["flop_per_img"] / aux15["unet_flops_b1"])
+                out["cpu_baseline"]["sd15"] = {"value": round(1.0 / s_img15, 6), "unit": "images/s", "cores": threads, "kind": "port",
+                                               "s_per_unet_eval": round(s15, 3),
+                                               "sample": f"{n15} of {nfe_per_img} batch-1 UNet evaluations of one SD1.5 512x512 image (fp32 oracle, "
+                                                         f"OpenMP {threads} threads), extrapolated to a whole image by algorithmic FLOPs"}
+            except Exception as e:
+                out["cpu_baseline"]["sd15"] = {"value": None, "sample": f"failed: {e}"}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -165,6 +165,7 @@ int mlis_amd_textcond_encode_pair(MLIS_AmdTextCond* T, const int32_t* toks, int 
 	float* cond, float* label, float* ncond, float* nlabel);
 
 /* prompt + negative prompt encoded and written into an engine's conditioning inputs in one call (launchers; rank 0 of a multi-GPU job) */
+const void* mlis_amd_cond_device(MLIS_AmdCtx* S, int what);   /* the plan's conditioning inputs (0: cond, 1: label), read-only */
 int mlis_amd_textcond_apply(MLIS_AmdTextCond* T, MLIS_AmdCtx* E, const int32_t* toks, int n_tok, const int32_t* neg, int n_neg);
 
 /* ---- CLIP BPE tokenizer (host).  Replaces clip_tokenize and helpers, src/clip.c:59-278 (public entry

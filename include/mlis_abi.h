@@ -18,30 +18,30 @@ extern "C" {
 #define MLIS_VERSION 0x000402                     /* mlimgsynth.h:60; accepted by mlis_ctx_create_i: 0x000400 <= v < 0x000500 */
 #define MLIS_VERSION_STR "0.4.2"
 
-/* mlimgsynth.h:67-76 */
+/* mlimgsynth.h:68-77 */
 typedef enum { MLIS_E_UNKNOWN = -1, MLIS_E_VERSION = -2, MLIS_E_UNK_OPT = -3, MLIS_E_OPT_VALUE = -4, MLIS_E_PROMPT_PARSE = -5,
                MLIS_E_FILE_NOT_FOUND = -6, MLIS_E_NAN = -7, MLIS_E_IMAGE = -8 } MLIS_ErrorCode;
-/* :80-86 */
+/* :81-87 */
 typedef enum { MLIS_STAGE_IDLE = 0, MLIS_STAGE_COND_ENCODE = 1, MLIS_STAGE_IMAGE_ENCODE = 2, MLIS_STAGE_IMAGE_DECODE = 3,
                MLIS_STAGE_DENOISE = 4 } MLIS_Stage;
-/* :90-98, :102-107 */
+/* :91-99, :103-108 */
 typedef enum { MLIS_METHOD_NONE = 0, MLIS_METHOD_EULER = 1, MLIS_METHOD_HEUN = 2, MLIS_METHOD_TAYLOR3 = 3, MLIS_METHOD_DPMPP2M = 4,
                MLIS_METHOD_DPMPP2S = 5, MLIS_METHOD__LAST = 5 } MLIS_Method;
 typedef enum { MLIS_SCHED_NONE = 0, MLIS_SCHED_UNIFORM = 1, MLIS_SCHED_KARRAS = 2, MLIS_SCHED__LAST = 2 } MLIS_Scheduler;
-/* :111-121 */
+/* :112-122 */
 typedef enum { MLIS_LOGLVL_NONE = 0, MLIS_LOGLVL_ERROR = 10, MLIS_LOGLVL_WARNING = 20, MLIS_LOGLVL_INFO = 30, MLIS_LOGLVL_VERBOSE = 40,
                MLIS_LOGLVL_DEBUG = 50, MLIS_LOGLVL_MAX = 255, MLIS_LOGLVL__INCREASE = 0x100 | 10, MLIS_LOGLVL__DECREASE = 0x200 | 10 } MLIS_LogLvl;
-/* :125-137, :141-147 */
+/* :126-138, :142-148 */
 typedef enum { MLIS_TENSOR_IMAGE = 1, MLIS_TENSOR_MASK = 2, MLIS_TENSOR_LATENT = 3, MLIS_TENSOR_LMASK = 4, MLIS_TENSOR_COND = 5,
                MLIS_TENSOR_LABEL = 6, MLIS_TENSOR_NCOND = 7, MLIS_TENSOR_NLABEL = 8, MLIS_TENSOR_TMP = 0x100 } MLIS_TensorId;
 typedef enum { MLIS_TUF_IMAGE = 1, MLIS_TUF_MASK = 2, MLIS_TUF_LATENT = 4, MLIS_TUF_LMASK = 8, MLIS_TUF_CONDITIONING = 16 } MLIS_TensorUseFlag;
-/* :151-157 (+ this library's test models, outside the reference's range) */
+/* :152-158 (+ this library's test models, outside the reference's range) */
 typedef enum { MLIS_MODEL_TYPE_NONE = 0, MLIS_MODEL_TYPE_SD1 = 1, MLIS_MODEL_TYPE_SD2 = 2, MLIS_MODEL_TYPE_SDXL = 3, MLIS_MODEL_TYPE__LAST = 3,
                MLIS_MODEL_TYPE_AMD_TINY = 101, MLIS_MODEL_TYPE_AMD_TINYXL = 102, MLIS_MODEL_TYPE_AMD_TINYV = 103 } MLIS_ModelType;
-/* :161-168 */
+/* :162-169 */
 typedef enum { MLIS_SUBMODEL_NONE = 0, MLIS_SUBMODEL_UNET = 1, MLIS_SUBMODEL_VAE = 2, MLIS_SUBMODEL_TAE = 3, MLIS_SUBMODEL_CLIP = 4,
                MLIS_SUBMODEL_CLIP2 = 5 } MLIS_SubModel;
-/* :173-356: option ids; argument types as in the reference's comments (str = const char*, float options take double) */
+/* :174-346: option ids; argument types as in the reference's comments (str = const char*, float options take double) */
 typedef enum {
 	MLIS_OPT_NONE = 0, MLIS_OPT_BACKEND = 1, MLIS_OPT_MODEL = 2, MLIS_OPT_TAE = 3, MLIS_OPT_LORA_DIR = 4, MLIS_OPT_LORA = 5,
 	MLIS_OPT_LORA_CLEAR = 6, MLIS_OPT_PROMPT = 7, MLIS_OPT_NPROMPT = 8, MLIS_OPT_IMAGE_DIM = 9, MLIS_OPT_BATCH_SIZE = 10,
@@ -53,32 +53,32 @@ typedef enum {
 	MLIS_OPT_NO_PROMPT_PARSE = 35, MLIS_OPT__LAST = 35
 } MLIS_Option;
 
-typedef struct MLIS_Ctx MLIS_Ctx;                                                                            /* :362 */
-typedef struct MLIS_Image { uint8_t* d; size_t sz; unsigned w, h, c; int flags; } MLIS_Image;                /* :366-373 */
-typedef struct MLIS_Progress { MLIS_Stage stage; int step, step_end, nfe; double step_time, time; } MLIS_Progress;   /* :377-384 */
-typedef struct MLIS_ErrorInfo { MLIS_ErrorCode code; const char* desc; } MLIS_ErrorInfo;                     /* :388-391 */
-typedef struct MLIS_BackendInfo {                                                                            /* :395-404 */
+typedef struct MLIS_Ctx MLIS_Ctx;                                                                            /* :352 */
+typedef struct MLIS_Image { uint8_t* d; size_t sz; unsigned w, h, c; int flags; } MLIS_Image;                /* :356-363 */
+typedef struct MLIS_Progress { MLIS_Stage stage; int step, step_end, nfe; double step_time, time; } MLIS_Progress;   /* :367-374 */
+typedef struct MLIS_ErrorInfo { MLIS_ErrorCode code; const char* desc; } MLIS_ErrorInfo;                     /* :378-381 */
+typedef struct MLIS_BackendInfo {                                                                            /* :385-394 */
 	const char* name; unsigned n_dev;
 	struct MLIS_BackendDeviceInfo { const char *name, *desc; size_t mem_free, mem_total; } *devs;
 } MLIS_BackendInfo;
-typedef struct MLIS_Tensor { float* d; int n[4]; int flags; } MLIS_Tensor;                                   /* :409-413 */
-typedef int (*MLIS_Callback)(void*, MLIS_Ctx*, const MLIS_Progress*);                                       /* :418 */
-typedef void (*MLIS_ErrorHandler)(void*, MLIS_Ctx*, const MLIS_ErrorInfo*);                                 /* :422 */
+typedef struct MLIS_Tensor { float* d; int n[4]; int flags; } MLIS_Tensor;                                   /* :399-403 */
+typedef int (*MLIS_Callback)(void*, MLIS_Ctx*, const MLIS_Progress*);                                       /* :408 */
+typedef void (*MLIS_ErrorHandler)(void*, MLIS_Ctx*, const MLIS_ErrorInfo*);                                 /* :412 */
 
 #define mlis_ctx_create() mlis_ctx_create_i(MLIS_VERSION)
-MLIS_Ctx* mlis_ctx_create_i(int version);                                                                    /* :428-429 */
-void mlis_ctx_destroy(MLIS_Ctx** pctx);                                                                      /* :433 */
-const char* mlis_errstr_get(const MLIS_Ctx* ctx);                                                            /* :437 */
-int mlis_option_set(MLIS_Ctx* ctx, MLIS_Option id, ...);                                                     /* :443 */
-int mlis_option_set_str(MLIS_Ctx* ctx, const char* name, const char* value);                                 /* :453 */
-int mlis_option_get(MLIS_Ctx* ctx, MLIS_Option id, ...);                                                     /* :460 */
-int mlis_generate(MLIS_Ctx* ctx);                                                                            /* :467 */
-MLIS_Image* mlis_image_get(MLIS_Ctx* ctx, int idx);                                                          /* :472 */
-const char* mlis_infotext_get(MLIS_Ctx* ctx, int idx);                                                       /* :478 */
-int mlis_setup(MLIS_Ctx* ctx);                                                                               /* :484 */
-MLIS_Tensor* mlis_tensor_get(MLIS_Ctx* ctx, MLIS_TensorId id);                                               /* :489 */
-const MLIS_BackendInfo* mlis_backend_info_get(MLIS_Ctx* ctx, unsigned idx, int flags);                       /* :495-496 */
-/* :500-521 */
+MLIS_Ctx* mlis_ctx_create_i(int version);                                                                    /* :418-419 */
+void mlis_ctx_destroy(MLIS_Ctx** pctx);                                                                      /* :423 */
+const char* mlis_errstr_get(const MLIS_Ctx* ctx);                                                            /* :427 */
+int mlis_option_set(MLIS_Ctx* ctx, MLIS_Option id, ...);                                                     /* :433 */
+int mlis_option_set_str(MLIS_Ctx* ctx, const char* name, const char* value);                                 /* :443 */
+int mlis_option_get(MLIS_Ctx* ctx, MLIS_Option id, ...);                                                     /* :450 */
+int mlis_generate(MLIS_Ctx* ctx);                                                                            /* :457 */
+MLIS_Image* mlis_image_get(MLIS_Ctx* ctx, int idx);                                                          /* :462 */
+const char* mlis_infotext_get(MLIS_Ctx* ctx, int idx);                                                       /* :468 */
+int mlis_setup(MLIS_Ctx* ctx);                                                                               /* :474 */
+MLIS_Tensor* mlis_tensor_get(MLIS_Ctx* ctx, MLIS_TensorId id);                                               /* :479 */
+const MLIS_BackendInfo* mlis_backend_info_get(MLIS_Ctx* ctx, unsigned idx, int flags);                       /* :485-486 */
+/* :490-508 */
 const char* mlis_stage_str(MLIS_Stage id);
 const char* mlis_stage_desc(MLIS_Stage id);
 MLIS_Stage mlis_stage_fromz(const char* str);
@@ -93,14 +93,14 @@ const char* mlis_model_type_desc(MLIS_ModelType id);
 MLIS_ModelType mlis_model_type_fromz(const char* str);
 const char* mlis_option_str(MLIS_Option id);
 MLIS_Option mlis_option_fromz(const char* str);
-/* :528-556 */
+/* :515-549 */
 int mlis_image_encode(MLIS_Ctx* ctx, const MLIS_Tensor* image, MLIS_Tensor* latent, int flags);
 int mlis_image_decode(MLIS_Ctx* ctx, const MLIS_Tensor* latent, MLIS_Tensor* image, int flags);
 int mlis_mask_encode(MLIS_Ctx* ctx, const MLIS_Tensor* mask, MLIS_Tensor* lmask, int flags);
 int mlis_text_tokenize(MLIS_Ctx* ctx, const char* text, int32_t** ptokens, MLIS_SubModel model);
 int mlis_clip_text_encode(MLIS_Ctx* ctx, const char* text, MLIS_Tensor* embed, MLIS_Tensor* feat, MLIS_SubModel model, int flags);
 enum { MLIS_CTEF_NO_NORM = 1 };
-/* :565-571 */
+/* :552-558 */
 void mlis_tensor_free(MLIS_Tensor*);
 size_t mlis_tensor_count(const MLIS_Tensor*);
 void mlis_tensor_resize(MLIS_Tensor*, int n0, int n1, int n2, int n3);

@@ -66,6 +66,12 @@ int mlsd_graph_destroy(void* graph_exec);
 int mlsd_rccl_unique_id(void* out128);
 int mlsd_rccl_init(void** comm, int world, int rank, const void* id128);
 int mlsd_rccl_destroy(void* comm);
+/* the same communicator interface over a HOST transport supplied by the launcher (gloo, MPI, ...): the engine's exchange entry
+ * points (mlis_amd_bcast_cond / mlis_amd_gather_results) run unchanged; device buffers are staged through host memory (in the
+ * dry runtime they already are host memory).  Callbacks return 0 on success. */
+typedef int (*mlsd_host_bcast_fn)(void* user, void* buf, size_t nbytes, int root);
+typedef int (*mlsd_host_allgather_fn)(void* user, const void* send, void* recv, size_t nbytes_per_rank);
+int mlsd_comm_host(void** comm, int world, int rank, mlsd_host_bcast_fn bcast, mlsd_host_allgather_fn all_gather, void* user);
 int mlsd_rccl_bcast(void* comm, void* buf, size_t nbytes, int root, void* stream);
 int mlsd_rccl_all_gather(void* comm, const void* send, void* recv, size_t nbytes_per_rank, void* stream);
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "mlsd_kernels.h"
 
@@ -35,6 +36,25 @@ int rccl_load()
 
 int chk(int r, const char* what) { return r == 0 ? 0 : mlsd_set_error(-1, "%s failed: %s", what, g.errstr ? g.errstr(r) : "RCCL error"); }
 
+// A communicator is either RCCL's (device buffers, asynchronous on the stream) or a HOST transport supplied by the launcher
+// (two callbacks that move host bytes: gloo, MPI, ...).  The host transport serves the CPU-only tests -- the engine's
+// mlis_amd_bcast_cond / mlis_amd_gather_results run unchanged on two gloo ranks in the dry runtime -- and machines without RCCL
+// (device buffers are staged through host memory there).
+struct Comm {
+    int kind;                 // 0 = RCCL, 1 = host transport
+    void* nccl;
+    int world, rank;
+    mlsd_host_bcast_fn hb; mlsd_host_allgather_fn hg; void* user;
+};
+
+int host_stage(void* dev, void* host, size_t n, int to_host, hipStream_t st)
+{
+    if (mlsd_runtime_is_dry()) { if (dev != host) memcpy(to_host ? host : dev, to_host ? dev : host, n); return 0; }
+    MLSD_HIP_TRY(hipMemcpyAsync(to_host ? host : dev, to_host ? dev : host, n, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, st));
+    MLSD_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -52,21 +72,60 @@ MLSD_API int mlsd_rccl_init(void** comm, int world, int rank, const void* id128)
 {
     if (rccl_load()) return -1;
     UniqueId id; memcpy(&id, id128, 128);
-    return chk(g.init(comm, world, id, rank), "ncclCommInitRank");
+    void* nc = nullptr;
+    if (chk(g.init(&nc, world, id, rank), "ncclCommInitRank")) return -1;
+    Comm* c = (Comm*)calloc(1, sizeof(Comm));
+    c->kind = 0; c->nccl = nc; c->world = world; c->rank = rank;
+    *comm = c;
+    return 0;
 }
 
-MLSD_API int mlsd_rccl_destroy(void* comm) { return (comm && g.destroy) ? chk(g.destroy(comm), "ncclCommDestroy") : 0; }
+MLSD_API int mlsd_comm_host(void** comm, int world, int rank, mlsd_host_bcast_fn bcast, mlsd_host_allgather_fn all_gather, void* user)
+{
+    if (!comm || !bcast || !all_gather || world < 1 || rank < 0 || rank >= world) return mlsd_set_error(-1, "mlsd_comm_host: bad arguments");
+    Comm* c = (Comm*)calloc(1, sizeof(Comm));
+    c->kind = 1; c->world = world; c->rank = rank; c->hb = bcast; c->hg = all_gather; c->user = user;
+    *comm = c;
+    return 0;
+}
+
+MLSD_API int mlsd_rccl_destroy(void* comm)
+{
+    Comm* c = (Comm*)comm;
+    if (!c) return 0;
+    int r = (c->kind == 0 && c->nccl && g.destroy) ? chk(g.destroy(c->nccl), "ncclCommDestroy") : 0;
+    free(c);
+    return r;
+}
 
 MLSD_API int mlsd_rccl_bcast(void* comm, void* buf, size_t nbytes, int root, void* stream)
 {
-    if (!comm) return mlsd_set_error(-1, "mlsd_rccl_bcast: no communicator");
-    return chk(g.bcast(buf, buf, nbytes, 0 /* ncclInt8 */, root, comm, (hipStream_t)stream), "ncclBroadcast");
+    Comm* c = (Comm*)comm;
+    if (!c) return mlsd_set_error(-1, "mlsd_rccl_bcast: no communicator");
+    if (c->kind == 0) return chk(g.bcast(buf, buf, nbytes, 0 /* ncclInt8 */, root, c->nccl, (hipStream_t)stream), "ncclBroadcast");
+    void* h = mlsd_runtime_is_dry() ? buf : malloc(nbytes);
+    if (!h) return mlsd_set_error(-1, "mlsd_rccl_bcast: out of host memory");
+    int r = (c->rank == root) ? host_stage(buf, h, nbytes, 1, (hipStream_t)stream) : (mlsd_runtime_is_dry() ? 0 : (int)(hipStreamSynchronize((hipStream_t)stream) != hipSuccess));
+    if (!r && c->hb(c->user, h, nbytes, root)) r = mlsd_set_error(-1, "host transport: broadcast failed");
+    if (!r && c->rank != root) r = host_stage(buf, h, nbytes, 0, (hipStream_t)stream);
+    if (h != buf) free(h);
+    return r;
 }
 
 MLSD_API int mlsd_rccl_all_gather(void* comm, const void* send, void* recv, size_t nbytes_per_rank, void* stream)
 {
-    if (!comm) return mlsd_set_error(-1, "mlsd_rccl_all_gather: no communicator");
-    return chk(g.allgather(send, recv, nbytes_per_rank, 0 /* ncclInt8 */, comm, (hipStream_t)stream), "ncclAllGather");
+    Comm* c = (Comm*)comm;
+    if (!c) return mlsd_set_error(-1, "mlsd_rccl_all_gather: no communicator");
+    if (c->kind == 0) return chk(g.allgather(send, recv, nbytes_per_rank, 0 /* ncclInt8 */, c->nccl, (hipStream_t)stream), "ncclAllGather");
+    const bool dry = mlsd_runtime_is_dry();
+    void* hs = dry ? (void*)send : malloc(nbytes_per_rank);
+    void* hr = dry ? recv : malloc(nbytes_per_rank * c->world);
+    if (!hs || !hr) { if (!dry) { free(hs); free(hr); } return mlsd_set_error(-1, "mlsd_rccl_all_gather: out of host memory"); }
+    int r = host_stage((void*)send, hs, nbytes_per_rank, 1, (hipStream_t)stream);
+    if (!r && c->hg(c->user, hs, hr, nbytes_per_rank)) r = mlsd_set_error(-1, "host transport: all-gather failed");
+    if (!r) r = host_stage(recv, hr, nbytes_per_rank * c->world, 0, (hipStream_t)stream);
+    if (!dry) { free(hs); free(hr); }
+    return r;
 }
 
 }  // extern "C"

@@ -96,12 +96,14 @@ MLSD_API int mlsd_free(void* p)
 MLSD_API int mlsd_host_alloc(void** out, size_t nbytes)
 {
     *out = NULL;
+    if (g_dry) { *out = calloc(1, nbytes ? nbytes : 16); return *out ? 0 : mlsd_set_error(-1, "out of host memory"); }
     MLSD_HIP_TRY(hipHostMalloc(out, nbytes ? nbytes : 16, hipHostMallocDefault));
     return 0;
 }
 
 MLSD_API int mlsd_host_free(void* p)
 {
+    if (g_dry) { free(p); return 0; }
     if (p) MLSD_HIP_TRY(hipHostFree(p));
     return 0;
 }
@@ -125,6 +127,7 @@ MLSD_API int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind, vo
 MLSD_API int mlsd_stream_create(void** out)
 {
     hipStream_t s;
+    if (g_dry) { *out = (void*)(uintptr_t)0xD0;  return 0; }      /* dry runtime: a token, never handed to HIP */
     MLSD_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out = (void*)s;
     return 0;
@@ -159,6 +162,7 @@ MLSD_API int mlsd_cu_census(unsigned* out_dev, int n_blocks, int spin_cycles, vo
 
 MLSD_API int mlsd_stream_destroy(void* s)
 {
+    if (g_dry || s == (void*)(uintptr_t)0xD0) return 0;
     if (s) MLSD_HIP_TRY(hipStreamDestroy((hipStream_t)s));
     return 0;
 }
@@ -179,6 +183,7 @@ MLSD_API int mlsd_device_sync(void)
 MLSD_API int mlsd_event_create(void** out)
 {
     hipEvent_t e;
+    if (g_dry) { *out = (void*)(uintptr_t)0xE0; return 0; }
     MLSD_HIP_TRY(hipEventCreate(&e));
     *out = (void*)e;
     return 0;
@@ -186,6 +191,7 @@ MLSD_API int mlsd_event_create(void** out)
 
 MLSD_API int mlsd_event_destroy(void* e)
 {
+    if (g_dry || e == (void*)(uintptr_t)0xE0) return 0;
     if (e) MLSD_HIP_TRY(hipEventDestroy((hipEvent_t)e));
     return 0;
 }

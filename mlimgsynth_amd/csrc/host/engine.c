@@ -254,6 +254,13 @@ MLB_API int mlis_amd_gather_results(MLIS_AmdCtx* S, void* comm, int what, void* 
 	return mlsd_rccl_all_gather(comm, what ? (void*)S->d_img : (void*)S->d_x, recv_dev, nb, S->stream) ? -1 : 1;
 }
 
+/* read-only view of the conditioning the UNet plan will use (what = 0: cond [N][77][n_ctx] fp32, 1: label [N][adm]): tests */
+MLB_API const void* mlis_amd_cond_device(MLIS_AmdCtx* S, int what)
+{
+	MLTensor *t = what ? S->unet.t_l : S->unet.t_c;
+	return t ? t->in_stage : NULL;
+}
+
 MLB_API int mlis_amd_seed(MLIS_AmdCtx* S, const uint64_t* seeds)
 {
 	for (int b=0;b<S->B;++b) { S->rng[b].seed = seeds[b]; S->rng[b].offset = 0; }

@@ -1,6 +1,10 @@
-"""N>1 plumbing on CPU: two gloo ranks run the same broadcast / shard / gather sequence bench.py uses
-(mlimgsynth_amd/dist.py) around a stand-in for the per-image work, and the gathered result must equal the
-single-process result (image -> seed mapping independent of the number of ranks, no per-step collective)."""
+"""N>1 plumbing on CPU: two gloo ranks run the per-batch sequence of the image-sharded job -- mlimgsynth_amd.dist.job_step, THE
+function bench.py runs -- through the library's own C entry points (mlis_amd_set_cond, mlis_amd_bcast_cond,
+mlis_amd_gather_results) on engines built in the dry runtime (device memory = host memory, no kernels), with the library's
+communicator over a host transport (gloo) in place of RCCL.  Only the denoising itself is a stand-in (no GPU here): each image's
+"latent" depends on its own seed and on the broadcast conditioning.  The gathered result must equal the single-process
+expectation (image -> seed mapping independent of the number of ranks, no per-step collective)."""
+import ctypes
 import os
 import socket
 import sys
@@ -14,36 +18,64 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+LAT = 8            # tiny model, 64 x 64 pixels
 
-def fake_image(seed, cond):
-    """stand-in for 'denoise one image': depends on the image's own seed and on the shared conditioning"""
-    g = torch.Generator().manual_seed(int(seed))
-    return torch.randn(4, 8, 8, generator=g) * cond.sum()
+
+def fake_latents(seeds, cond_sum):
+    """stand-in for 'denoise these images': depends on each image's own seed and on the shared conditioning"""
+    out = []
+    for s in seeds:
+        g = torch.Generator().manual_seed(int(s))
+        out.append((torch.randn(4, LAT, LAT, generator=g) * cond_sum).numpy())
+    return np.stack(out).astype(np.float32)
+
+
+def conditioning(step, n_ctx):
+    cond = (np.arange(77 * n_ctx, dtype=np.float32).reshape(77, n_ctx) / 1000 + step).astype(np.float32)
+    return cond, (cond * -0.5).astype(np.float32)
 
 
 def worker(rank, world, port, B, steps, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlimgsynth_amd import _lib, engine
     from mlimgsynth_amd import dist as mdist
-    cond = torch.zeros(2, 77, 16)
-    label = torch.zeros(2, 5)
+    L = _lib.lib()
+    L.mlsd_runtime_dry(1)
+    Lh = engine._proto2()
+    Lh.mlis_amd_bcast_cond.argtypes = [_lib.vp, _lib.vp, ctypes.c_int]
+    Lh.mlis_amd_gather_results.argtypes = [_lib.vp, _lib.vp, ctypes.c_int, _lib.vp]
+    Lh.mlis_amd_cond_device.restype = _lib.vp
+    Lh.mlis_amd_cond_device.argtypes = [_lib.vp, ctypes.c_int]
+    g = engine.Generator("tiny", LAT * 8, LAT * 8, B, n_step=2, defer_weights=True)     # plans only: no kernel can run here
+    n_ctx = g.P.n_ctx
+    comm = mdist.host_comm(L, world, rank)
+    gather = _lib.DeviceBuffer(world * B * 4 * LAT * LAT * 4)
     outs = []
     for step in range(steps):
-        if rank == 0:
-            cond.copy_(torch.arange(2 * 77 * 16, dtype=torch.float32).reshape(2, 77, 16) / 1000 + step)
-            label.fill_(step + 0.5)
-        mdist.broadcast_conditioning(cond, label, 0)
-        assert float(label[0, 0]) == step + 0.5                      # every rank sees rank 0's conditioning
-        seeds = mdist.image_seeds(step, world, rank, B)
-        local = torch.stack([fake_image(s, cond) for s in seeds])
-        got = mdist.gather_latents(local, 0)
-        if rank == 0:
-            outs.append(torch.cat(got))
+        cond, uncond = conditioning(step, n_ctx)
+
+        def read_cond():
+            c = np.empty((2 * B, 77, n_ctx), np.float32)
+            L.mlsd_memcpy(c.ctypes.data_as(_lib.vp), _lib.vp(Lh.mlis_amd_cond_device(g.h, 0)), ctypes.c_size_t(c.nbytes), 1, None)
+            return c
+
+        def generate():
+            c = read_cond()                      # every rank must hold rank 0's conditioning by now (cond rows, then uncond rows)
+            assert np.array_equal(c[0], cond) and np.array_equal(c[B], uncond), "conditioning was not broadcast"
+            lat = fake_latents(mdist.image_seeds(step, world, rank, B), float(c[0].sum()))
+            L.mlsd_memcpy(_lib.vp(g.latent_ptr()), lat.ctypes.data_as(_lib.vp), ctypes.c_size_t(lat.nbytes), 0, None)
+            return lat
+
+        mdist.job_step(Lh, engine.check1, g.h, comm, world, rank, lambda: g.set_cond(cond, None, uncond, None), generate,
+                       _lib.vp(gather.ptr))
+        outs.append(gather.download((world * B, 4, LAT, LAT), np.float32))              # every rank holds the whole batch
     t = mdist.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))
     assert abs(t - 0.1 * world) < 1e-9
-    if rank == 0:
-        q.put(torch.stack(outs).numpy())
+    q.put((rank, np.stack(outs)))
     dist.barrier()
+    assert L.mlsd_rccl_destroy(comm) == 0
+    g.destroy()
     dist.destroy_process_group()
 
 
@@ -55,34 +87,37 @@ def free_port():
     return p
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_shard_equals_single_process():
+@pytest.mark.timeout(180)
+def test_two_rank_job_step_equals_single_process():
     B, steps, world = 3, 2, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, free_port_shared(), B, steps, q)) for r in range(world)]
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, B, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=100)
+    res = {}
+    import queue
+    for _ in range(3000):                       # (fails at once when a rank dies instead of waiting out the queue timeout)
+        try:
+            r, v = q.get(timeout=0.05)
+            res[r] = v
+        except queue.Empty:
+            pass
+        if len(res) == world or any(p.exitcode not in (None, 0) for p in procs):
+            break
+    assert len(res) == world, [p.exitcode for p in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     # single-process expectation: image i of global batch `step` has seed 42 + step*world*B + i
     exp = []
     for step in range(steps):
-        cond = torch.arange(2 * 77 * 16, dtype=torch.float32).reshape(2, 77, 16) / 1000 + step
-        exp.append(torch.stack([fake_image(42 + step * world * B + i, cond) for i in range(world * B)]))
-    assert np.array_equal(res, torch.stack(exp).numpy())
-
-
-_PORT = None
-
-
-def free_port_shared():
-    global _PORT
-    if _PORT is None:
-        _PORT = free_port()
-    return _PORT
+        cond, _ = conditioning(step, 64)
+        exp.append(fake_latents([42 + step * world * B + i for i in range(world * B)], float(cond.sum())))
+    exp = np.stack(exp)
+    for r in range(world):
+        assert np.array_equal(res[r], exp), r
 
 
 def test_seed_mapping_is_world_size_independent():
