@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--kernel-table", default="", help="write the per-kernel time table of one UNet evaluation to this file")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (sd15, sdxl + TAESD) reported beside the headline")
     ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--extras", action="store_true", help="run the secondary workloads also when the headline workload is not sdxl (tests)")
     return ap.parse_args()
 
 
@@ -306,7 +307,7 @@ def main():
     # ---- secondary workloads of the BASELINE metric (N=1 only, after the headline's timed region; the headline `value` is
     # untouched): SD1.5 512x512 batch 1 (configs[1]) and SDXL with the TAESD decoder (configs[4] without weight streaming)
     plist = g.unet_ctx().param_list()
-    extras = world == 1 and not a.no_extras and a.workload == "sdxl" and not a.tae
+    extras = world == 1 and not a.no_extras and ((a.workload == "sdxl" and not a.tae) or a.extras)
     aux15 = None
     if extras:
         g.destroy()

@@ -292,3 +292,29 @@ def test_bench_json_contract_on_tiny_workload():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] and c["value"] > 0 and c["unit"] == "images/s" and "oracle" in c["sample"]
     assert d["value"] > 50 * c["value"]                                          # a GPU against a CPU port, even on the tiny model
+    m = d["unet_eval_mfma"]                                                       # time-weighted matrix-pipe fraction of one whole evaluation
+    assert 0 < m["frac_of_mfma_peak"] < 1 and abs(m["frac_of_mfma_peak"] - m["tflops"] / 2500.0) < 1e-3 and m["by_family"]
+    assert abs(sum(v["share"] for v in m["by_family"].values()) - 1) < 0.35       # (top six families)
+
+
+def test_bench_line_carries_the_whole_baseline_metric():
+    """beside the unchanged headline value the one JSON line holds SD1.5 512x512 b1 (BASELINE configs[1]) and
+    SDXL + TAESD as extra keys, each with its own roofline, and the CPU sample of BASELINE.md section 3 (one SD1.5 evaluation).
+    Run with the tiny model as the headline (--extras) so that the test is about the keys, not about minutes of SDXL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "tiny",
+                          "--extras", "--extra-steps", "1"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key, cfg in (("sd15", "sd15-512x512"), ("sdxl_tae", "sdxl-1024x1024")):
+        e = d[key]
+        assert e["config"].startswith(cfg) and e["value"] > 0 and e["unit"] == "images/s" and e["ms_per_step"] > 0
+        assert abs(e["value"] - (4 if key == "sdxl_tae" else 1) * 1e3 / e["ms_per_step"]) / e["value"] < 0.02
+        assert e["roofline"]["frac"] > 0 and 0 < e["unet_eval_mfma"]["frac_of_mfma_peak"] < 1
+    assert d["sdxl_tae"]["config"].endswith("-tae") and d["sd15"]["config"].endswith("-vae")
+    c15 = d["cpu_baseline"]["sd15"]
+    assert c15["kind"] == "port" and c15["value"] > 0 and c15["s_per_unet_eval"] > 0 and "SD1.5" in c15["sample"]
