@@ -535,11 +535,186 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tk <= 96, no causal mask (the 77-token cross attention of every UNet layer): ONE pass.
+//   The general kernels walk 64-key tiles with an online softmax: for 77 keys that is two tiles (128 key slots, 28 MFMAs and
+//   ~340 vector instructions per 32 query rows), two barriers and a rescale test per block, and the launch is bound by that
+//   per-block chain (tools/attn_bench.py: 20.8 us for 42 MB).  Here the whole key set (padded to 96 = three 32-key sub-tiles,
+//   rows past Tk are clamped duplicates whose scores are masked) is staged ONCE per workgroup; a wave then walks QB 32-row
+//   query blocks: S^T = K.Q^T for the sub-tiles that hold keys, one max / exp2 / sum over the lane's <= 48 scores, O^T += V^T.P
+//   for the 16-key steps that hold keys (77 keys: 12 + 10 MFMAs, 40 exponentials per lane), no loop over keys, no barrier and
+//   no rescale branch in the block loop; the next block's Q is fetched as soon as the current QK^T has consumed the registers.
+//   Same fragment layouts as attn_kernel (swapped QK^T, S accumulators reused as the P.V B operand, V^T by ds_read_b64_tr_b16).
+template <int DH, int WPS>       // WPS: waves per SIMD the register allocation aims for
+__global__ __launch_bounds__(256, WPS) void attn_tk96_kernel(const AttnP p, const int QB)
+{
+    constexpr int DQK = (DH + 15) / 16 * 16, NKS = DQK / 16, NDV = (DH + 31) / 32;
+    constexpr int KSTR = DQK * 2 + 16;             // bytes; conflict-free b128 row reads (see attn_kernel)
+    constexpr int VSTR = ((NDV & 1) ? NDV : NDV + 1) * 64;
+    constexpr int CH = DH / 8, NK = 96;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[NK * KSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[NK * VSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // all blocks of one (batch, head) group on one XCD (see attn_kernel)
+    const int gk = slot / p.nq, qb = slot - gk * p.nq;
+    const int grp = gk * 8 + xcd;
+    if (grp >= p.G) return;
+    const int head = grp % p.n_head, b = grp / p.n_head;
+    const _Float16* Qg = p.q + (long)b * p.bsq + (long)head * DH;
+    const _Float16* Kg = p.k + (long)b * p.bsk + (long)head * DH;
+    const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
+    const int Tk = p.Tk;
+
+    auto load_q = [&](f16x8 (&qf)[NKS], int qrow) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int c = 16 * ks + 8 * lh;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qrow < p.Tq && c < DH) v = *reinterpret_cast<const uint4*>(Qg + (long)qrow * p.ldq + c);
+            qf[ks] = __builtin_bit_cast(f16x8, v);
+        }
+    };
+    const int q_first = qb * QB * 128 + wave * 32 + lr;
+    f16x8 qf[NKS];
+    load_q(qf, q_first);                                             // in flight while the keys are staged
+
+    // K / V (rows >= Tk: duplicates of the last key) -> LDS; padding columns (d_head not a multiple of 16 / 32) zeroed
+    if constexpr (DQK != DH || NDV * 32 != DH) {
+        for (int i = tid * 16; i < NK * KSTR; i += 256 * 16) *reinterpret_cast<uint4*>(Ks + i) = make_uint4(0, 0, 0, 0);
+        for (int i = tid * 16; i < NK * VSTR; i += 256 * 16) *reinterpret_cast<uint4*>(Vs + i) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+    const int nrow = min(NK, (Tk + 31) & ~31);                       // sub-tiles that hold at least one key
+    for (int idx = tid; idx < nrow * CH; idx += 256) {
+        const int row = idx / CH, ch = idx - row * CH;
+        const long r = min(row, Tk - 1);
+        const uint4 a = *reinterpret_cast<const uint4*>(Kg + r * p.ldk + ch * 8);
+        const uint4 c = *reinterpret_cast<const uint4*>(Vg + r * p.ldv + ch * 8);
+        *reinterpret_cast<uint4*>(Ks + row * KSTR + ch * 16) = a;
+        *reinterpret_cast<uint4*>(Vs + row * VSTR + ch * 16) = c;
+    }
+    __syncthreads();
+
+    const int tg = lane >> 4, ti = lane & 15;                        // transposed-read lane pattern (see attn_kernel)
+    const int tr_row = 4 * (tg >> 1) + (ti >> 2);
+    const int tr_col = 16 * (tg & 1) + 4 * (ti & 3);
+
+    for (int it = 0; it < QB; ++it) {
+        const int qrow = q_first + it * 128;
+        if (qrow - lr >= p.Tq) break;                                // wave-uniform: the wave's 32 rows are past the end
+        // ---- S^T = K . Q^T for the sub-tiles that hold keys
+        f32x16 sacc[3];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            f32x16 r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (32 * kt < Tk) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (32 * kt + lr) * KSTR + (16 * ks + 8 * lh) * 2);
+                    r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], r, 0, 0, 0);
+                }
+            }
+            sacc[kt] = r;
+        }
+        if (it + 1 < QB) load_q(qf, qrow + 128);                     // next block's Q: lands under the softmax / P.V below
+        // ---- mask the clamped duplicates, row maximum (in-lane + one cross-half exchange)
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            if (32 * kt < Tk) {
+                if (32 * kt + 32 > Tk) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (32 * kt + (e & 3) + 8 * (e >> 2) + 4 * lh >= Tk) sacc[kt][e] = -1.0e30f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) mx = max3f(mx, sacc[kt][e], sacc[kt][e + 1]);
+            }
+        }
+        mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);
+        const float msc = -mx * p.sc;
+        f32x2 vsum = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                             // register quad j: keys 32 kt + 8 j + {0..3} + 4 lh
+                if (32 * kt + 8 * j < Tk) {
+#pragma unroll
+                    for (int e = 4 * j; e < 4 * j + 4; e += 2) {
+                        const f32x2 r = exp2_pair(sacc[kt][e], sacc[kt][e + 1], p.sc, msc);
+                        sacc[kt][e] = r.x; sacc[kt][e + 1] = r.y;
+                        vsum += r;
+                    }
+                }
+            }
+        }
+        // ---- O^T = V^T . P over the 16-key steps that hold keys
+        f32x16 oacc[NDV];
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kb = 32 * kt + 16 * s;
+                if (kb < Tk) {
+                    f16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sacc[kt][8 * s + j];
+#pragma unroll
+                    for (int d = 0; d < NDV; ++d) {
+                        const unsigned char* a0 = Vs + (kb + tr_row) * VSTR + (32 * d + tr_col) * 2;
+                        union { h16x4 h[2]; f16x8 f; } vf;
+                        vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)a0);
+                        vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(a0 + 8 * VSTR));
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.f, pf, oacc[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- O = O^T / l, heads merged (as attn_kernel's epilogue)
+        const float l = vsum.x + vsum.y;
+        const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
+        if (qrow < p.Tq) {
+            _Float16* og = p.o + (long)b * p.bso + (long)qrow * p.ldo + (long)head * DH;
+            auto piece = [&](int d, int eg) __attribute__((always_inline)) {
+                const f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
+                                 (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
+                return __builtin_bit_cast(u32x2, h);
+            };
+#pragma unroll
+            for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                for (int eg = 0; eg < 4; eg += 2) {
+                    if (p.wide_o && 32 * d + 8 * eg + 16 <= DH) {
+                        u32x2 a = piece(d, eg), c = piece(d, eg + 1);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                        *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    } else {
+#pragma unroll
+                        for (int e2 = eg; e2 < eg + 2; ++e2) {
+                            const int dbase = 32 * d + 8 * e2 + 4 * lh;
+                            if (dbase < DH) *reinterpret_cast<u32x2*>(og + dbase) = piece(d, e2);
+                        }
+                    }
+                }
+        }
+    }
+}
+
 int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_kernel
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
+int g_attn_tk96 = 1;        // Tk <= 96 without a causal mask: the one-pass kernel (0 = the general kernels; A/B timing)
+int g_attn_tk96_qb = 0;     // query blocks of 128 rows per workgroup (0 = by the launch size)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
@@ -575,6 +750,30 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
     return mlsd_check_launch("attn_kernel");
 }
 
+
+template <int DH>
+int launch_attn_tk96(const mlsd_attn_args* a, hipStream_t st)
+{
+    AttnP p;
+    p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = 0;
+    p.sc = (float)(1.4426950408889634 / sqrt((double)a->d_head));
+    p.G = a->n_head * a->n_batch;
+    p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
+    const int G8 = 8 * ((p.G + 7) / 8), nblk128 = (a->Tq + 127) / 128;
+    // query blocks per workgroup: the keys are staged once per workgroup, so fewer, longer workgroups stage less -- as long as
+    // the launch still holds >= 2 workgroups per CU to hide the Q / O latency of one behind the arithmetic of another
+    int QB = g_attn_tk96_qb;
+    if (QB <= 0) { QB = 8; while (QB > 1 && (long)G8 * ((nblk128 + QB - 1) / QB) < 512) QB >>= 1; }
+    p.nq = (nblk128 + QB - 1) / QB;
+    const dim3 grid((unsigned)(G8 * p.nq));
+    if (DH == 64 && g_attn_tk96 == 2) hipLaunchKernelGGL((attn_tk96_kernel<DH, (DH == 64 ? 4 : 2)>), grid, dim3(256), 0, st, p, QB);   // (A/B: 127 registers + 2 spilled)
+    else hipLaunchKernelGGL((attn_tk96_kernel<DH, (DH <= 80 ? 3 : 2)>), grid, dim3(256), 0, st, p, QB);
+    return mlsd_check_launch("attn_tk96_kernel");
+}
+
 }  // namespace
 
 extern "C" {
@@ -585,6 +784,15 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
     if (a->Tq <= 0 || a->Tk <= 0 || a->n_batch <= 0 || a->n_head <= 0) return mlsd_set_error(-1, "mlsd_attention: empty problem");
     if ((a->ldq & 7) || (a->ldk & 7) || (a->ldv & 7) || (a->ldo & 3)) return mlsd_set_error(-1, "mlsd_attention: strides must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
+    if (g_attn_tk96 && !a->causal && a->Tk <= 96) {
+        switch (a->d_head) {
+        case 40: return launch_attn_tk96<40>(a, st);
+        case 64: return launch_attn_tk96<64>(a, st);
+        case 80: return launch_attn_tk96<80>(a, st);
+        case 160: return launch_attn_tk96<160>(a, st);
+        default: break;
+        }
+    }
     switch (a->d_head) {
     case 32: return launch_attn<32>(a, st);
     case 40: return launch_attn<40>(a, st);
@@ -603,5 +811,6 @@ MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
+MLSD_API void mlsd_attention_tk96(int on, int qb) { g_attn_tk96 = on; g_attn_tk96_qb = qb; }
 
 }  // extern "C"

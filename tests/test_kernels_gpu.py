@@ -430,7 +430,11 @@ def test_conv2d_split_k(K):
     (1, 2, 80, 130, 77, 0), (1, 2, 160, 64, 64, 0), (1, 2, 32, 64, 77, 0), (2, 10, 64, 1024, 1024, 0),
     (1, 1, 64, 1, 1, 0), (1, 2, 64, 300, 300, 1),
     # d_head 64, Tq % 256 == 0: the 64-rows-per-wave LDS-DMA kernel (ragged key counts: clamped duplicates are masked)
-    (2, 3, 64, 256, 256, 0), (1, 2, 64, 512, 77, 0), (1, 3, 64, 256, 333, 0), (1, 9, 64, 768, 32, 0), (3, 3, 64, 256, 1, 0)])
+    (2, 3, 64, 256, 256, 0), (1, 2, 64, 512, 77, 0), (1, 3, 64, 256, 333, 0), (1, 9, 64, 768, 32, 0), (3, 3, 64, 256, 1, 0),
+    # Tk <= 96 without a mask: the one-pass kernel (every d_head it is built for; key counts on both sides of the 32 / 16 / 8-key
+    # skip conditions; ragged query counts; the SDXL cross-attention launch itself)
+    (1, 2, 40, 200, 77, 0), (1, 2, 160, 64, 77, 0), (2, 3, 64, 300, 96, 0), (1, 2, 64, 128, 65, 0), (1, 2, 64, 128, 80, 0),
+    (1, 2, 64, 130, 33, 0), (1, 2, 80, 100, 1, 0), (1, 3, 64, 96, 64, 0), (1, 2, 40, 64, 17, 0), (8, 20, 64, 1024, 77, 0)])
 def test_attention(K, nb, heads, dh, tq, tk, causal):
     kernels, _lib = K
     rng = np.random.default_rng(dh + tq)
@@ -478,6 +482,39 @@ def test_attention_output_store_width(K, dh, tq, tk):
         outs.append(got[:, :D].copy())
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize("dh,tq,tk,qb", [(64, 1000, 77, 4), (64, 4096, 77, 8), (80, 300, 50, 2), (160, 256, 77, 2), (40, 520, 96, 3)])
+def test_attention_one_pass_kernel_vs_general_kernel(K, dh, tq, tk, qb):
+    """The Tk <= 96 kernel with several 128-row query blocks per workgroup (also past the end of the sequence, and a count that does
+    not divide it) against the general tile-loop kernel on the same operands: same fp16 rounding points, so they agree far inside
+    the tolerance against the fp32 oracle; both builds of the d_head 64 kernel (3 / 4 waves per SIMD) give identical bits."""
+    kernels, _lib = K
+    L = _lib.lib()
+    rng = np.random.default_rng(dh + tq + tk)
+    nb, heads = 2, 5
+    D = heads * dh
+    q, k, v = (rng.standard_normal((nb, t, D)).astype(np.float16) for t in (tq, tk, tk))
+    dq, dk, dv = dev(_lib, q), dev(_lib, k), dev(_lib, v)
+    do = _lib.DeviceBuffer(nb * tq * D * 2)
+    a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
+                         bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
+    outs = {}
+    try:
+        for name, on, b in (("general", 0, 0), ("auto", 1, 0), ("qb", 1, qb), ("w4", 2, qb)):
+            L.mlsd_attention_tk96(on, b)
+            _lib.check(L.mlsd_memset(_lib.vp(do.ptr), 0x7C, ctypes.c_size_t(do.nbytes), None))
+            kernels.attention(a)
+            outs[name] = do.download((nb, tq, D), np.float16)
+    finally:
+        L.mlsd_attention_tk96(1, 0)
+    g = outs["general"].astype(np.float32)
+    assert np.isfinite(g).all()
+    for name in ("auto", "qb", "w4"):
+        o = outs[name].astype(np.float32)
+        assert np.isfinite(o).all() and not (outs[name].view(np.uint16) == 0x7C7C).any(), name
+        assert rel(o, g) < 5e-4, (name, rel(o, g))
+    assert np.array_equal(outs["auto"], outs["qb"]) and np.array_equal(outs["qb"], outs["w4"])
 
 
 def test_attention_fused_qkv_strides(K):

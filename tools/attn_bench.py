@@ -9,7 +9,35 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ev = [vp(), vp()]
 for e in ev: L.mlsd_event_create(ctypes.byref(e))
 rng = np.random.default_rng(0)
-for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024), (8, 20, 64, 1024, 77)]:
+def timeit(fn):
+    for _ in range(3): fn()
+    L.mlsd_event_record(ev[0], None)
+    for _ in range(reps): fn()
+    L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
+    ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
+    return ms.value / reps
+
+# ---- the 77-key cross attention: general tile-loop kernels against the one-pass kernel (query blocks per workgroup, register budget)
+for (nb, heads, dh, tq, tk) in [(8, 20, 64, 1024, 77), (8, 10, 64, 4096, 77), (2, 8, 40, 4096, 77), (2, 8, 160, 256, 77)]:
+    D = heads * dh
+    q = rng.standard_normal((nb, tq, D)).astype(np.float16); k = rng.standard_normal((nb, tk, D)).astype(np.float16)
+    v = rng.standard_normal((nb, tk, D)).astype(np.float16)
+    dq, dk, dv = _lib.from_numpy(q), _lib.from_numpy(k), _lib.from_numpy(v)
+    do = _lib.DeviceBuffer(nb * tq * D * 2)
+    a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
+                         bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
+    ref = None
+    for name, on, qb in [("general kernels", 0, 0), ("one pass, auto", 1, 0), ("one pass, qb 1", 1, 1), ("one pass, qb 2", 1, 2), ("one pass, qb 4", 1, 4),
+                         ("one pass, qb 8", 1, 8), ("one pass w4, auto", 2, 0), ("one pass w4, qb 1", 2, 1), ("one pass w4, qb 2", 2, 2)]:
+        L.mlsd_attention_tk96(on, qb)
+        t = timeit(lambda: kernels.attention(a))
+        o = do.download((nb, tq, D), np.float16).astype(np.float32)
+        if ref is None: ref = o
+        gb = 2.0 * nb * D * (2 * tq + 2 * tk) / 1e9
+        print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name:18s}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s  {gb/t/1e3:6.2f} TB/s   max|diff vs general| {np.abs(o - ref).max():.2e}", flush=True)
+    L.mlsd_attention_tk96(1, 0)
+
+for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)]:
     D = heads * dh
     q = rng.standard_normal((nb, tq, D)).astype(np.float16); k = rng.standard_normal((nb, tk, D)).astype(np.float16)
     v = rng.standard_normal((nb, tk, D)).astype(np.float16)
