@@ -708,11 +708,271 @@ __global__ __launch_bounds__(256, WPS) void attn_tk96_kernel(const AttnP p, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d_head = 64, no causal mask: the PING-PONG kernel.
+//   PMC on the kernels above: matrix pipes busy 28-39 % + vector ALU ~55 % ~ 94 %: a wave's QK^T -> softmax -> P.V chain runs
+//   almost serially and the 2-3 waves of a SIMD overlap little (compiler-ordered software pipelining lost to occupancy twice,
+//   DESIGN.md section 9.2).  Here the overlap is built into the block structure instead of the instruction order, the way the
+//   ping-pong GEMM tiles do it (gemm_pp.hpp):
+//     (operands of one (batch, head) must span < 2 GiB: 32-bit buffer offsets; the launcher checks)
+//     block = 8 waves = group A (waves 0-3) + group B (waves 4-7), one wave of each group per SIMD, NB x 32 query rows per wave;
+//     the block alternates PHASES separated by ONE s_barrier:      phase g:  A: matrix   B: vector     g+1:  A: vector   B: matrix
+//       matrix phase (tile t):  O^T += V^T(t-1) . P(t-1)   then   S'(t) = K(t) . Q'^T       16 NB MFMAs, nothing else but LDS reads
+//       vector phase (tile t):  row max, (rare) rescale, P = exp2(S'), row sums                        no MFMA, no LDS
+//     so one SIMD always has one wave on its matrix pipe and the other on its vector ALU.  B runs one phase behind A on the SAME
+//     K / V tiles: K(t+1) and V(t) are staged (LDS-DMA, issued by group A at the start of its matrix phase t, two-slot rings)
+//     into the slots whose last reader (B, phase before) has passed the barrier, and are first read two phases later.
+//   The softmax argument costs no vector instruction: Q' = Q * (log2(e) / sqrt(d)) is folded into the query fragments once per
+//   block (fp32 product, one rounding), and the S' accumulators START at -m (the running, deferred maximum in the exp2 domain,
+//   known before the tile's QK^T because the vector phase of the previous tile has finished), so P = exp2(acc) directly;
+//   the 16 NB x 2 accumulator initialisations ride in the matrix phase, where the vector ALU idles.
+template <int NB, int WPS>      // NB: 32-row query blocks per wave; WPS: waves per SIMD the register allocation aims for (2 per resident block)
+__global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
+{
+    constexpr int DH = 64, RB = 128;                 // bytes per K/V row
+    __shared__ __attribute__((aligned(1024))) unsigned char Ks2[2][64 * RB];
+    __shared__ __attribute__((aligned(1024))) unsigned char Vs2[2][64 * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;        // group (0 = A, 1 = B), wave inside the group
+    const int lr = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gk = slot / p.nq, qb = slot - gk * p.nq;
+    const int g_ = gk * 8 + xcd;
+    if (g_ >= p.G) return;
+    const int head = g_ % p.n_head, b = g_ / p.n_head;
+    const int qw = qb * (256 * NB) + wave * (32 * NB);       // first query row of this wave
+
+    const _Float16* Qg = p.q + (long)b * p.bsq + (long)head * DH;
+    const _Float16* Kg = p.k + (long)b * p.bsk + (long)head * DH;
+    const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
+
+    // Q' fragments (B operand of S'^T = K . Q'^T): lane (lr = query, lh) holds Q[q][16 ks + 8 lh + j] * sc, rounded once
+    f16x8 qf[NB][4];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 raw = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh));
+            f16x8 sc8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc8[j] = (_Float16)((float)raw[j] * p.sc);
+            qf[sb][ks] = sc8;
+        }
+
+    const int nt = (p.Tk + 63) / 64;
+    // LDS-DMA staging by the 4 waves of group A: wave w fills rows 16w .. 16w+15 of a tile with two 1-KiB pieces per operand
+    // (K image: slot = chunk ^ ((row >> 1) & 7), V image: slot = chunk ^ (((row >> 1) & 1) << 2): see attn64x2_kernel)
+    // buffer_load ... lds through one descriptor per operand (base = this (batch, head)'s first row, range = its Tk rows): the
+    // per-lane part of the address is ONE 32-bit offset (row inside the wave's 8-row piece + swizzled chunk), the tile / piece
+    // advance is a scalar offset, and rows past Tk fail the range check and arrive as ZEROS (their scores are masked, P = 0).
+    const int srow = lane >> 3, sslot = lane & 7;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, (int)(((long)(p.Tk - 1) * p.ldk + DH) * 2), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((long)(p.Tk - 1) * p.ldv + DH) * 2), 0x00020000);
+    const int kvo0 = srow * (int)p.ldk * 2 + ((sslot ^ (srow >> 1)) << 4);              // piece 0 of a wave: rows 16 wq + srow
+    const int kvo1 = srow * (int)p.ldk * 2 + ((sslot ^ (4 | (srow >> 1))) << 4);        // piece 1: rows 16 wq + 8 + srow
+    const int vvo = srow * (int)p.ldv * 2 + ((sslot ^ (((srow >> 1) & 1) << 2)) << 4);
+    auto stage_k = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(Ks2[t & 1] + (wq * 16 + i * 8) * RB), 16,
+                                                     i ? kvo1 : kvo0, (t * 64 + wq * 16 + i * 8) * (int)p.ldk * 2, 0, 0);
+    };
+    auto stage_v = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(Vs2[t & 1] + (wq * 16 + i * 8) * RB), 16,
+                                                     vvo, (t * 64 + wq * 16 + i * 8) * (int)p.ldv * 2, 0, 0);
+    };
+
+    f32x16 oacc[NB][2];                               // O^T accumulators: [query block][d block of 32]
+    f32x16 sacc[NB][2];                               // S'^T accumulators: [query block][32-key sub-tile]
+    float msc[NB];                                    // running (deferred) maximum of the scaled scores, exp2 domain
+    f32x2 vsum[NB];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) {
+        msc[sb] = 0.f; vsum[sb] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oacc[sb][d][e] = 0.f; sacc[sb][d][e] = 0.f; }
+    }
+
+    if (grp == 0) stage_k(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(0) (group A's pieces) and everybody's Q
+    __syncthreads();
+
+    // fragment addressing (as attn64x2_kernel)
+    const int kswz = (lr >> 1) & 7;
+    const int tg = lane >> 4, ti = lane & 15;
+    const int tr_row = 4 * (tg >> 1) + (ti >> 2);
+    const int vswz = ((tr_row >> 1) & 1) << 2;
+    const int tr_c = 2 * (tg & 1) + ((ti & 3) >> 1), tr_b = 8 * (ti & 1);
+
+    // Phase bodies.  qk(t): S'(t) = -m + K(t) . Q'^T (group A also issues the staging of K(t+1) and V(t): both targets were last
+    // read, by group B, in the phase that just ended).  pv(t): O^T += V^T(t) . P(t).  sm(t): the softmax of tile t.
+    auto qk = [&](int t) __attribute__((always_inline)) {
+        if (grp == 0) {
+            if (t + 1 < nt) stage_k(t + 1);
+            stage_v(t);
+        }
+        const unsigned char* Ks = Ks2[t & 1];
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            const float ini = -msc[sb];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sacc[sb][0][e] = ini; sacc[sb][1][e] = ini; }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = ((2 * ks + lh) ^ kswz) << 4;
+            const f16x8 k0 = *reinterpret_cast<const f16x8*>(Ks + lr * RB + off);
+            const f16x8 k1 = *reinterpret_cast<const f16x8*>(Ks + (32 + lr) * RB + off);
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) {
+                sacc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[sb][ks], sacc[sb][0], 0, 0, 0);
+                sacc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[sb][ks], sacc[sb][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto pv = [&](int t) __attribute__((always_inline)) {
+        const unsigned char* Vs = Vs2[t & 1];
+        const bool sub1 = t * 64 + 32 < p.Tk;        // the tile's second 32-key sub-tile holds at least one key (wave-uniform)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && !sub1) continue;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const int kb = 32 * kt + 16 * sx;
+                f16x8 pf[NB];                         // P (fp32, left in the S' accumulators by sm) -> fp16 B operand, permuted k order
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[sb][j] = (_Float16)sacc[sb][kt][8 * sx + j];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned char* a0 = Vs + (kb + tr_row) * RB + (((4 * d + tr_c) ^ vswz) << 4) + tr_b;
+                    union { h16x4 h[2]; f16x8 f; } vf;
+                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)a0);
+                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(a0 + 8 * RB));
+#pragma unroll
+                    for (int sb = 0; sb < NB; ++sb)
+                        oacc[sb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.f, pf[sb], oacc[sb][d], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto sm = [&](int t) __attribute__((always_inline)) {
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            f32x16& sa = sacc[sb][0];
+            f32x16& sc_ = sacc[sb][1];
+            if (kv0 + 64 > p.Tk) {                    // ragged last tile (wave-uniform): mask the clamped duplicates
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (key >= p.Tk) sa[e] = -1.0e30f;
+                    if (key + 32 >= p.Tk) sc_[e] = -1.0e30f;
+                }
+            }
+            float mx = max3f(sa[0], sa[1], sc_[0]);
+            mx = max3f(mx, sc_[1], sa[2]);
+#pragma unroll
+            for (int e = 3; e < 16; e += 2) mx = max3f(mx, sa[e], (e + 1 < 16) ? sa[e + 1] : sa[e]);
+#pragma unroll
+            for (int e = 2; e < 16; e += 2) mx = max3f(mx, sc_[e], sc_[e + 1]);
+            mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);
+            // deferred rescale (T13): the reference maximum moves only when a row's tile maximum exceeds it by more than 2^6
+            // (P <= 64 keeps full relative precision in fp16); always in the first tile (m starts at 0, not at a maximum).
+            // The decision covers the whole wave and is taken BEFORE this tile's P is formed: O, l and P share one reference.
+            if (t == 0 || __any(mx > 6.0f)) {
+                const float dlt = t == 0 ? mx : fmaxf(mx, 0.f);
+                msc[sb] += dlt;
+                if (t > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-dlt);
+                    vsum[sb] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oacc[sb][d][e] *= alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sa[e] -= dlt; sc_[e] -= dlt; }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16& sx_ = kt ? sc_ : sa;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 r = {__builtin_amdgcn_exp2f(sx_[e]), __builtin_amdgcn_exp2f(sx_[e + 1])};
+                    sx_[e] = r.x; sx_[e + 1] = r.y;
+                    vsum[sb] += r;
+                }
+            }
+        }
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1), V(t) issued a phase ago have landed
+    };
+    auto phase_end = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                 // raw barrier (no vmcnt drain): LDS-DMA pieces stay in flight across it
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // Global phases g = 0 .. 2 nt + 1, one barrier after each of g = 0 .. 2 nt (2 nt + 1 barriers for every wave):
+    //   group A:  g = 0: qk(0)   g = 2t+1: sm(t)   g = 2t+2: pv(t) [+ qk(t+1)]          (ends with pv(nt-1) at g = 2 nt, then its epilogue)
+    //   group B:  the same sequence one phase later (idle at g = 0, pv(nt-1) at g = 2 nt + 1 with no barrier behind it)
+    if (grp == 1) phase_end();
+    qk(0);
+    phase_end();
+    for (int t = 0; t < nt; ++t) {
+        sm(t);
+        phase_end();
+        pv(t);
+        __builtin_amdgcn_sched_barrier(0);            // P(t) is dead here: the accumulators restart at -m for the next tile
+        if (t + 1 < nt) qk(t + 1);
+        if (t + 1 < nt || grp == 0) phase_end();
+    }
+
+    // ---- epilogue: O = O^T / l, heads merged.  o[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) {
+        const float l = vsum[sb].x + vsum[sb].y;      // a lane half holds the keys 4*lh + {0..3} + 8j of every 32
+        const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
+        _Float16* og = p.o + (long)b * p.bso + (long)(qw + 32 * sb + lr) * p.ldo + (long)head * DH;
+        auto piece = [&](int d, int eg) __attribute__((always_inline)) {
+            const f16x4 h = {(_Float16)(oacc[sb][d][4 * eg + 0] * inv), (_Float16)(oacc[sb][d][4 * eg + 1] * inv),
+                             (_Float16)(oacc[sb][d][4 * eg + 2] * inv), (_Float16)(oacc[sb][d][4 * eg + 3] * inv)};
+            return __builtin_bit_cast(u32x2, h);
+        };
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int eg = 0; eg < 4; eg += 2) {
+                if (p.wide_o) {                       // 16 bytes per lane (see attn_kernel's epilogue)
+                    u32x2 a = piece(d, eg), c = piece(d, eg + 1);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                    *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                } else {
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * eg + 4 * lh) = piece(d, eg);
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * (eg + 1) + 4 * lh) = piece(d, eg + 1);
+                }
+            }
+    }
+}
+
 int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_kernel
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
+int g_attn_pp = 1;          // ping-pong kernel for d_head 64: 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
 int g_attn_tk96 = 1;        // Tk <= 96 without a causal mask: the one-pass kernel (0 = the general kernels; A/B timing)
 int g_attn_tk96_qb = 0;     // query blocks of 128 rows per workgroup (0 = by the launch size)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
@@ -750,6 +1010,22 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
     return mlsd_check_launch("attn_kernel");
 }
 
+
+template <int NB, int WPS>
+int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
+{
+    AttnP p;
+    p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
+    p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = 0;
+    p.sc = (float)(1.4426950408889634 / sqrt(64.0));
+    p.nq = a->Tq / (256 * NB); p.G = a->n_head * a->n_batch;
+    p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
+    const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
+    hipLaunchKernelGGL((attn64pp_kernel<NB, WPS>), grid, dim3(512), 0, st, p);
+    return mlsd_check_launch("attn64pp_kernel");
+}
 
 template <int DH>
 int launch_attn_tk96(const mlsd_attn_args* a, hipStream_t st)
@@ -797,6 +1073,13 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
     case 32: return launch_attn<32>(a, st);
     case 40: return launch_attn<40>(a, st);
     case 64:
+        if (g_attn_pp && !g_attn_force_old && !a->causal && !(a->Tq & 255) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) &&
+            (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30)) {
+            const bool big = !(a->Tq & 511) && a->Tq >= 2048;
+            if (g_attn_pp == 3 ? !(a->Tq & 511) : (g_attn_pp == 1 && big)) return launch_attn64pp<2, 2>(a, st);
+            if (g_attn_pp == 4) return launch_attn64pp<1, 2>(a, st);
+            return launch_attn64pp<1, 4>(a, st);
+        }
         // every q/k/v row must be 16-byte aligned for the LDS-DMA pieces (strides are multiples of 8 halfs: checked above)
         if (!g_attn_force_old && !a->causal && a->Tq >= g_attn_x2_min_tq && !(a->Tq & 255) &&
             !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15)) return launch_attn64x2(a, st);
@@ -811,6 +1094,7 @@ MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
+MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode; }
 MLSD_API void mlsd_attention_tk96(int on, int qb) { g_attn_tk96 = on; g_attn_tk96_qb = qb; }
 
 }  // extern "C"

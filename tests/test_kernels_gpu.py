@@ -434,7 +434,9 @@ def test_conv2d_split_k(K):
     # Tk <= 96 without a mask: the one-pass kernel (every d_head it is built for; key counts on both sides of the 32 / 16 / 8-key
     # skip conditions; ragged query counts; the SDXL cross-attention launch itself)
     (1, 2, 40, 200, 77, 0), (1, 2, 160, 64, 77, 0), (2, 3, 64, 300, 96, 0), (1, 2, 64, 128, 65, 0), (1, 2, 64, 128, 80, 0),
-    (1, 2, 64, 130, 33, 0), (1, 2, 80, 100, 1, 0), (1, 3, 64, 96, 64, 0), (1, 2, 40, 64, 17, 0), (8, 20, 64, 1024, 77, 0)])
+    (1, 2, 64, 130, 33, 0), (1, 2, 80, 100, 1, 0), (1, 3, 64, 96, 64, 0), (1, 2, 40, 64, 17, 0), (8, 20, 64, 1024, 77, 0),
+    # d_head 64, Tq % 512 == 0 and >= 2048: the ping-pong kernel with 64 rows per wave (whole and ragged key tiles)
+    (1, 2, 64, 2048, 2048, 0), (1, 3, 64, 2048, 300, 0), (2, 2, 64, 2560, 1000, 0)])
 def test_attention(K, nb, heads, dh, tq, tk, causal):
     kernels, _lib = K
     rng = np.random.default_rng(dh + tq)
@@ -517,12 +519,52 @@ def test_attention_one_pass_kernel_vs_general_kernel(K, dh, tq, tk, qb):
     assert np.array_equal(outs["auto"], outs["qb"]) and np.array_equal(outs["qb"], outs["w4"])
 
 
+@pytest.mark.parametrize("tq,tk", [(512, 512), (512, 333), (1024, 97), (512, 130)])
+def test_attention_pingpong_variants(K, tq, tk):
+    """Every build of the d_head 64 ping-pong kernel (32 rows per wave at two blocks / one block per CU, 64 rows per wave) against
+    the oracle and against the tile-loop kernels it replaces; each is bit-repeatable (no atomics, barrier-ordered LDS-DMA)."""
+    kernels, _lib = K
+    L = _lib.lib()
+    rng = np.random.default_rng(tq + tk)
+    nb, heads, dh = 2, 3, 64
+    D = heads * dh
+    q = f16r(rng.standard_normal((nb, tq, D))); k = f16r(rng.standard_normal((nb, tk, D))); v = f16r(rng.standard_normal((nb, tk, D)))
+    k[0, tk - 3, :dh] = f16r(q[0, 5, :dh] * 4.0)        # a late key that dominates one query row: the rescale branch of the last tile
+    ref = np.stack([O.from_ot(O.L().orc_attention(O.to_ot(q[i][None, None]), O.to_ot(k[i][None, None]), O.to_ot(v[i][None, None]), heads, 0)).reshape(tq, D)
+                    for i in range(nb)])
+    dq, dk, dv = (dev(_lib, a.astype(np.float16)) for a in (q, k, v))
+    do = _lib.DeviceBuffer(nb * tq * D * 2)
+    a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
+                         bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
+    outs = {}
+    try:
+        L.mlsd_attention_tk96(0, 0)
+        for mode in (0, 2, 3, 4):
+            L.mlsd_attention_pp(mode)
+            for rep in range(2):
+                _lib.check(L.mlsd_memset(_lib.vp(do.ptr), 0x7C, ctypes.c_size_t(do.nbytes), None))
+                kernels.attention(a)
+                o = do.download((nb, tq, D), np.float16)
+                if rep:
+                    assert np.array_equal(o, outs[mode]), mode
+                outs[mode] = o
+    finally:
+        L.mlsd_attention_pp(1); L.mlsd_attention_tk96(1, 0)
+    for mode, o in outs.items():
+        g = o.astype(np.float32)
+        assert np.isfinite(g).all() and not (o.view(np.uint16) == 0x7C7C).any(), mode
+        assert rel(g, ref) < 2e-3, (mode, rel(g, ref))
+        assert np.abs(g[0, 5, :dh] - ref[0, 5, :dh]).max() < 5e-3, mode
+    assert np.array_equal(outs[2], outs[4])                    # same arithmetic, different register budgets
+
+
 def test_attention_fused_qkv_strides(K):
     """q/k/v as column slices of one [T][3*D] projection output (how the UNet self-attention feeds it)."""
     kernels, _lib = K
     rng = np.random.default_rng(3)
     _attention_fused_qkv(K, 5, 64, 192)
-    _attention_fused_qkv(K, 5, 64, 512)      # the 64-rows-per-wave kernel on strided rows
+    _attention_fused_qkv(K, 5, 64, 512)      # the ping-pong kernel (32 rows per wave) on strided rows
+    _attention_fused_qkv(K, 2, 64, 2048)     # the ping-pong kernel (64 rows per wave) on strided rows
 
 
 def _attention_fused_qkv(K, heads, dh, T):

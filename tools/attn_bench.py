@@ -37,7 +37,8 @@ for (nb, heads, dh, tq, tk) in [(8, 20, 64, 1024, 77), (8, 10, 64, 4096, 77), (2
         print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name:18s}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s  {gb/t/1e3:6.2f} TB/s   max|diff vs general| {np.abs(o - ref).max():.2e}", flush=True)
     L.mlsd_attention_tk96(1, 0)
 
-for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)]:
+# ---- self attention of the SDXL UNet: tile-loop kernels against the ping-pong kernel builds
+for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024), (4, 10, 64, 4096, 4096), (4, 20, 64, 1024, 1024)]:
     D = heads * dh
     q = rng.standard_normal((nb, tq, D)).astype(np.float16); k = rng.standard_normal((nb, tk, D)).astype(np.float16)
     v = rng.standard_normal((nb, tk, D)).astype(np.float16)
@@ -46,26 +47,12 @@ for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)
     a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D,
                          bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
     L.mlsd_attention_x2_min_tq(256)                      # let the 64-rows/wave kernel take every shape here
-    outs = {}
-    for name, old, vsum in (("general kernel ", 1, 0), ("general + vsum ", 1, 1), ("64-rows/wave   ", 0, 0), ("64-rows + vsum ", 0, 1)):
-        L.mlsd_attention_force_old(old); L.mlsd_attention_vsum(vsum)
-        for _ in range(3): kernels.attention(a)
-        L.mlsd_event_record(ev[0], None)
-        for _ in range(reps): kernels.attention(a)
-        L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
-        ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
-        t = ms.value / reps
-        outs[name] = do.download((nb, tq, D), np.float16).astype(np.float32)
-        err = np.abs(outs[name] - outs["general kernel "]).max()
-        print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {t*1e3:8.1f} us  {4.0*nb*heads*tq*tk*dh/t/1e9:7.1f} TFLOP/s   max|diff vs general| {err:.2e}")
-        if vsum:           # the same kernel with the output in 8-byte pieces (before the 16-byte stores)
-            L.mlsd_attention_wide_stores(0)
-            for _ in range(3): kernels.attention(a)
-            L.mlsd_event_record(ev[0], None)
-            for _ in range(reps): kernels.attention(a)
-            L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
-            ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
-            o8 = do.download((nb, tq, D), np.float16).astype(np.float32)
-            print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}, 8-byte output stores: {ms.value/reps*1e3:8.1f} us   identical output: {np.array_equal(o8, outs[name])}")
-            L.mlsd_attention_wide_stores(1)
-L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048)
+    ref = None
+    for name, pp, old in (("general (32 rows/wave)", 0, 1), ("64 rows/wave, LDS-DMA ", 0, 0), ("ping-pong 32 rows, 2/CU", 2, 0),
+                          ("ping-pong 32 rows, 1/CU", 4, 0), ("ping-pong 64 rows      ", 3, 0), ("ping-pong by shape     ", 1, 0)):
+        L.mlsd_attention_pp(pp); L.mlsd_attention_force_old(old); L.mlsd_attention_vsum(1)
+        ts = sorted(timeit(lambda: kernels.attention(a)) for _ in range(3))
+        o = do.download((nb, tq, D), np.float16).astype(np.float32)
+        if ref is None: ref = o
+        print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {ts[0]*1e3:8.1f} us (median {ts[1]*1e3:8.1f})  {4.0*nb*heads*tq*tk*dh/ts[0]/1e9:7.1f} TFLOP/s   max|diff vs general| {np.abs(o - ref).max():.2e}", flush=True)
+L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_pp(1)
