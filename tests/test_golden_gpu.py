@@ -144,7 +144,11 @@ def test_hip_unet_bench_plan_sd15_batch2_hipgraph_vs_independent_golden(slot):
     cond = r.standard_normal((n, 77, c1.shape[2])).astype(np.float32)
     sig = r.uniform(0.1, 14.0, n).astype(np.float32)
     x[slot], cond[slot], sig[slot] = x1[0], c1[0], 3.0
-    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED, flags=8)      # MLB_F_HIPGRAPH: what bench.py --workload sd15 replays
+    import ctypes
+    from mlimgsynth_amd import _lib
+    st = _lib.vp()
+    _lib.check(_lib.lib().mlsd_stream_create(ctypes.byref(st)), "stream")     # (stream capture is not permitted on the NULL stream)
+    un = engine.Unet(model, lat, lat, n, stream=st.value, seed=G.WEIGHT_SEED, flags=8)      # MLB_F_HIPGRAPH: what bench.py --workload sd15 replays
     got = un.run(x, cond, None, sig)
     again = un.run(x, cond, None, sig)                                      # second call = graph replay
     assert np.array_equal(got, again)
