@@ -126,6 +126,8 @@ typedef struct mlsd_gemm_args {
 	 * colstats[block][0][n] and colstats[block][1][n] (floats, 2*N per block).  Only the launches for which
 	 * mlsd_gemm_colstats_rows() > 0 honour it (ping-pong tiles, fp32 output without activation); NULL = off. */
 	float* colstats;
+	int colstats_rows;      /* > 0: the consumer was wired for statistics blocks of this many rows: mlsd_gemm FAILS unless this
+	                         * launch writes exactly those (a tile / epilogue knob changed between planning and launching) */
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -165,7 +167,7 @@ int mlsd_attention(const mlsd_attn_args* a, void* stream);
 /* diagnostics / A-B timing: 1 = the d_head 64 problems also run on the general kernel instead of the 64-rows-per-wave one */
 void mlsd_attention_force_old(int on);
 void mlsd_attention_x2_min_tq(int tq);     /* smallest Tq (multiple of 256) the 64-rows-per-wave kernel takes (default 2048) */
-void mlsd_attention_pp(int mode);          /* d_head 64 ping-pong kernel: 0 off, 1 by shape (default), 2 always 32 rows per wave, 3 always 64, 4 = 32 rows with one block per CU */
+void mlsd_attention_pp(int mode);          /* d_head 64 ping-pong kernel: 0 off, 1 by shape (default), 2 always 32 rows per wave, 3 always 64, 4 = 32 rows with one block per CU; + 16 / 32: s_setprio 1 around the MFMA clusters / the vector phase (A-B timing) */
 void mlsd_attention_tk96(int on, int qb);  /* Tk <= 96 one-pass kernel on/off (A-B timing); qb = 128-row query blocks per workgroup, 0 = automatic */
 void mlsd_attention_wide_stores(int on);  /* diagnostics / A-B timing: 0 = the output in 8-byte pieces per lane */
 void mlsd_attention_vsum(int on);         /* diagnostics / A-B timing: 1 = row sums of the 64-rows-per-wave kernel on the VALU instead of ones.P MFMAs */

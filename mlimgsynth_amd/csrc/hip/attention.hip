@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, WPS) void attn_tk96_kernel(const AttnP p, cons
         for (int kt = 0; kt < 3; ++kt) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                             // register quad j: keys 32 kt + 8 j + {0..3} + 4 lh
-                if (32 * kt + 8 * j < Tk) {
+                if (32 * kt + 16 * (j >> 1) < Tk) {                  // (whole 16-key steps: what the P.V MFMAs below consume; masked scores give P = 0)
 #pragma unroll
                     for (int e = 4 * j; e < 4 * j + 4; e += 2) {
                         const f32x2 r = exp2_pair(sacc[kt][e], sacc[kt][e + 1], p.sc, msc);
@@ -727,7 +727,9 @@ __global__ __launch_bounds__(256, WPS) void attn_tk96_kernel(const AttnP p, cons
 //   block (fp32 product, one rounding), and the S' accumulators START at -m (the running, deferred maximum in the exp2 domain,
 //   known before the tile's QK^T because the vector phase of the previous tile has finished), so P = exp2(acc) directly;
 //   the 16 NB x 2 accumulator initialisations ride in the matrix phase, where the vector ALU idles.
-template <int NB, int WPS>      // NB: 32-row query blocks per wave; WPS: waves per SIMD the register allocation aims for (2 per resident block)
+// PRIO: s_setprio 1 around 0 = nothing, 1 = the MFMA clusters, 2 = the vector phase.  (MI355X_MICROARCH.md "Two waves per SIMD" item 2:
+// with the matrix wave at priority 1 its partner's vector instructions only get the left-over issue slots.)
+template <int NB, int WPS, int PRIO>      // NB: 32-row query blocks per wave; WPS: waves per SIMD the register allocation aims for (2 per resident block)
 __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
 {
     constexpr int DH = 64, RB = 128;                 // bytes per K/V row
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sacc[sb][0][e] = ini; sacc[sb][1][e] = ini; }
         }
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((2 * ks + lh) ^ kswz) << 4;
@@ -837,12 +839,12 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
                 sacc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[sb][ks], sacc[sb][1], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
     auto pv = [&](int t) __attribute__((always_inline)) {
         const unsigned char* Vs = Vs2[t & 1];
         const bool sub1 = t * 64 + 32 < p.Tk;        // the tile's second 32-key sub-tile holds at least one key (wave-uniform)
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if (kt == 1 && !sub1) continue;
@@ -866,10 +868,11 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
     auto sm = [&](int t) __attribute__((always_inline)) {
         const int kv0 = t * 64;
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) {
             f32x16& sa = sacc[sb][0];
@@ -917,6 +920,7 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
                 }
             }
         }
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1), V(t) issued a phase ago have landed
     };
     auto phase_end = [&]() __attribute__((always_inline)) {
@@ -1011,6 +1015,7 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
 }
 
 
+int g_attn_pp_prio = 0;
 template <int NB, int WPS>
 int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
 {
@@ -1023,7 +1028,9 @@ int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
     p.nq = a->Tq / (256 * NB); p.G = a->n_head * a->n_batch;
     p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
-    hipLaunchKernelGGL((attn64pp_kernel<NB, WPS>), grid, dim3(512), 0, st, p);
+    if (g_attn_pp_prio == 1) hipLaunchKernelGGL((attn64pp_kernel<NB, WPS, 1>), grid, dim3(512), 0, st, p);
+    else if (g_attn_pp_prio == 2) hipLaunchKernelGGL((attn64pp_kernel<NB, WPS, 2>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((attn64pp_kernel<NB, WPS, 0>), grid, dim3(512), 0, st, p);
     return mlsd_check_launch("attn64pp_kernel");
 }
 
@@ -1094,7 +1101,7 @@ MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
-MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode; }
+MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode & 15; g_attn_pp_prio = (mode >> 4) & 3; }
 MLSD_API void mlsd_attention_tk96(int on, int qb) { g_attn_tk96 = on; g_attn_tk96_qb = qb; }
 
 }  // extern "C"

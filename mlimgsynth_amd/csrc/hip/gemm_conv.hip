@@ -764,6 +764,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     }
     if (a->act == MLSD_ACT_GEGLU && (a->N & 63)) return mlsd_set_error(-1, "mlsd_gemm: GEGLU needs N %% 64 == 0");
     if (!a->C32 && !a->C16) return mlsd_set_error(-1, "mlsd_gemm: no output");
+    if (a->colstats && a->colstats_rows > 0 && mlsd_gemm_colstats_rows(a) != a->colstats_rows)
+        return mlsd_set_error(-1, "mlsd_gemm: a GroupNorm was planned on this launch's column statistics (blocks of %d rows) but the launch "
+                              "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
     case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);

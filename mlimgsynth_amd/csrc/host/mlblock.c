@@ -736,14 +736,45 @@ static int tune_gemm(MLCtx* C, MLOp* op)
  * that launch gets a statistics buffer and the GroupNorm's first pass over the fp32 map is replaced by gn_finalize over the
  * statistics.  The choice is a pure function of the plan (tile table + shapes); MLSD_GN_TWO_PASS=1 keeps the two-pass form
  * (A/B timing, and the reference for the parity test). */
-static MLOp* gn_producer(MLCtx* C, int before, const float* x, int64_t ld, int Ci, int64_t rows)
+/* every buffer an op writes (at most 3) */
+static int op_outputs(const MLOp* o, const void* out[3])
 {
-	for (int j=before-1; j>=0; --j) {
-		MLOp *o = &C->ops[j];
-		if (o->kind == OP_GEMM && o->u.gemm.C32 == x && o->u.gemm.ldc32 == ld && o->u.gemm.N == Ci && o->u.gemm.M == rows &&
-		    o->u.gemm.act != MLSD_ACT_GEGLU) return o;
+	int n = 0;
+	switch (o->kind) {
+	case OP_GEMM: if (o->u.gemm.C32) out[n++] = o->u.gemm.C32; if (o->u.gemm.C16) out[n++] = o->u.gemm.C16; break;
+	case OP_ATTN: out[n++] = o->u.attn.out; break;
+	case OP_GN: out[n++] = o->u.gn.y16; if (o->u.gn.raw16) out[n++] = o->u.gn.raw16; break;
+	case OP_LN: if (o->u.ln.y16) out[n++] = o->u.ln.y16; if (o->u.ln.y32) out[n++] = o->u.ln.y32; break;
+	case OP_NCHW2NHWC: out[n++] = o->u.n2h.dst; break;
+	case OP_NHWC2NCHW: out[n++] = o->u.h2n.dst; break;
+	case OP_TEMB: out[n++] = o->u.temb.out; break;
+	case OP_ACT: out[n++] = o->u.act.y; break;
+	case OP_CLIP_EMBED: out[n++] = o->u.cemb.out; break;
+	case OP_SOFTMAX: out[n++] = o->u.smax.out; break;
+	case OP_COPY_F32: out[n++] = o->u.copy.dst; break;
 	}
-	return NULL;
+	return n;
+}
+
+/* The producer of a GroupNorm source is the op that DEFINES the source tensor (MLTensor.prod, recorded with the GroupNorm:
+ * MLOp.gn_src), not "the last GEMM that happens to write this address": arena blocks are recycled, so an address match alone
+ * could pick a stale writer.  It qualifies only if it still writes exactly this matrix and NO op between it and the GroupNorm
+ * writes into the buffer (any kind of op: a recycled block rewritten by a LayerNorm / copy / gather would leave the column
+ * statistics describing data that is gone). */
+static MLOp* gn_producer(MLCtx* C, int gn_idx, int src, const float* x, int64_t ld, int Ci, int64_t rows)
+{
+	const int j = C->ops[gn_idx].gn_src[src];
+	if (j < 0 || j >= gn_idx) return NULL;
+	MLOp *o = &C->ops[j];
+	if (o->kind != OP_GEMM || o->u.gemm.C32 != x || o->u.gemm.ldc32 != ld || o->u.gemm.N != Ci || o->u.gemm.M != rows ||
+	    o->u.gemm.act == MLSD_ACT_GEGLU) return NULL;
+	const char *lo = (const char*)x, *hi = lo + (size_t)rows * ld * sizeof(float);
+	for (int k=j+1; k<gn_idx; ++k) {
+		const void *out[3];
+		const int n = op_outputs(&C->ops[k], out);
+		for (int q=0;q<n;++q) if ((const char*)out[q] >= lo && (const char*)out[q] < hi) return NULL;
+	}
+	return o;
 }
 
 static int gn_producer_rows(MLOp* o)
@@ -764,8 +795,8 @@ static void wire_gn_stats(MLCtx* C)
 		if (C->ops[i].kind != OP_GN) continue;
 		mlsd_gn_args *g = &C->ops[i].u.gn;
 		const int64_t rows = (int64_t)g->n_img * g->HW;
-		MLOp *p1 = gn_producer(C, i, g->x1, g->ld1, g->C1, rows);
-		MLOp *p2 = g->C2 ? gn_producer(C, i, g->x2, g->ld2, g->C2, rows) : NULL;
+		MLOp *p1 = gn_producer(C, i, 0, g->x1, g->ld1, g->C1, rows);
+		MLOp *p2 = g->C2 ? gn_producer(C, i, 1, g->x2, g->ld2, g->C2, rows) : NULL;
 		if (!p1 || (g->C2 && !p2)) continue;
 		const int r1 = gn_producer_rows(p1), r2 = p2 ? gn_producer_rows(p2) : 0;
 		if (r1 <= 0 || (g->HW % r1) || (p2 && (r2 <= 0 || (g->HW % r2)))) continue;
@@ -779,6 +810,9 @@ static void wire_gn_stats(MLCtx* C)
 		if (!ok) continue;
 		g->cs1 = p1->u.gemm.colstats; g->rb_rows1 = r1;
 		g->cs2 = p2 ? p2->u.gemm.colstats : NULL; g->rb_rows2 = r2;
+		/* the promise the launcher checks at every launch (mlsd_gemm fails if its tile / epilogue no longer writes these blocks) */
+		p1->u.gemm.colstats_rows = r1;
+		if (p2) p2->u.gemm.colstats_rows = r2;
 	}
 }
 

@@ -19,6 +19,7 @@ typedef struct MLOp {
 	MLOpKind kind;
 	double flops;
 	char label[56];
+	int gn_src[2];          /* OP_GN: index of the op that PRODUCES each fp32 source (MLTensor.prod), -1 = not a GEMM/conv output */
 	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
 	                         * re-runs it only after such an input was written (mlctx_input_set / mlctx_input_device_ptr) */
 	union {

@@ -147,6 +147,7 @@ MLTensor* mlb_groupnorm_ex(MLCtx* C, MLTensor* x, int n_grp, float eps, int silu
 	g->x2 = x2; g->ld2 = bb ? bb->ld32 : 0; g->C2 = bb ? bb->c : 0;
 	g->n_img = x->n; g->HW = HW; g->n_grp = n_grp; g->eps = eps; g->gamma = wd; g->beta = bd; g->silu = silu;
 	g->y16 = y->d16; g->raw16 = raw ? raw->d16 : NULL; g->ws = ws;
+	op->gn_src[0] = a->prod; op->gn_src[1] = bb ? bb->prod : -1;       /* the defining ops of the sources (statistics wiring) */
 	return y;
 }
 
