@@ -50,6 +50,7 @@ struct AttnP {
     long ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
     int n_head, Tq, Tk, causal;
     int nq, G;  // query blocks per (batch, head) group; number of groups
+    unsigned long long* tbuf;   // diagnostics (attn64pp_kernel): cycle stamps of block 0, [wave][tile][5], or null
     int wide_o; // output rows are 16-byte aligned: lane pairs exchange halves and store 16 bytes each (T21)
     float sc;  // 1/sqrt(d_head) * log2(e)
 };
@@ -770,19 +771,27 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
     // buffer_load ... lds through one descriptor per operand (base = this (batch, head)'s first row, range = its Tk rows): the
     // per-lane part of the address is ONE 32-bit offset (row inside the wave's 8-row piece + swizzled chunk), the tile / piece
     // advance is a scalar offset, and rows past Tk fail the range check and arrive as ZEROS (their scores are masked, P = 0).
-    const int srow = lane >> 3, sslot = lane & 7;
+    // The lane offsets are RECOMPUTED at every use from an opaque copy of the lane id: kept in registers across the tile loop
+    // they were spilled, and every reload carried a compiler-inserted s_waitcnt vmcnt(0) in front of the DMA it fed -- each piece
+    // then waited for the previous one to land (the pitfall of cdna_hip_programming.md, "lane-constant address hoisted ...").
     const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, (int)(((long)(p.Tk - 1) * p.ldk + DH) * 2), 0x00020000);
     const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((long)(p.Tk - 1) * p.ldv + DH) * 2), 0x00020000);
-    const int kvo0 = srow * (int)p.ldk * 2 + ((sslot ^ (srow >> 1)) << 4);              // piece 0 of a wave: rows 16 wq + srow
-    const int kvo1 = srow * (int)p.ldk * 2 + ((sslot ^ (4 | (srow >> 1))) << 4);        // piece 1: rows 16 wq + 8 + srow
-    const int vvo = srow * (int)p.ldv * 2 + ((sslot ^ (((srow >> 1) & 1) << 2)) << 4);
     auto stage_k = [&](int t) __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));      // lane id, never live across the loop
+        const int srow = l >> 3, sslot = l & 7;
+        const int kvo0 = srow * (int)p.ldk * 2 + ((sslot ^ (srow >> 1)) << 4);              // piece 0 of a wave: rows 16 wq + srow
+        const int kvo1 = kvo0 ^ 64;                                                         // piece 1 (rows + 8): swizzle term + 4
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(Ks2[t & 1] + (wq * 16 + i * 8) * RB), 16,
                                                      i ? kvo1 : kvo0, (t * 64 + wq * 16 + i * 8) * (int)p.ldk * 2, 0, 0);
     };
     auto stage_v = [&](int t) __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const int srow = l >> 3, sslot = l & 7;
+        const int vvo = srow * (int)p.ldv * 2 + ((sslot ^ (((srow >> 1) & 1) << 2)) << 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(Vs2[t & 1] + (wq * 16 + i * 8) * RB), 16,
@@ -815,30 +824,49 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
 
     // Phase bodies.  qk(t): S'(t) = -m + K(t) . Q'^T (group A also issues the staging of K(t+1) and V(t): both targets were last
     // read, by group B, in the phase that just ended).  pv(t): O^T += V^T(t) . P(t).  sm(t): the softmax of tile t.
-    auto qk = [&](int t) __attribute__((always_inline)) {
+    // Matrix phase, NB = 1 (register room for it): ALL LDS reads of the phase -- the 16 transposed V reads of P.V and the 8 row reads
+    // of the next QK^T, 64 registers -- are issued up front, then the 16 MFMAs run against counted lgkmcnt waits.  With one wave per
+    // SIMD on the matrix pipe nobody hides a read -> wait -> MFMA chain: issued group by group the phase took twice its MFMA time
+    // (timing-only builds, tools/attn_bench.py: matrix phases alone 321 us of a 393 us launch at 4096 x 4096).
+    auto stage_next = [&](int t) __attribute__((always_inline)) {     // group A: K(t+1) and V(t) into the slots group B finished with a phase ago
         if (grp == 0) {
             if (t + 1 < nt) stage_k(t + 1);
             stage_v(t);
         }
-        const unsigned char* Ks = Ks2[t & 1];
+    };
+    auto init_s = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) {
             const float ini = -msc[sb];
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sacc[sb][0][e] = ini; sacc[sb][1][e] = ini; }
         }
-        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    };
+    auto read_k = [&](int t, f16x8 (&kf)[8]) __attribute__((always_inline)) {
+        const unsigned char* Ks = Ks2[t & 1];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((2 * ks + lh) ^ kswz) << 4;
-            const f16x8 k0 = *reinterpret_cast<const f16x8*>(Ks + lr * RB + off);
-            const f16x8 k1 = *reinterpret_cast<const f16x8*>(Ks + (32 + lr) * RB + off);
+            kf[2 * ks] = *reinterpret_cast<const f16x8*>(Ks + lr * RB + off);
+            kf[2 * ks + 1] = *reinterpret_cast<const f16x8*>(Ks + (32 + lr) * RB + off);
+        }
+    };
+    auto mfma_qk = [&](const f16x8 (&kf)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) {
-                sacc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[sb][ks], sacc[sb][0], 0, 0, 0);
-                sacc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[sb][ks], sacc[sb][1], 0, 0, 0);
+                sacc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2 * ks], qf[sb][ks], sacc[sb][0], 0, 0, 0);
+                sacc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2 * ks + 1], qf[sb][ks], sacc[sb][1], 0, 0, 0);
             }
-        }
+    };
+    auto qk = [&](int t) __attribute__((always_inline)) {
+        stage_next(t);
+        f16x8 kf[8];
+        read_k(t, kf);
+        init_s();
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        mfma_qk(kf);
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
     auto pv = [&](int t) __attribute__((always_inline)) {
@@ -868,6 +896,39 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
                 }
             }
         }
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    };
+    // pv(t) + qk(t+1) as ONE phase with every LDS read in front (NB = 1; whole tiles only: a ragged last tile takes pv / qk)
+    auto pv_qk = [&](int t) __attribute__((always_inline)) {
+        stage_next(t + 1);
+        const unsigned char* Vs = Vs2[t & 1];
+        union VF { h16x4 h[2]; f16x8 f; };
+        VF vf[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                 // g = (kt, sx, d)
+            const int kb = 16 * (g >> 1), d = g & 1;
+            const unsigned char* a0 = Vs + (kb + tr_row) * RB + (((4 * d + tr_c) ^ vswz) << 4) + tr_b;
+            vf[g].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)a0);
+            vf[g].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)(a0 + 8 * RB));
+        }
+        f16x8 kf[8];
+        read_k(t + 1, kf);
+        f16x8 pf[NB][4];
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb)
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[sb][h][j] = (_Float16)sacc[sb][h >> 1][8 * (h & 1) + j];
+        __builtin_amdgcn_sched_barrier(0);            // reads and conversions above, MFMAs below (the compiler counts the lgkmcnt waits)
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb)
+                oacc[sb][g & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g].f, pf[sb][g >> 1], oacc[sb][g & 1], 0, 0, 0);
+        init_s();
+        mfma_qk(kf);
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
     auto sm = [&](int t) __attribute__((always_inline)) {
@@ -931,16 +992,28 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
     // Global phases g = 0 .. 2 nt + 1, one barrier after each of g = 0 .. 2 nt (2 nt + 1 barriers for every wave):
     //   group A:  g = 0: qk(0)   g = 2t+1: sm(t)   g = 2t+2: pv(t) [+ qk(t+1)]          (ends with pv(nt-1) at g = 2 nt, then its epilogue)
     //   group B:  the same sequence one phase later (idle at g = 0, pv(nt-1) at g = 2 nt + 1 with no barrier behind it)
+    const int dbg = p.causal;                         // timing-only builds of the loop (tools/attn_bench.py): 1 = no vector phase, 2 = no matrix phase
+    auto stamp = [&](int t, int k) __attribute__((always_inline)) {      // diagnostics: s_memtime at the phase boundaries of block 0
+        if (p.tbuf && blockIdx.x == 0 && t < 16 && lane == 0) p.tbuf[(wave * 16 + t) * 5 + k] = __builtin_readcyclecounter();
+    };
     if (grp == 1) phase_end();
     qk(0);
     phase_end();
     for (int t = 0; t < nt; ++t) {
-        sm(t);
+        stamp(t, 0);
+        if (!(dbg & 1)) sm(t);
+        stamp(t, 1);
         phase_end();
-        pv(t);
-        __builtin_amdgcn_sched_barrier(0);            // P(t) is dead here: the accumulators restart at -m for the next tile
-        if (t + 1 < nt) qk(t + 1);
+        stamp(t, 2);
+        if (NB == 1 && WPS == 2 && t + 1 < nt && (t + 1) * 64 <= p.Tk && !(dbg & 2)) pv_qk(t);
+        else {
+            if (!(dbg & 2)) pv(t);
+            __builtin_amdgcn_sched_barrier(0);        // P(t) is dead here: the accumulators restart at -m for the next tile
+            if (t + 1 < nt && !(dbg & 2)) qk(t + 1);
+        }
+        stamp(t, 3);
         if (t + 1 < nt || grp == 0) phase_end();
+        stamp(t, 4);
     }
 
     // ---- epilogue: O = O^T / l, heads merged.  o[d][e]: d-index = 32*d + (e&3) + 8*(e>>2) + 4*lh, query = lane&31
@@ -976,14 +1049,14 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
-int g_attn_pp = 1;          // ping-pong kernel for d_head 64: 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
+int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity with the tile-loop kernels; off by default): 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
 int g_attn_tk96 = 1;        // Tk <= 96 without a causal mask: the one-pass kernel (0 = the general kernels; A/B timing)
 int g_attn_tk96_qb = 0;     // query blocks of 128 rows per workgroup (0 = by the launch size)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
 {
-    AttnP p;
+    AttnP p; p.tbuf = nullptr;
     p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
@@ -1000,7 +1073,7 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
 template <int DH>
 int launch_attn(const mlsd_attn_args* a, hipStream_t st)
 {
-    AttnP p;
+    AttnP p; p.tbuf = nullptr;
     p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
@@ -1015,15 +1088,16 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
 }
 
 
-int g_attn_pp_prio = 0;
+int g_attn_pp_prio = 0, g_attn_pp_dbg = 0;
+unsigned long long* g_attn_tbuf = nullptr;
 template <int NB, int WPS>
 int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
 {
-    AttnP p;
+    AttnP p; p.tbuf = nullptr;
     p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
-    p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = 0;
+    p.n_head = a->n_head; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = g_attn_pp_dbg; p.tbuf = g_attn_tbuf;
     p.sc = (float)(1.4426950408889634 / sqrt(64.0));
     p.nq = a->Tq / (256 * NB); p.G = a->n_head * a->n_batch;
     p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
@@ -1037,7 +1111,7 @@ int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
 template <int DH>
 int launch_attn_tk96(const mlsd_attn_args* a, hipStream_t st)
 {
-    AttnP p;
+    AttnP p; p.tbuf = nullptr;
     p.q = (const _Float16*)a->q; p.k = (const _Float16*)a->k; p.v = (const _Float16*)a->v; p.o = (_Float16*)a->out;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.bsq = a->bsq; p.bsk = a->bsk; p.bsv = a->bsv; p.bso = a->bso;
@@ -1101,7 +1175,8 @@ MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
-MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode & 15; g_attn_pp_prio = (mode >> 4) & 3; }
+MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode & 15; g_attn_pp_prio = (mode >> 4) & 3; g_attn_pp_dbg = (mode >> 8) & 3; }
+MLSD_API void mlsd_attention_set_trace(void* buf) { g_attn_tbuf = (unsigned long long*)buf; }   /* 8 waves x 16 tiles x 5 stamps of block 0 */
 MLSD_API void mlsd_attention_tk96(int on, int qb) { g_attn_tk96 = on; g_attn_tk96_qb = qb; }
 
 }  // extern "C"

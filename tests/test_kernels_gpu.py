@@ -549,7 +549,7 @@ def test_attention_pingpong_variants(K, tq, tk):
                     assert np.array_equal(o, outs[mode]), mode
                 outs[mode] = o
     finally:
-        L.mlsd_attention_pp(1); L.mlsd_attention_tk96(1, 0)
+        L.mlsd_attention_pp(0); L.mlsd_attention_tk96(1, 0)
     for mode, o in outs.items():
         g = o.astype(np.float32)
         assert np.isfinite(g).all() and not (o.view(np.uint16) == 0x7C7C).any(), mode

@@ -50,11 +50,12 @@ for (nb, heads, dh, tq, tk) in [(8, 10, 64, 4096, 4096), (8, 20, 64, 1024, 1024)
     ref = None
     for name, pp, old in (("general (32 rows/wave)", 0, 1), ("64 rows/wave, LDS-DMA ", 0, 0), ("ping-pong 32 rows, 2/CU", 2, 0),
                           ("ping-pong 32 rows, 1/CU", 4, 0), ("ping-pong 64 rows      ", 3, 0),
-                          ("pp 32 rows 2/CU, prio M", 2 + 16, 0), ("pp 32 rows 1/CU, prio M", 4 + 16, 0), ("pp 64 rows, prio M    ", 3 + 16, 0),
-                          ("pp 32 rows 2/CU, prio V", 2 + 32, 0), ("pp 32 rows 1/CU, prio V", 4 + 32, 0), ("pp 64 rows, prio V    ", 3 + 32, 0)):
+                          ("pp 64 rows, prio M    ", 3 + 16, 0), ("pp 64 rows, prio V    ", 3 + 32, 0),
+                          ("pp 64 rows NO VECTOR PHASE (timing only)", 3 + 256, 0), ("pp 64 rows NO MATRIX PHASE (timing only)", 3 + 512, 0),
+                          ("pp 32 rows 1/CU NO VECTOR PHASE (timing only)", 4 + 256, 0), ("pp 32 rows 1/CU NO MATRIX PHASE (timing only)", 4 + 512, 0)):
         L.mlsd_attention_pp(pp); L.mlsd_attention_force_old(old); L.mlsd_attention_vsum(1)
         ts = sorted(timeit(lambda: kernels.attention(a)) for _ in range(3))
         o = do.download((nb, tq, D), np.float16).astype(np.float32)
         if ref is None: ref = o
         print(f"attn b{nb} h{heads} d{dh} {tq}x{tk} {name}: {ts[0]*1e3:8.1f} us (median {ts[1]*1e3:8.1f})  {4.0*nb*heads*tq*tk*dh/ts[0]/1e9:7.1f} TFLOP/s   max|diff vs general| {np.abs(o - ref).max():.2e}", flush=True)
-L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_pp(1)
+L.mlsd_attention_force_old(0); L.mlsd_attention_vsum(1); L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_pp(0)

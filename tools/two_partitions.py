@@ -14,6 +14,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 modes = sys.argv[5:] or ["half", "parity", "none"]
 L.mlsd_gemm_set_cus.argtypes = [ctypes.c_int]
+FLAGS = int(os.environ.get('PLAN_FLAGS', '0'))      # 8 = replay each plan as a hipGraph
 
 
 def stream(mask=None):
@@ -56,7 +57,7 @@ def timed(fn, sync):
 
 
 s0 = stream()
-full = engine.Unet(model, lat, lat, N, stream=s0)
+full = engine.Unet(model, lat, lat, N, stream=s0, flags=FLAGS)
 t_full = timed(lambda: full.ctx.compute(), lambda: full.ctx.sync())
 print(f"{model} latent {lat}: whole chip, one plan of batch {N}: {t_full:.2f} ms per evaluation", flush=True)
 for mode in modes:
@@ -65,7 +66,7 @@ for mode in modes:
     if ma is not None:
         print(f"[{mode}] stream A: XCCs {census(sa)}, stream B: XCCs {census(sb)}", flush=True)
     L.mlsd_gemm_set_cus(128 if ma is not None else 256)
-    ha, hb = engine.Unet(model, lat, lat, N // 2, stream=sa), engine.Unet(model, lat, lat, N // 2, stream=sb)
+    ha, hb = engine.Unet(model, lat, lat, N // 2, stream=sa, flags=FLAGS), engine.Unet(model, lat, lat, N // 2, stream=sb, flags=FLAGS)
     t_half = timed(lambda: ha.ctx.compute(), lambda: ha.ctx.sync())
     # one host thread per stream (ctypes releases the GIL inside the library): the two streams drift apart by themselves
     for delay_ms in (0.0, 15.0, 30.0):
