@@ -128,6 +128,9 @@ typedef struct mlsd_gemm_args {
 	float* colstats;
 	int colstats_rows;      /* > 0: the consumer was wired for statistics blocks of this many rows: mlsd_gemm FAILS unless this
 	                         * launch writes exactly those (a tile / epilogue knob changed between planning and launching) */
+	/* stream-K (tile variant 19): one zeroed 32-bit flag per persistent block (256 words; cleared again by their consumers) beside
+	 * the workspace `ws` (>= 256 fp32 slabs of 256 x 256: mlsd_gemm_streamk_ws_bytes()).  NULL: the launch runs as variant 17. */
+	unsigned* sk_flags;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -144,6 +147,7 @@ int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
 /* timing-only builds of the main loop (needs -DMLSD_GEMM_EXPERIMENTS; otherwise ignored) */
 void mlsd_gemm_set_debug(int d);
+size_t mlsd_gemm_streamk_ws_bytes(void);   /* workspace of a stream-K launch (slabs); the flags are 256 x 4 bytes, zeroed once */
 void mlsd_gemm_set_cus(int n);      /* CUs a persistent GEMM launch occupies (default 256; 128 for half-chip partitions) */
 void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */
 size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit);

@@ -72,6 +72,10 @@ struct GemmP {
     int gw;    // tile-order panel width (0: row-major)
     unsigned long long* tbuf;   // diagnostics: per-block cycle stamps of the ping-pong kernels (tools/gemm_trace.py), or null
     float* colstats;            // ping-pong kernels built with a *_STATS epilogue: [row block][2][N] column sums / sums of squares
+    // stream-K (gemm_pp.hpp, SK): K-tile units per block, slabs [block][BM*BN] fp32, one flag per block
+    int sk_L;
+    float* sk_ws;
+    unsigned* sk_flag;
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -587,7 +591,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
                 (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
     }
-    p.dbg = g_gemm_dbg; p.tbuf = nullptr; p.colstats = nullptr;
+    p.dbg = g_gemm_dbg; p.tbuf = nullptr; p.colstats = nullptr; p.sk_L = 0; p.sk_ws = nullptr; p.sk_flag = nullptr;
     p.gw = g_gemm_panel;
     int kt_per;
     const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
@@ -653,7 +657,17 @@ int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 }
 
 // launcher of the ping-pong kernels (gemm_pp.hpp): same argument handling as launch<>
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH>
+// stream-K needs: the ping-pong conditions, a workspace of one fp32 slab per block + a zeroed flag word per block (cleared again by
+// their consumers), at least 4 K-tile units per block and a tile count the blocks do not divide (otherwise nothing is gained)
+bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
+{
+    if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15)) return false;
+    const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
+    const long L = (tiles * nkt + g_gemm_ncu - 1) / g_gemm_ncu;
+    return nkt >= 3 && L >= 4 && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);
+}
+
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool SK = false>
 int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 {
     constexpr int BK = 64;
@@ -671,7 +685,12 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.kt_per = (a->K + BK - 1) / BK; p.ws_stride = 0;      // no split-K on these tiles
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
-    const dim3 grid(ntiles < g_gemm_ncu ? ntiles : g_gemm_ncu), block(512);   // persistent: one block per CU walks tiles b, b+G, ...
+    p.sk_L = 0; p.sk_ws = nullptr; p.sk_flag = nullptr;
+    if constexpr (SK) {
+        p.sk_L = (int)(((long)ntiles * (a->K / BK) + g_gemm_ncu - 1) / g_gemm_ncu);
+        p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags;
+    }
+    const dim3 grid(SK ? g_gemm_ncu : (ntiles < g_gemm_ncu ? ntiles : g_gemm_ncu)), block(512);   // persistent: one block per CU walks tiles b, b+G, ... (stream-K: K-tile units)
     auto go = [&](auto kfn) -> int {
         MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
@@ -680,6 +699,23 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     // the epilogue the kernel is built with (gemm_pp.hpp): the bulk launches of the UNet / VAE have no activation in the GEMM
     const int epi = pp_epilogue_kind(a, BN);
     p.colstats = (epi == PP_EPI_F32_STATS || epi == PP_EPI_F32_RES_STATS) ? a->colstats : nullptr;
+    if constexpr (SK) {       // the stream-K builds: the fp32 epilogues of the long-K convs / feed-forward outputs, fp16 for the fused projections
+        if (a->conv) {
+            switch (epi) {
+            case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32, true>);
+            case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES, true>);
+            case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_STATS, true>);
+            case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES_STATS, true>);
+            default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_GENERIC, true>);
+            }
+        }
+        switch (epi) {
+        case PP_EPI_F16: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F16, true>);
+        case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32, true>);
+        case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES, true>);
+        default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, true>);
+        }
+    }
     if (a->conv) {
         switch (epi) {
         case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32>);
@@ -726,6 +762,7 @@ const Variant kVariants[] = {
     {"128x320x64s2", 128, 320, 256},    // 16: 8 waves (4x2, wave tile 32x160): N = 1280 / 640 outputs in exactly 4 / 2 tile columns
     {"256x256x64pp", 256, 256, 256},    // 17: 8 waves in two ping-pong groups, 16x16x32 MFMA, 4 phases per K tile (gemm_pp.hpp)
     {"128x320x64pp", 128, 320, 256},    // 18: the same structure on the 128x320 tile (wave 64x80)
+    {"256x256x64ppsk", 256, 256, 256},  // 19: variant 17 as STREAM-K: the launch's K-tile units dealt evenly over the 256 blocks, partial tiles combined in-launch
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -774,6 +811,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
     case 17: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 19:
+        if (sk_eligible(a, 256, 256)) return launch_pp<256, 256, 2, 2, false, true>(a, st);
+        return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 18:
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
@@ -813,12 +853,14 @@ MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 
 MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
 
+MLSD_API size_t mlsd_gemm_streamk_ws_bytes(void) { return (size_t)256 * 256 * 256 * sizeof(float); }
+
 MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
 {
     if (!a || !a->colstats) return 0;
     const int v = pick_variant(a);
     int bm, bn;
-    if (v == 17 && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
+    if ((v == 17 || v == 19) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
     else if (v == 18 && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
@@ -829,6 +871,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
     int v = pick_variant(a);
+    if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
     if (v == 17 && !pp_eligible(a, 256, 256)) v = 9;
     if (v == 18 && !pp_eligible(a, 128, 320)) v = 16;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;

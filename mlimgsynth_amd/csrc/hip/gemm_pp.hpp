@@ -52,6 +52,38 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
     return PPTile{bm * BM, bn * BN};
 }
 
+// tile `bid` of the panel order, WITHOUT the XCD remap (stream-K: the block numbering is XCD-contiguous already)
+template <int BM, int BN>
+__device__ __forceinline__ PPTile pp_tile_plain(const GemmP& p, int bid)
+{
+    int bm, bn;
+    if (p.gw > 0 && p.nbn > p.gw) {
+        const int per_panel = p.gw * p.nbm;
+        const int panel = bid / per_panel;
+        const int first = panel * p.gw;
+        const int w = min(p.gw, p.nbn - first);
+        const int rr = bid - panel * per_panel;
+        bm = rr / w; bn = first + (rr - bm * w);
+    } else {
+        bm = bid / p.nbn; bn = bid - bm * p.nbn;
+    }
+    return PPTile{bm * BM, bn * BN};
+}
+
+// STREAM-K (template parameter SK).  With T output tiles on G = 256 persistent blocks a launch takes
+// ceil(T / G) whole tile times: 8192 x 1280 on 256 x 256 tiles is 160 tiles = 62 % of the chip, which is why those outputs ran
+// on the less efficient 128 x 320 tile (256 tiles).  Here the T * (K / 64) K-tile UNITS of the launch are dealt out evenly instead:
+// block w (numbered XCD-contiguously: the blocks that share a tile share an L2) takes units [w L, (w + 1) L), L = ceil(units / G),
+// in tile-major order -- its stream starts in the middle of a tile, may contain whole tiles, and ends in the middle of one:
+//   * a segment that STARTS inside a tile (only a block's first one) is a contribution: at its end the block writes its raw
+//     accumulators to its slab of the workspace (write-through stores), drains them, and raises its flag;
+//   * a segment that starts AT a tile's first K tile makes the block the tile's OWNER: if its stream ends before the tile's last K
+//     tile it waits, in block order, for the flags of the blocks holding the rest (they never wait for anybody: no cycle, no
+//     residency assumption), adds their slabs in that fixed order (bit-repeatable) and runs the normal epilogue; each flag has
+//     exactly one consumer, which clears it for the next launch.
+// Everything else -- the staging sequences, the phases, the counted waits -- is the persistent kernel's: a stream of K tiles that
+// crosses tile seams was already its model.  (Hand-off: cdna_hip_programming.md section 5 "In-launch split-K reduction", the
+// write-through form.)
 // Geometry (template): the block tile is BM x BN, waves 2 x 4, a wave owns WM x WN = (BM/2) x (BN/4):
 //   256 x 256: wave 128 x 64, quadrants 64 x 32 (CB0 = CB1 = 2 column blocks of 16)   -- the description above
 //   128 x 320: wave  64 x 80, quadrants 32 x 48 | 32 x 32 (CB0 = 3, CB1 = 2): N = 1280 / 640 / 320 outputs in whole tile
@@ -69,7 +101,7 @@ __device__ __forceinline__ PPTile pp_tile_coords(const GemmP& p, int v)
 // residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
 enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6 };
 // *_STATS: additionally the column sums / sums of squares of the wave's rows (GemmP::colstats) for a consuming GroupNorm
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI>
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -89,9 +121,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     const int l15 = lane & 15, lg = lane >> 4;
     const int nblk = p.nbm * p.nbn;
     const int G = gridDim.x;
-    const int ntile = (nblk - (int)blockIdx.x + G - 1) / G;      // output tiles of this block (>= 1)
     const int nkt = p.K / BK;
-    const int S = ntile * nkt;                                   // K tiles in this block's stream
+    int ntile = (nblk - (int)blockIdx.x + G - 1) / G;            // output tiles of this block (>= 1)
+    int S = ntile * nkt;                                         // K tiles in this block's stream
+    int kt0 = 0, tfirst = 0, skw = 0;                            // stream-K: first K tile inside the first tile, first tile, block number
+    if constexpr (SK) {
+        const int q = G >> 3, r = G & 7, x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        skw = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        const long W = (long)nblk * nkt, u0 = (long)skw * p.sk_L;
+        if (u0 >= W) return;                                     // (the whole block leaves before any barrier)
+        const long u1 = min(u0 + p.sk_L, W);
+        S = (int)(u1 - u0); tfirst = (int)(u0 / nkt); kt0 = (int)(u0 - (long)tfirst * nkt);
+        ntile = (int)((u1 - 1) / nkt) - tfirst + 1;
+    }
+    auto tile_at = [&](int ti) __attribute__((always_inline)) {   // coordinates of this block's ti-th output tile
+        if constexpr (SK) return pp_tile_plain<BM, BN>(p, min(tfirst + ti, nblk - 1));
+        else return pp_tile_coords<BM, BN>(p, (int)blockIdx.x + ti * G);
+    };
+    int kenter = kt0;                                            // K tile the staging sequences start at when they enter a tile (kt0 once, then 0)
 
     // ---- staging.  A wave-instruction fills 8 consecutive tile rows (lane l -> row l>>3, slot l&7); instruction
     // g = it*8 + wave of a unit covers the g-th group of 8 rows of the unit's row list.  The thread fetches the LOGICAL
@@ -119,12 +166,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     SeqA sa[2];    // [0] = U1, [1] = U4
     SeqB2 sb2;     // U2
     SeqB3 sb3;     // U3
-    PPTile tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x);   // coordinates the sequences use at their next tile entry
+    PPTile tnext = tile_at(0);                                   // coordinates the sequences use at their next tile entry
     PPTile tcur = tnext;                                         // tile of the MFMAs / next epilogue
     const _Float16* zsrc = reinterpret_cast<const _Float16*>(g_zero_page);
 
     auto enter_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
-        s.kt = 0; s.kh = 0; s.kw = 0; s.cin = 0;
+        s.kt = kenter; s.kh = 0; s.kw = 0; s.cin = 0;
+        if constexpr (CONV) {
+            if (kenter) { const int k0 = kenter * BK, tap = k0 / p.Cin; s.cin = k0 - tap * p.Cin; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
+        }
 #pragma unroll
         for (int it = 0; it < NU1; ++it) {
             const int r = a_row0(it, second) + (lane >> 3);
@@ -141,24 +191,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 s.mask[it] = mk;
                 s.ptr[it] = p.A + ((long)img * p.H * p.W + (long)ih0 * p.W + iw0) * p.lda + chunk_of(r);
             } else {
-                s.ptr[it] = p.A + (long)m * p.lda + chunk_of(r);
+                s.ptr[it] = p.A + (long)m * p.lda + chunk_of(r) + kenter * BK;
             }
         }
     };
     auto enter_B2 = [&](SeqB2& s) __attribute__((always_inline)) {
-        s.kt = 0;
+        s.kt = kenter;
 #pragma unroll
         for (int it = 0; it < NU2; ++it) {
             const int r = b_row0(it, 0) + (lane >> 3);
-            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r);
+            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r) + kenter * BK;
         }
     };
     auto enter_B3 = [&](SeqB3& s) __attribute__((always_inline)) {
-        s.kt = 0;
+        s.kt = kenter;
 #pragma unroll
         for (int it = 0; it < NU3; ++it) {
             const int r = b_row0(it, 1) + (lane >> 3);
-            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r);
+            s.ptr[it] = p.B + (long)min(tnext.n0 + r, p.N - 1) * p.ldb + chunk_of(r) + kenter * BK;
         }
     };
     auto issue_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
@@ -485,8 +535,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     // ---- prologue: U1..U4 of stream position 0 and U1 of position 1 in flight; U1(0), U2(0) retired and visible
     sa[0].par = sa[1].par = sb2.par = sb3.par = 0;
     enter_A(sa[0], 0); enter_A(sa[1], 1); enter_B2(sb2); enter_B3(sb3);
+    kenter = 0;                                    // every later tile is entered at its first K tile
     tcur = tnext;
-    tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x + (ntile > 1 ? G : 0));   // past the end: any valid tile (staged, never read)
+    tnext = tile_at(ntile > 1 ? 1 : 0);            // past the end: any valid tile (staged, never read)
     issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1); issue_A(sa[0], 0);
     wait_vmcnt<W4>();
     __builtin_amdgcn_s_barrier();
@@ -513,27 +564,73 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
 
-    int kt = 0, ti = 0;
+    // ---- stream-K hand-off (SK): accumulators <-> this block's slab, [wave][register group][lane] f32x4: 1 KiB per wave-instruction
+    auto sk_publish = [&]() __attribute__((always_inline)) {
+        if constexpr (SK) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_ws + (long)skw * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+            int idx = wave * (2 * RA * NCB) * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c, idx += 64)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][i][c]), rs, idx * 16, 0, 16);   // aux 16 = sc1: write-through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains (and with it the staging loads in flight: one bubble per contribution)
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) __hip_atomic_store(p.sk_flag + skw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto sk_gather = [&](int end_k) __attribute__((always_inline)) {   // owner of an unfinished tile: add the slabs of the blocks holding K tiles end_k .. nkt-1
+        if constexpr (SK) {
+            int c = skw + 1;
+            for (int rem = nkt - end_k; rem > 0; rem -= p.sk_L, ++c) {
+                if (tid == 0) {
+                    unsigned spins = 0;                            // bounded: a lost contribution must not hang the device (the result is then wrong, tests catch it)
+                    while (__hip_atomic_load(p.sk_flag + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.sk_flag + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one consumer per flag: clear it for the next launch
+                }
+                __builtin_amdgcn_s_barrier();
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws + (long)c * (BM * BN)) + wave * (2 * RA * NCB) * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < RA; ++i)
+#pragma unroll
+                        for (int cc = 0; cc < NCB; ++cc, src += 64) acc[a][i][cc] += *src;
+            }
+        }
+    };
+
+    int kt = kt0, ti = 0;
     for (int s = 0; s < S; ++s) {
         const unsigned char* stage = smem + (s & 1) * STAGE;
         MLSD_PP_PHASE(0, 0, true, true, issue_B2(), W1)
         MLSD_PP_PHASE(0, 1, false, true, issue_B3(), W2)
         MLSD_PP_PHASE(1, 1, true, false, issue_A(sa[1], 1), -1)
         MLSD_PP_PHASE(1, 0, false, false, issue_A(sa[0], 0), W4)
-        if (++kt == nkt) {
+        const bool tile_done = ++kt == nkt;
+        if (tile_done || (SK && s == S - 1)) {
             // seam: the next output tile's first units are in flight / landed; nothing is drained.  The groups
             // rejoin (group 0's extra barrier pairs with group 1's last one) so that all 8 waves run their
             // epilogues side by side, then group 1 drops one barrier behind again (equal barrier counts).
             if (wr == 0) __builtin_amdgcn_s_barrier();
             if (ti == 0) stamp(2);
             if (ti == ntile - 1) stamp(4);
-            if (!(p.dbg & 1)) epilogue();
+            if constexpr (SK) {
+                if (ti == 0 && kt0 > 0) sk_publish();                  // this segment started inside the tile: a contribution
+                else { if (!tile_done) sk_gather(kt); epilogue(); }    // this block owns the tile (its stream may end before the tile does)
+            } else {
+                if (!(p.dbg & 1)) epilogue();
+            }
             if (ti == 0) stamp(3);
             if (ti == ntile - 1) stamp(5);
             zero_acc();
             kt = 0; ++ti;
             tcur = tnext;                                  // every sequence has entered tile ti by now (K >= 3 K tiles)
-            tnext = pp_tile_coords<BM, BN>(p, (int)blockIdx.x + (ti + 1 < ntile ? ti + 1 : 0) * G);
+            tnext = tile_at(ti + 1 < ntile ? ti + 1 : 0);
             if (s + 1 < S && wr == 1) __builtin_amdgcn_s_barrier();
         }
     }

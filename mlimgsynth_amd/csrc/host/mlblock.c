@@ -68,6 +68,7 @@ static void ctx_reset_(MLCtx* C)
 	C->n_ops = 0;
 	for (int i=0;i<C->n_chunks;++i) mlsd_free(C->chunks[i]);
 	if (C->splitk_ws) { mlsd_free(C->splitk_ws); C->splitk_ws = NULL; C->splitk_ws_bytes = 0; }
+	if (C->sk_flags) { mlsd_free(C->sk_flags); C->sk_flags = NULL; }
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
@@ -631,6 +632,18 @@ static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
 	return 0;
 }
 
+#define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile */
+static int streamk_get(MLCtx* C, mlsd_gemm_args* g)
+{	/* slabs in the split-K workspace (ops run one at a time on the plan's stream) + the plan's flag words */
+	if (splitk_ws_get(C, g)) return -1;
+	if (!C->sk_flags) {
+		if (mlsd_malloc((void**)&C->sk_flags, 4096)) return -1;
+		if (mlsd_memset(C->sk_flags, 0, 4096, C->stream) || mlsd_stream_sync(C->stream)) return -1;
+	}
+	g->sk_flags = C->sk_flags;
+	return 0;
+}
+
 /* prep-time selection: table hit -> its variant / K split; miss -> the launcher's static choice (tile_variant 0) */
 static int select_gemm(MLCtx* C, MLOp* op)
 {
@@ -641,6 +654,7 @@ static int select_gemm(MLCtx* C, MLOp* op)
 		g->tile_variant = best; g->ksplit = ks;
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
 		if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+		if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
 		return 1;
 	}
 	g->tile_variant = 0; g->ksplit = 1;
@@ -673,6 +687,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		if (tune_lookup(&k, &best, &ks)) {
 			g->tile_variant = best; g->ksplit = ks;
 			if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+			if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
 			return 1;
 		}
 	}
@@ -683,7 +698,12 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
 		 * one filter tap (anything else they would hand to the LDS-transposing tile of the same shape anyway) */
 		const int pp_ok = !(g->K & 63) && g->K >= 192 && (!g->conv || (!g->upsample && !(g->Cin & 63)));
-		if (pp_ok && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63)) { cv[nc]=17; cs[nc++]=1; }
+		if (pp_ok && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63)) {
+			cv[nc]=17; cs[nc++]=1;
+			/* stream-K on the same tile where the tiles do not fill whole rounds of the 256 blocks */
+			const long t256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256);
+			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
+		}
 		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; }
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}

@@ -102,7 +102,8 @@ struct MLCtx {
 	int static_valid;       /* the outputs of the `once` ops are current (no static_src input was written since they last ran) */
 	int n_once, graph_hoisted;
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
-	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums (one buffer: ops run in order on one stream) */
+	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums / stream-K slabs (one buffer: ops run in order on one stream) */
+	unsigned* sk_flags;                        /* stream-K: one flag per persistent block, zeroed once (consumers clear them) */
 	MLCtxInfo info;
 };
 

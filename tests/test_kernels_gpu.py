@@ -235,6 +235,90 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
         assert np.abs(got - ref).max() < 1e-3, rep
 
 
+SK_CASES = [(8192, 1280, 1280, 0), (8192, 1280, 5120, 1), (2560, 768, 4096, 0), (8192, 3840, 1280, 2), (1280, 1024, 8192, 1), (33024, 256, 512, 0), (512, 512, 16384, 3)]
+
+
+@pytest.mark.parametrize("M,N,Kd,mode", SK_CASES)
+def test_gemm_stream_k_matches_plain_pingpong_tile(K, M, N, Kd, mode):
+    """Stream-K (tile variant 19: the launch's K-tile units dealt evenly over the 256 persistent blocks, partial tiles combined in-launch
+    through write-through slabs + flags) against the same tile without it (17) and the exact product: segments that start in the
+    middle of a tile, whole tiles inside a stream, streams that end in the middle of a tile, one to four contributors per tile,
+    streams of under one tile and of many tiles; fp32 / fp32 + residual / fp16 / bias + SiLU (generic) epilogues.  Repeated: the
+    hand-off is flag-ordered and the slabs are added in block order, so every launch gives the same bits, and the flags must come
+    back cleared (a second launch would hang on a stale one or skip a wait)."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(M + Kd + mode)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA, dW, dR, dB = dev(_lib, A), dev(_lib, W), dev(_lib, R), dev(_lib, bias)
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = _lib.DeviceBuffer(4096)
+    _lib.check(L.mlsd_memset(_lib.vp(fl.ptr), 0, ctypes.c_size_t(4096), None))
+    dC = _lib.DeviceBuffer(M * N * 4)
+    def mk(v):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, tile_variant=v + 1, ws=ws.ptr, ws_bytes=ws.nbytes,
+                             sk_flags=fl.ptr)
+        if mode == 2: a.C16, a.ldc16 = dC.ptr, N
+        else: a.C32, a.ldc32 = dC.ptr, N
+        if mode == 1: a.resid, a.ldr = dR.ptr, N
+        if mode == 3: a.bias, a.act = dB.ptr, kernels.ACT_SILU
+        return a
+    exact = A.astype(np.float32) @ W.astype(np.float32).T
+    if mode == 1: exact = exact + R
+    if mode == 3: exact = (exact + bias) / (1 + np.exp(-(exact + bias)))
+    dt = np.float16 if mode == 2 else np.float32
+    tol = 1e-3 if mode == 2 else 3e-5
+    kernels.gemm(mk(17))
+    ref = dC.download((M, N), dt).astype(np.float32)
+    assert rel(ref, exact) < tol
+    assert "ppsk" in kernels.gemm_variant(mk(19))
+    first = None
+    for rep in range(5):
+        _lib.check(L.mlsd_memset(_lib.vp(dC.ptr), 0x7C, ctypes.c_size_t(M * N * 4), None))
+        kernels.gemm(mk(19))
+        raw = dC.download((M, N), dt)
+        got = raw.astype(np.float32)
+        assert np.isfinite(got).all() and rel(got, exact) < tol, rep
+        assert np.abs(got - ref).max() < (2e-2 if mode == 2 else 1e-3) * max(1.0, np.abs(ref).max()), rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+        assert not fl.download((1024,), np.uint32).any(), rep           # every flag consumed and cleared
+
+
+def test_conv2d_stream_k(K):
+    """The implicit-GEMM conv as stream-K: a stream that starts inside a tile starts inside a filter tap / channel slab."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(5)
+    n, h, w, cin, cout = 2, 32, 32, 320, 768
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin))
+    dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    dW = dev(_lib, repack_conv_w(wt, cin).astype(np.float16))
+    M = n * h * w
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = _lib.DeviceBuffer(4096)
+    _lib.check(L.mlsd_memset(_lib.vp(fl.ptr), 0, ctypes.c_size_t(4096), None))
+    outs = {}
+    for v in (17, 19):
+        dC = _lib.DeviceBuffer(M * cout * 4)
+        a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=h, OW=w, KH=3, KW=3, stride=1, pad=1, W_=dW.ptr,
+                             ldb=9 * cin, M=M, N=cout, K=9 * cin, C32=dC.ptr, ldc32=cout, tile_variant=v + 1, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr)
+        assert ("ppsk" in kernels.gemm_variant(a)) == (v == 19)
+        for rep in range(3):
+            kernels.gemm(a)
+            o = dC.download((M, cout), np.float32)
+            assert rep == 0 or np.array_equal(o, outs[v])
+            outs[v] = o
+    assert rel(outs[19], outs[17]) < 1e-5 and np.abs(outs[19] - outs[17]).max() < 1e-3
+    assert not fl.download((1024,), np.uint32).any()
+
+
 @pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
                                      if not (pp == 18 and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
