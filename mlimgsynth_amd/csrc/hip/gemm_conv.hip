@@ -662,6 +662,7 @@ int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
     if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15)) return false;
+    if (a->conv && a->colstats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
     const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
     const long L = (tiles * nkt + g_gemm_ncu - 1) / g_gemm_ncu;
     return nkt >= 3 && L >= 4 && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);

@@ -594,12 +594,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 }
                 __builtin_amdgcn_s_barrier();
                 const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws + (long)c * (BM * BN)) + wave * (2 * RA * NCB) * 64 + lane;
+                // NCB loads in flight at a time: left free, the compiler issued all 2 RA NCB loads (128 registers) beside the 128
+                // accumulators and spilled through the whole kernel (5x slower main loop)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int i = 0; i < RA; ++i)
+                    for (int i = 0; i < RA; ++i) {
+                        f32x4 t[NCB];
 #pragma unroll
-                        for (int cc = 0; cc < NCB; ++cc, src += 64) acc[a][i][cc] += *src;
+                        for (int cc = 0; cc < NCB; ++cc) t[cc] = src[((a * RA + i) * NCB + cc) * 64];
+#pragma unroll
+                        for (int cc = 0; cc < NCB; ++cc) acc[a][i][cc] += t[cc];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
             }
         }
     };
@@ -620,8 +627,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             if (ti == 0) stamp(2);
             if (ti == ntile - 1) stamp(4);
             if constexpr (SK) {
-                if (ti == 0 && kt0 > 0) sk_publish();                  // this segment started inside the tile: a contribution
-                else { if (!tile_done) sk_gather(kt); epilogue(); }    // this block owns the tile (its stream may end before the tile does)
+                const bool contrib = ti == 0 && kt0 > 0;               // this segment started inside the tile: a contribution
+                if (!contrib && !tile_done) sk_gather(kt);             // this block owns the tile but its stream ends before the tile does
+                if (contrib) sk_publish(); else epilogue();
             } else {
                 if (!(p.dbg & 1)) epilogue();
             }
