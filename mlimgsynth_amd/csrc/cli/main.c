@@ -154,7 +154,9 @@ static int inflate_(const unsigned char* src, size_t n, Buf* out)
 			for (int i=0;i<30;++i) lens[i] = 5;
 			huff_build(&hd, lens, 30);
 		} else if (type == 2) {
-			const int nl = getbits(&s,5)+257, nd = getbits(&s,5)+1, nc = getbits(&s,4)+4;
+			const int b5 = getbits(&s,5), d5 = getbits(&s,5), c4 = getbits(&s,4);
+			if (b5 < 0 || d5 < 0 || c4 < 0) return -1;                  /* (end of input inside the header) */
+			const int nl = b5+257, nd = d5+1, nc = c4+4;
 			if (nl > 286 || nd > 30) return -1;
 			unsigned char cl[19]; memset(cl, 0, sizeof(cl));
 			for (int i=0;i<nc;++i) { const int v = getbits(&s,3); if (v < 0) return -1; cl[order[i]] = (unsigned char)v; }
@@ -162,11 +164,11 @@ static int inflate_(const unsigned char* src, size_t n, Buf* out)
 			for (int i=0; i<nl+nd; ) {
 				int sym = huff_decode(&s, &hc); if (sym < 0) return -1;
 				if (sym < 16) { lens[i++] = (unsigned char)sym; continue; }
-				int rep, val = 0;
-				if (sym == 16) { if (!i) return -1; val = lens[i-1]; rep = 3 + getbits(&s,2); }
-				else if (sym == 17) rep = 3 + getbits(&s,3);
-				else rep = 11 + getbits(&s,7);
-				if (i + rep > nl + nd) return -1;
+				int rep, val = 0, xb;
+				if (sym == 16) { if (!i) return -1; val = lens[i-1]; xb = getbits(&s,2); rep = 3 + xb; }
+				else if (sym == 17) { xb = getbits(&s,3); rep = 3 + xb; }
+				else { xb = getbits(&s,7); rep = 11 + xb; }
+				if (xb < 0 || i + rep > nl + nd) return -1;
 				while (rep--) lens[i++] = (unsigned char)val;
 			}
 			huff_build(&hl, lens, nl); huff_build(&hd, lens + nl, nd);
@@ -176,16 +178,21 @@ static int inflate_(const unsigned char* src, size_t n, Buf* out)
 			if (sym < 256) { unsigned char c = (unsigned char)sym; buf_put(out, &c, 1); continue; }
 			if (sym == 256) break;
 			sym -= 257; if (sym >= 29) return -1;
-			const int len = lbase[sym] + getbits(&s, lext[sym]);
+			const int lx = lext[sym] ? getbits(&s, lext[sym]) : 0;
+			if (lx < 0) return -1;
+			const int len = lbase[sym] + lx;
 			const int ds = huff_decode(&s, &hd); if (ds < 0 || ds >= 30) return -1;
-			const size_t dist = (size_t)dbase[ds] + (size_t)getbits(&s, dext[ds]);
-			if (dist > out->n) return -1;
+			const int dx = dext[ds] ? getbits(&s, dext[ds]) : 0;
+			if (dx < 0) return -1;                                      /* (-1 at the end of the input used to give dist == 0: a read past the buffer) */
+			const size_t dist = (size_t)dbase[ds] + (size_t)dx;
+			if (dist < 1 || dist > out->n) return -1;
 			for (int i=0;i<len;++i) { unsigned char c = out->d[out->n - dist]; buf_put(out, &c, 1); }
 		}
 	} while (!last);
 	return 1;
 }
 
+#define IMG_DIM_MAX 65535      /* like MLIS_OPT_IMAGE_DIM's range */
 typedef struct { unsigned char* d; unsigned w, h, c; } Img;
 static int paeth(int a, int b, int c) { int p=a+b-c, pa=abs(p-a), pb=abs(p-b), pc=abs(p-c); return (pa<=pb && pa<=pc) ? a : (pb<=pc ? b : c); }
 static int img_read(const char* path, Img* im)
@@ -208,6 +215,7 @@ static int img_read(const char* path, Img* im)
 		}
 		im->c = ct == 0 ? 1 : ct == 2 ? 3 : ct == 6 ? 4 : ct == 4 ? 2 : 0;
 		if (bd != 8 || !im->c || il || !im->w || !im->h || z.n < 6) { free(f.d); free(z.d); FAIL("'%s': only 8-bit non-interlaced gray/RGB/RGBA PNG is supported", path); }
+		if (im->w > IMG_DIM_MAX || im->h > IMG_DIM_MAX) { free(f.d); free(z.d); FAIL("'%s': image larger than %d x %d", path, IMG_DIM_MAX, IMG_DIM_MAX); }   /* header fields are untrusted: keeps every size product below 2^34 */
 		if (inflate_(z.d + 2, z.n - 2, &raw) < 0 || raw.n < (size_t)im->h * ((size_t)im->w * im->c + 1)) { free(f.d); free(z.d); free(raw.d); FAIL("'%s': corrupt PNG data", path); }
 		const size_t st = (size_t)im->w * im->c;
 		im->d = (unsigned char*)malloc(st * im->h);
@@ -226,12 +234,13 @@ static int img_read(const char* path, Img* im)
 		size_t p = 2; unsigned v[3];
 		for (int i=0;i<3;++i) {
 			for (;;) { while (p < f.n && isspace(f.d[p])) p++; if (p < f.n && f.d[p] == '#') { while (p < f.n && f.d[p] != '\n') p++; } else break; }
-			v[i] = 0; while (p < f.n && isdigit(f.d[p])) v[i] = v[i]*10 + (f.d[p++] - '0');
+			v[i] = 0; while (p < f.n && isdigit(f.d[p])) { if (v[i] > 100000000u) v[i] = 100000000u; v[i] = v[i]*10 + (f.d[p++] - '0'); }   /* (saturating: no wrap on long digit strings) */
 		}
 		p++;
 		im->w = v[0]; im->h = v[1]; im->c = f.d[1] == '6' ? 3 : 1;
+		if (im->w > IMG_DIM_MAX || im->h > IMG_DIM_MAX) { free(f.d); FAIL("'%s': image larger than %d x %d", path, IMG_DIM_MAX, IMG_DIM_MAX); }
 		const size_t need = (size_t)im->w * im->h * im->c;
-		if (v[2] != 255 || !need || p + need > f.n) { free(f.d); FAIL("'%s': unsupported PNM (binary, maxval 255 only)", path); }
+		if (v[2] != 255 || !need || p > f.n || need > f.n - p) { free(f.d); FAIL("'%s': unsupported PNM (binary, maxval 255 only)", path); }
 		im->d = (unsigned char*)malloc(need); memcpy(im->d, f.d + p, need);
 		free(f.d);
 		return 1;
@@ -265,15 +274,16 @@ static int tensor_load(MLIS_Tensor* t, const char* path)
 	int s[4] = {1,1,1,1}; size_t p = 11, i = 0;
 	if (f.n < 24 || memcmp(f.d, "TENSOR F32 ", 11)) { free(f.d); FAIL("file '%s' is not a valid tensor", path); }
 	for (; i<4; ++i) {
-		int n = 0; while (p < f.n && isdigit(f.d[p])) n = n*10 + (f.d[p++] - '0');
+		int n = 0; while (p < f.n && isdigit(f.d[p])) { if (n > 100000000) n = 100000000; n = n*10 + (f.d[p++] - '0'); }
 		s[i] = n;
 		if (p >= f.n) break;
 		if (f.d[p] == '\n') { p++; break; }
 		if (i == 3 || f.d[p] != ' ') { free(f.d); FAIL("file '%s' is not a valid tensor", path); }
 		p++;
 	}
-	const size_t cnt = (size_t)s[0]*s[1]*s[2]*s[3];
-	if (!cnt || p + cnt*4 > f.n) { free(f.d); FAIL("file '%s': truncated tensor", path); }
+	size_t cnt = 1;
+	for (int k=0;k<4;++k) { if (s[k] <= 0 || (size_t)s[k] > f.n || cnt > f.n / (size_t)s[k]) { cnt = 0; break; } cnt *= (size_t)s[k]; }   /* overflow-safe: every factor and the product are bounded by the file size */
+	if (!cnt || p > f.n || cnt > (f.n - p) / 4) { free(f.d); FAIL("file '%s': truncated tensor", path); }
 	mlis_tensor_resize(t, s[0], s[1], s[2], s[3]);
 	memcpy(t->d, f.d + p, cnt*4);
 	free(f.d);

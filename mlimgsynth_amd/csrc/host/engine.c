@@ -21,7 +21,7 @@
 
 int unet_denoise_build(UnetState* S);
 
-#define MAX_STEPS 256
+#define MAX_STEPS 1001     /* the public option STEPS accepts 0..1000 like the reference (mlimgsynth_options_set.c.h); buffers that follow the step count are sized in ensure_steps */
 #define MAX_BATCH 64
 #define MAX_DRAWS (2 * MAX_STEPS + 2)
 #define N_TMP 2
@@ -92,7 +92,7 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 /* buffers whose size follows the step count: noise draws (<= 2 per step + 2), per-evaluation scalars and events (<= 2 per step) */
 static int ensure_steps(MLIS_AmdCtx* S, int ns)
 {
-	if (ns >= MAX_STEPS) return fail("too many steps (max 255)");
+	if (ns >= MAX_STEPS) return fail("too many steps (max 1000)");
 	if (ns <= S->cap_steps) return 1;
 	const size_t lat_elems = (size_t)S->B * 4 * S->hw;
 	mlsd_stream_sync(S->stream);
@@ -125,7 +125,7 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 	snprintf(S->model, sizeof(S->model), "%s", cfg->model ? cfg->model : "sd1");
 	S->c.model = S->model;
 	if (S->c.n_step < 1) S->c.n_step = 20;
-	if (S->c.n_step >= MAX_STEPS) { fail("too many steps (max 255)"); goto err; }
+	if (S->c.n_step >= MAX_STEPS) { fail("too many steps (max 1000)"); goto err; }
 	if (S->c.n_batch < 1) S->c.n_batch = 1;
 	if (S->c.n_batch > MAX_BATCH) { fail("n_batch > 64 not supported"); goto err; }
 	if (!(S->c.cfg_scale > 0)) S->c.cfg_scale = 7;          /* default cfg 7, src/mlimgsynth.c:474 */

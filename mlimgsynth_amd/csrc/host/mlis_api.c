@@ -183,7 +183,9 @@ MLB_API MLIS_Ctx* mlis_ctx_create_i(int version)
 
 static void engine_drop(MLIS_Ctx* S)
 {
-	if (S->eng) { S->rng_offset = mlis_amd_rng_offset(S->eng); mlis_amd_destroy(S->eng); S->eng = NULL; S->eng_key[0] = 0; }
+	/* (the context's Philox offset is copied back after every SEEDED use of an engine -- generate / image encode -- and nowhere else:
+	 * an engine that was only built for mlis_image_decode still has offset 0 and must not reset the context's running offset) */
+	if (S->eng) { mlis_amd_destroy(S->eng); S->eng = NULL; S->eng_key[0] = 0; }
 }
 static void textcond_drop(MLIS_Ctx* S) { if (S->tc) { mlis_amd_textcond_destroy(S->tc); S->tc = NULL; S->tc_key[0] = 0; } }
 static void model_drop(MLIS_Ctx* S)
@@ -219,7 +221,11 @@ MLB_API const char* mlis_errstr_get(const MLIS_Ctx* S) { return S ? S->errstr : 
 MLB_API struct MLIS_AmdCtx* mlis_amd_engine_get(MLIS_Ctx* S) { return S ? S->eng : NULL; }
 
 /* ------------------------------------------------------------------ options */
-static int model_type_set(MLIS_Ctx* S, int mt)
+/* by_option: the type comes from MLIS_OPT_MODEL_TYPE (it then survives a checkpoint whose type cannot be detected); a type that
+ * mlis_setup DETECTED describes that checkpoint only and must not excuse the next, unidentifiable one */
+static int model_type_set_ex(MLIS_Ctx* S, int mt, int by_option);
+static int model_type_set(MLIS_Ctx* S, int mt) { return model_type_set_ex(S, mt, 1); }
+static int model_type_set_ex(MLIS_Ctx* S, int mt, int by_option)
 {	/* mlis_model_type_set :738-786: per-model defaults of size and clip_skip */
 	int w = 0, skip = 0;
 	switch (mt) {
@@ -233,7 +239,7 @@ static int model_type_set(MLIS_Ctx* S, int mt)
 	}
 	if (mt) { if (S->width <= 0) S->width = w; if (S->height <= 0) S->height = S->width; if (S->clip_skip <= 0) S->clip_skip = skip; }
 	S->model_type = mt;
-	if (mt) S->flags |= CF_MODEL_TYPE_SET; else S->flags &= ~CF_MODEL_TYPE_SET;
+	if (by_option) { if (mt) S->flags |= CF_MODEL_TYPE_SET; else S->flags &= ~CF_MODEL_TYPE_SET; }
 	snprintf(S->mname, sizeof(S->mname), "%s", mt ? model_name(mt) : "");
 	return 1;
 }
@@ -547,13 +553,15 @@ MLB_API int mlis_setup(MLIS_Ctx* S)
 	}
 	if (!(S->rflags & READY_MODEL)) {
 		if (str_empty(S->path_model)) return api_error(S, MLIS_E_FILE_NOT_FOUND, "no model set (option MODEL)");
+		if (S->ts) { mlts_close(S->ts); S->ts = NULL; }               /* left over from a set-up that failed after opening the file */
+		if (S->ts_tae) { mlts_close(S->ts_tae); S->ts_tae = NULL; }
 		if (!strncmp(S->path_model, "synth:", 6)) {
 			char nm[32]; snprintf(nm, sizeof(nm), "%s", S->path_model + 6);
 			char *c = strchr(nm, ':'); S->synth_seed = 1234;
 			if (c) { *c = 0; S->synth_seed = strtoull(c + 1, NULL, 10); }
 			const int mt = model_from(nm, strlen(nm));
 			if (mt <= 0) return api_error(S, MLIS_E_OPT_VALUE, "unknown synthetic model '%s'", nm);
-			if (model_type_set(S, mt) < 0) return MLIS_E_OPT_VALUE;
+			if (model_type_set_ex(S, mt, 0) < 0) return MLIS_E_OPT_VALUE;
 			S->synth = 1;
 		} else {
 			/* mlis_model_load :1163-1204 + mlis_model_identify :1206-1249 */
@@ -562,13 +570,13 @@ MLB_API int mlis_setup(MLIS_Ctx* S)
 			if (!S->ts) return api_error_lib(S, file_exists(S->path_model) ? MLIS_E_UNKNOWN : MLIS_E_FILE_NOT_FOUND);
 			int wt = -1;
 			const char *m = mlts_model_identify(S->ts, &wt);
-			if (m) { if (model_type_set(S, model_from(m, strlen(m))) < 0) return MLIS_E_OPT_VALUE; }
-			else if (!(S->flags & CF_MODEL_TYPE_SET)) return api_error(S, MLIS_E_UNKNOWN, "could not detect the model type");
+			if (m) { if (model_type_set_ex(S, model_from(m, strlen(m)), 0) < 0) { mlts_close(S->ts); S->ts = NULL; return MLIS_E_OPT_VALUE; } }
+			else if (!(S->flags & CF_MODEL_TYPE_SET)) { mlts_close(S->ts); S->ts = NULL; return api_error(S, MLIS_E_UNKNOWN, "could not detect the model type"); }
 			if (wt >= 0 && !(S->flags & CF_WEIGHT_TYPE_SET)) S->wtype = (wt == MLT_F32 || wt == MLT_BF16) ? wt : MLT_F16;   /* quantised GGUF weights: dequantised, kept as F16 */
 		}
 		if ((S->flags & CF_USE_TAE) && !S->synth && !str_empty(S->path_tae)) {
 			S->ts_tae = mlts_open_safetensors(S->path_tae, 0);
-			if (!S->ts_tae) return api_error_lib(S, file_exists(S->path_tae) ? MLIS_E_UNKNOWN : MLIS_E_FILE_NOT_FOUND);
+			if (!S->ts_tae) { if (S->ts) { mlts_close(S->ts); S->ts = NULL; } return api_error_lib(S, file_exists(S->path_tae) ? MLIS_E_UNKNOWN : MLIS_E_FILE_NOT_FOUND); }
 		}
 		S->rflags |= READY_MODEL;
 		S->rflags &= ~READY_LORAS;

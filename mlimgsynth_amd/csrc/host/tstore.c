@@ -509,13 +509,23 @@ MLB_API int mlts_lora_apply(MLTStore* D, const MLTStore* L, float mult, int wtyp
 		const MLTSEntry *ls = mlts_find(L, key);
 		snprintf(key, sizeof(key), "%.*s.alpha", bl, ld->name);
 		const MLTSEntry *la = mlts_find(L, key);
+		/* the file is untrusted input (the reference's arithmetic here is unchecked, src/lora.c:30-50): a 0-dimensional or
+		 * zero-sized tensor must not index shape[-1] or divide by zero, and the element counts must factor exactly */
+		if (ld->n_dim < 2 || lu->n_dim < 2 || dst->n_dim < 2 || ld->n_dim > 4 || lu->n_dim > 4)
+			return mlsd_set_error(-1, "lora up/down invalid shapes for %.*s", bl, ld->name);
 		const int64_t n_inner = ld->shape[ld->n_dim - 1];
 		const int64_t cd = ld->shape[0]*ld->shape[1]*ld->shape[2]*ld->shape[3], cu = lu->shape[0]*lu->shape[1]*lu->shape[2]*lu->shape[3];
 		const int64_t cw = dst->shape[0]*dst->shape[1]*dst->shape[2]*dst->shape[3];
-		const int64_t n0 = cd / n_inner, n1 = cu / n_inner;
-		if (!(dst->n_dim >= 2 && ld->n_dim == dst->n_dim && lu->n_dim == dst->n_dim && cw == n0 * n1))
+		if (n_inner <= 0 || cd <= 0 || cu <= 0 || cw <= 0 || cd % n_inner || cu % n_inner)
 			return mlsd_set_error(-1, "lora up/down invalid shapes for %.*s", bl, ld->name);
+		const int64_t n0 = cd / n_inner, n1 = cu / n_inner;
+		if (!(ld->n_dim == dst->n_dim && lu->n_dim == dst->n_dim && cw == n0 * n1))
+			return mlsd_set_error(-1, "lora up/down invalid shapes for %.*s", bl, ld->name);
+		if (ld->dtype == MLT_I32 || ld->dtype == MLT_I64 || lu->dtype == MLT_I32 || lu->dtype == MLT_I64 || dst->dtype == MLT_I32 || dst->dtype == MLT_I64)
+			return mlsd_set_error(-1, "lora: integer tensor in %.*s", bl, ld->name);
 		float scale = 1;
+		if (ls && ls->shape[0]*ls->shape[1]*ls->shape[2]*ls->shape[3] < 1) ls = NULL;
+		if (la && la->shape[0]*la->shape[1]*la->shape[2]*la->shape[3] < 1) la = NULL;
 		if (ls) { float *t = entry_to_f32(ls, 0); scale = t[0]; free(t); }
 		else if (la) { float *t = entry_to_f32(la, 0); scale = t[0] / n_inner; free(t); }
 		scale *= mult;
@@ -533,7 +543,11 @@ MLB_API int mlts_lora_apply(MLTStore* D, const MLTStore* L, float mult, int wtyp
 		}
 		free(delta);
 		free(down); free(up);
-		if (!isfinite(w[0])) { free(w); return mlsd_set_error(-1, "NaN in LoRA result"); }
+		{	/* (the reference checks element 0 only, src/lora.c:63; a corrupt adapter can poison any row) */
+			int bad = 0;
+			for (int64_t c=0; c<cw && !bad; ++c) bad = !isfinite(w[c]);
+			if (bad) { free(w); return mlsd_set_error(-1, "NaN in LoRA result"); }
+		}
 		void *buf;
 		if (r16) {
 			uint16_t *h = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cw);

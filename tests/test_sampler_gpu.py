@@ -354,3 +354,23 @@ def test_vae_tiling_decode_and_encode_vs_oracle():
     print("tiled encode+sample vs oracle", e)
     assert e < 4e-3
     g.destroy()
+
+
+def test_step_counts_up_to_the_api_limit():
+    """the public option STEPS accepts 0..1000 like the reference; the engine's step-sized buffers (events, scalars, noise
+    draws, sigma table) follow the requested count instead of a fixed 255 cap (300 Euler-a steps, 500 requested Heun steps = 250 + 250 evaluations)."""
+    from mlimgsynth_amd import engine
+    import golden_cases as G
+    cond, uncond, _, _ = G.gen_inputs("gen_tiny_8_20", "tiny")
+    g = engine.Generator("tiny", 64, 64, 1, n_step=300, cfg_scale=7.0, s_ancestral=1.0)
+    g.set_cond(cond, None, uncond, None)
+    lat, _ = g.generate([3], want_images=False)
+    assert np.isfinite(lat).all() and g.last_n_step() == 300 and g.last_nfe() == 600
+    g.destroy()
+    g = engine.Generator("tiny", 64, 64, 1, n_step=500, cfg_scale=7.0, s_ancestral=0.0, method="heun")
+    g.set_cond(cond, None, uncond, None)
+    lat, _ = g.generate([3], want_images=False)
+    assert np.isfinite(lat).all() and g.last_n_step() == 250
+    g.destroy()
+    with pytest.raises(Exception):
+        engine.Generator("tiny", 64, 64, 1, n_step=1001)
