@@ -101,7 +101,15 @@ __device__ __forceinline__ PPTile pp_tile_plain(const GemmP& p, int bid)
 // residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
 enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6 };
 // *_STATS: additionally the column sums / sums of squares of the wave's rows (GemmP::colstats) for a consuming GroupNorm
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false>
+// NPH = 2: TWO phases per K tile instead of four (round 3).  In-kernel stamps of the four-phase loop on the 128 x 320 tile: 2075 clocks
+// per K tile against 1280 of matrix work, the same with the staging switched off (profiles/r2_gemm_trace_*: the loop is not fill-bound
+// on this tile) -- each of its 8 barrier-to-barrier sections carries only 8 or 12 MFMAs (128 / 192 clocks) against ~100 clocks of
+// fixed cost per section (barrier hand-over, priority switch, issue of the next section's reads).  With two phases a section is 20
+// MFMAs (320 clocks):   A: all B fragments + the a0 rows, MFMAs of acc[0];   B: the a1 rows (B fragments stay in registers), acc[1].
+// Staging, every unit ONE K tile ahead:   slot A: U1, U2, U3 of tile s+1, counted wait retires U4(s);   slot B: U4 of tile s+1,
+// counted wait retires U1..U3(s+1).  RAW: a unit is read one slot after the wait that retires it, by then every wave of both groups
+// has passed that wait and a barrier.  WAR: a stage is refilled two or more barriers after its last fragment read was consumed.
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false, int NPH = 4>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -538,8 +546,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     kenter = 0;                                    // every later tile is entered at its first K tile
     tcur = tnext;
     tnext = tile_at(ntile > 1 ? 1 : 0);            // past the end: any valid tile (staged, never read)
-    issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1); issue_A(sa[0], 0);
-    wait_vmcnt<W4>();
+    issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1);
+    if constexpr (NPH == 4) { issue_A(sa[0], 0); wait_vmcnt<W4>(); }      // U1 runs two K tiles ahead
+    else wait_vmcnt<NU1>();                                               // two phases: U1..U3(0) landed, U4(0) retired by slot A
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0 from here on
@@ -611,13 +620,37 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         }
     };
 
+#define MLSD_PP_PHASE2(QA, READS, ISSUE, WAITN)                                                              \
+    {                                                                                                        \
+        READS;                                                                                               \
+        ISSUE;                                                                                               \
+        wait_vmcnt<WAITN>();                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
+                _Pragma("unroll") for (int c = 0; c < NCB; ++c)                                              \
+                    acc[QA][i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[c][ks], af[i][ks], acc[QA][i][c], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+
     int kt = kt0, ti = 0;
     for (int s = 0; s < S; ++s) {
         const unsigned char* stage = smem + (s & 1) * STAGE;
+        if constexpr (NPH == 2) {
+            MLSD_PP_PHASE2(0, (read_B(stage, 0), read_B(stage, 1), read_A(stage, 0)), (issue_A(sa[0], 0), issue_B2(), issue_B3()), NU1 + NU2 + NU3)
+            MLSD_PP_PHASE2(1, read_A(stage, 1), issue_A(sa[1], 1), NU1)
+        } else {
         MLSD_PP_PHASE(0, 0, true, true, issue_B2(), W1)
         MLSD_PP_PHASE(0, 1, false, true, issue_B3(), W2)
         MLSD_PP_PHASE(1, 1, true, false, issue_A(sa[1], 1), -1)
         MLSD_PP_PHASE(1, 0, false, false, issue_A(sa[0], 0), W4)
+        }
         const bool tile_done = ++kt == nkt;
         if (tile_done || (SK && s == S - 1)) {
             // seam: the next output tile's first units are in flight / landed; nothing is drained.  The groups
@@ -643,6 +676,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         }
     }
 #undef MLSD_PP_PHASE
+#undef MLSD_PP_PHASE2
     wait_vmcnt<0>();                               // the tail stages (clamped rows) still target this block's LDS
     stamp(6);
     if (p.tbuf && tid == 0) p.tbuf[(long)blockIdx.x * 8 + 7] = ntile;

@@ -207,8 +207,9 @@ def test_conv2d_every_tile_variant(K, variant):
 PP_SHAPES = [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768, 320), (4096, 3072, 320), (256, 16640, 256), (8192, 10240, 192),
              (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640), (131072, 320, 320), (192, 960, 1280)]
 # the ping-pong tiles take whole wave blocks (128x64 of the 256x256 tile / 64x80 of the 128x320 tile): only those combinations are cases
-PP_CASES = [(pp, M, N, Kd) for pp in (17, 18) for (M, N, Kd) in PP_SHAPES
-            if not ((pp == 18 and (N % 80 or M % 64)) or (pp == 17 and (N % 64 or M % 128)))]
+# 20 / 21: the same tiles with two phases per K tile instead of four (other staging schedule and counted waits: a sync structure of its own)
+PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21) for (M, N, Kd) in PP_SHAPES
+            if not ((pp in (18, 20) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)))]
 
 
 @pytest.mark.parametrize("pp,M,N,Kd", PP_CASES)
@@ -319,14 +320,14 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
-@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
-                                     if not (pp == 18 and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
+@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
+                                     if not (pp in (18, 20) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
     here -- the multi-tile stream is covered by test_gemm_pingpong_tile_matches_plain_tile."""
     kernels, _lib = K
-    M, N, Kd = (1536, 768, 448) if pp == 17 else (1536, 960, 448)
+    M, N, Kd = (1536, 768, 448) if pp in (17, 21) else (1536, 960, 448)
     rng = np.random.default_rng(len(mode))
     A = f16r(rng.standard_normal((M, Kd)))
     W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
@@ -375,7 +376,7 @@ def test_gemm_pingpong_epilogues(K, mode, pp):
     assert rel(dC16.download((M, nout), np.float16).astype(np.float32), ref) < 1e-3
 
 
-@pytest.mark.parametrize("pp", [17, 18])
+@pytest.mark.parametrize("pp", [17, 18, 20, 21])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 16, 16, 64, 320, 3, 1), (1, 32, 32, 128, 640, 3, 2), (2, 16, 8, 192, 320, 1, 1),
                                                  (4, 32, 32, 64, 1280, 3, 1)])
 def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
@@ -394,7 +395,7 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
     M = n * oh * ow
     rowb = rng.standard_normal((n, cout)).astype(np.float32)
     res = rng.standard_normal((M, cout)).astype(np.float32)
-    use_rb = (oh * ow) % (256 if pp == 17 else 128) == 0
+    use_rb = (oh * ow) % (256 if pp in (17, 21) else 128) == 0
     ref = ref + (rowb[:, :, None, None] if use_rb else 0) + res.reshape(n, oh, ow, cout).transpose(0, 3, 1, 2)
     dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
     dW, dB, dRB, dR = dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias), dev(_lib, rowb), dev(_lib, res)
@@ -402,7 +403,7 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
     a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=oh, OW=ow, KH=k, KW=k, stride=s, pad=pad,
                          W_=dW.ptr, ldb=k * k * cin, M=M, N=cout, K=k * k * cin, bias=dB.ptr, rowbias=dRB.ptr if use_rb else None,
                          rows_per_batch=oh * ow, ldrb=cout, resid=dR.ptr, ldr=cout, C32=dC.ptr, ldc32=cout, tile_variant=pp + 1)
-    if (M % (128 if pp == 17 else 64)) or (cout % (64 if pp == 17 else 80)) or k * k * cin < 192:
+    if (M % (128 if pp in (17, 21) else 64)) or (cout % (64 if pp in (17, 21) else 80)) or k * k * cin < 192:
         pytest.skip("not made of whole wave blocks for this tile")
     assert "pp" in kernels.gemm_variant(a)
     for rep in range(3):
@@ -411,7 +412,8 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
         assert rel(got, ref) < 2e-5, rep
 
 
-@pytest.mark.parametrize("pp,M,N,Kd", [(17, 4096, 2560, 1280), (18, 8192, 1280, 1280), (17, 8192, 5120, 320), (18, 32768, 640, 640)])
+@pytest.mark.parametrize("pp,M,N,Kd", [(17, 4096, 2560, 1280), (18, 8192, 1280, 1280), (17, 8192, 5120, 320), (18, 32768, 640, 640),
+                                       (20, 8192, 1280, 1280), (20, 32768, 640, 640), (21, 4096, 2560, 1280), (20, 131072, 320, 192)])
 def test_gemm_pingpong_is_bit_repeatable(K, pp, M, N, Kd):
     """Race screen: the ping-pong kernels order LDS-DMA writes, fragment reads and restaging only through counted waits
     and barrier parity, and have no atomics -- so 40 launches on the same operands must give bit-identical outputs
@@ -871,7 +873,8 @@ def oracle_key(name, seed):
     return z
 
 
-@pytest.mark.parametrize("pp,conv,res", [(17, False, False), (17, False, True), (18, False, True), (18, True, False), (17, True, True), (18, False, False)])
+@pytest.mark.parametrize("pp,conv,res", [(17, False, False), (17, False, True), (18, False, True), (18, True, False), (17, True, True), (18, False, False),
+                                          (20, False, True), (20, True, False), (21, True, True)])
 def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     """mlsd_gemm_args.colstats: the ping-pong kernels built with a *_STATS epilogue also write, per block of
     mlsd_gemm_colstats_rows() rows and per column, the sum and the sum of squares of the fp32 output they store (the first
@@ -908,7 +911,7 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a0)) == 0
     kernels.gemm(a0)
     plain = dC0.download((M, N), np.float32)
-    rows = 128 if pp == 17 else 64
+    rows = 128 if pp in (17, 21) else 64
     dS = _lib.DeviceBuffer(M // rows * 2 * N * 4)
     a1 = args(dC, dS)
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a1)) == rows
@@ -928,7 +931,7 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
 
 
-@pytest.mark.parametrize("pp,geglu", [(17, False), (18, False), (17, True)])
+@pytest.mark.parametrize("pp,geglu", [(17, False), (18, False), (17, True), (20, False), (21, True)])
 @pytest.mark.parametrize("misalign", ["none", "base+8B", "ld%8=4"])
 def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
     """The fp16 fast epilogues store 16 bytes per lane (v_permlane16_swap pairs of column blocks): they need 16-byte aligned
@@ -938,7 +941,7 @@ def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
     L, vp = _lib.lib(), _lib.vp
     rng = np.random.default_rng(pp + geglu)
     M, Kd = 512, 256
-    N = 1024 if pp == 17 else 960
+    N = 1024 if pp in (17, 21) else 960
     nout = N // 2 if geglu else N
     A = rng.standard_normal((M, Kd)).astype(np.float16)
     W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
