@@ -13,7 +13,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmlimgsynth_amd.so")
+LIB_PATH = os.environ.get("MLSD_LIB_PATH") or os.path.join(_HERE, "lib", "libmlimgsynth_amd.so")     # (override: diagnostic builds, tools/gemm_trace.py)
 
 try:  # plumbing only: device selection + torch.distributed live on the torch side
     import torch  # noqa: F401

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 for (int c = 0; c < NCB; ++c) acc[a][i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    f16x8 af[RA][2], bf[NCB][2];
+    f16x8 af[RA][2] = {}, bf[NCB][2] = {};
 
     auto read_A = [&](const unsigned char* stage, int qa) __attribute__((always_inline)) {
 #pragma unroll
@@ -553,21 +553,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0 from here on
 
+    // timing-only BUILDS of the loop (make EXTRA=-DMLSD_PP_DBG=n, tools/gemm_trace.py; the results are wrong): 4 = no LDS-DMA issue in the loop,
+    // 8 = no fragment reads, 16 = no MFMAs, 32 = no s_setprio.  Compile-time: the same switches as run-time tests cost the production loop 3-59
+    // spilled registers.
+#ifndef MLSD_PP_DBG
+#define MLSD_PP_DBG 0
+#endif
+    constexpr int dbg = MLSD_PP_DBG;
 #define MLSD_PP_PHASE(QA, QB, LOAD_A, LOAD_B, ISSUE, WAITN)                                                  \
     {                                                                                                        \
-        if (LOAD_B) read_B(stage, QB);                                                                       \
-        if (LOAD_A) read_A(stage, QA);                                                                       \
-        ISSUE;                                                                                               \
+        if (!(dbg & 8)) {                                                                                    \
+            if (LOAD_B) read_B(stage, QB);                                                                   \
+            if (LOAD_A) read_A(stage, QA);                                                                   \
+        }                                                                                                    \
+        if (!(dbg & 4)) { ISSUE; }                                                                           \
         if (WAITN >= 0) wait_vmcnt<(WAITN >= 0 ? WAITN : 0)>();                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                                       \
+        if (!(dbg & 32)) __builtin_amdgcn_s_setprio(1);                                                      \
+        if (!(dbg & 16)) {                                                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
             _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
                 _Pragma("unroll") for (int c = (QB ? CB0 : 0); c < (QB ? NCB : CB0); ++c)                    \
                     acc[QA][i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[c][ks], af[i][ks], acc[QA][i][c], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                       \
+        }                                                                                                    \
+        if (!(dbg & 32)) __builtin_amdgcn_s_setprio(0);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                   \

@@ -692,19 +692,19 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		}
 	}
 	/* candidates: (tile variant, K slices) */
-	int cv[24], cs[24], nc = 0;
+	int cv[32], cs[32], nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
 		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
 		 * one filter tap (anything else they would hand to the LDS-transposing tile of the same shape anyway) */
 		const int pp_ok = !(g->K & 63) && g->K >= 192 && (!g->conv || (!g->upsample && !(g->Cin & 63)));
 		if (pp_ok && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63)) {
-			cv[nc]=17; cs[nc++]=1;
+			cv[nc]=17; cs[nc++]=1; cv[nc]=21; cs[nc++]=1;
 			/* stream-K on the same tile where the tiles do not fill whole rounds of the 256 blocks */
 			const long t256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256);
 			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
 		}
-		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; }
+		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; cv[nc]=20; cs[nc++]=1; }   /* four / two phases per K tile */
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);
@@ -725,7 +725,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 				int s = (int)((targets[ti] + tiles / 2) / tiles);
 				if (s > nkt / 2) s = nkt / 2;               /* >= 2 K tiles per slice */
 				while (s > 1 && (size_t)s * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) --s;
-				if (s <= last || nc >= 24) continue;
+				if (s <= last || nc >= 32) continue;
 				cv[nc] = v; cs[nc++] = s; last = s;
 			}
 		}

@@ -31,7 +31,8 @@ tb = _lib.DeviceBuffer(256 * 8 * 8)
 ev = [vp(), vp()]
 for e in ev:
     L.mlsd_event_create(ctypes.byref(e))
-for dbg in (0, 2, 1):
+DBGS = [int(x) for x in os.environ.get('TRACE_DBG', '0,2,1').split(',')]
+for dbg in DBGS:
     L.mlsd_gemm_set_debug(dbg)
     for _ in range(3):
         kernels.gemm(a)
