@@ -668,7 +668,7 @@ bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
     return nkt >= 3 && L >= 4 && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);
 }
 
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool SK = false, int NPH = 4>
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool SK = false, int NPH = 4, int SCH = 0>
 int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 {
     constexpr int BK = 64;
@@ -719,25 +719,25 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     }
     if (a->conv) {
         switch (epi) {
-        case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32, false, NPH>);
-        case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES, false, NPH>);
-        case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_STATS, false, NPH>);
-        case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES_STATS, false, NPH>);
-        default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_GENERIC, false, NPH>);
+        case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32, false, NPH, SCH>);
+        case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES, false, NPH, SCH>);
+        case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_STATS, false, NPH, SCH>);
+        case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_F32_RES_STATS, false, NPH, SCH>);
+        default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, true, PP_EPI_GENERIC, false, NPH, SCH>);
         }
     }
     switch (epi) {
-    case PP_EPI_F16: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F16, false, NPH>);
-    case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32, false, NPH>);
-    case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES, false, NPH>);
-    case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_STATS, false, NPH>);
-    case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES_STATS, false, NPH>);
+    case PP_EPI_F16: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F16, false, NPH, SCH>);
+    case PP_EPI_F32: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32, false, NPH, SCH>);
+    case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES, false, NPH, SCH>);
+    case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_STATS, false, NPH, SCH>);
+    case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES_STATS, false, NPH, SCH>);
     case PP_EPI_GEGLU16:
-        if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16, false, NPH>);
+        if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16, false, NPH, SCH>);
         break;
     default: break;
     }
-    return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, false, NPH>);
+    return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, false, NPH, SCH>);
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
@@ -766,6 +766,7 @@ const Variant kVariants[] = {
     {"256x256x64ppsk", 256, 256, 256},  // 19: variant 17 as STREAM-K: the launch's K-tile units dealt evenly over the 256 blocks, partial tiles combined in-launch
     {"128x320x64pp2", 128, 320, 256},   // 20: variant 18 with TWO phases per K tile (20 MFMAs per barrier-to-barrier section instead of 8 / 12)
     {"256x256x64pp2", 256, 256, 256},   // 21: variant 17 with two phases per K tile (32 MFMAs per section)
+    {"128x320x64ppb", 128, 320, 256},   // 22: variant 18 on the re-balanced staging schedule (gemm_pp.hpp SCH = 1)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -825,6 +826,10 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, false, 2>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
+    case 22:
+        if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, false, 4, 1>(a, st);
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
     case 21: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false, false, 2>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
@@ -869,7 +874,7 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     const int v = pick_variant(a);
     int bm, bn;
     if ((v == 17 || v == 19 || v == 21) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
-    else if ((v == 18 || v == 20) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+    else if ((v == 18 || v == 20 || v == 22) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
     return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
@@ -881,7 +886,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     int v = pick_variant(a);
     if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
-    if ((v == 18 || v == 20) && !pp_eligible(a, 128, 320)) v = 16;
+    if ((v == 18 || v == 20 || v == 22) && !pp_eligible(a, 128, 320)) v = 16;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = v >= 17 ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);

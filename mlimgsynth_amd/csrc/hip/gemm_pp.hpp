@@ -109,7 +109,15 @@ enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, P
 // Staging, every unit ONE K tile ahead:   slot A: U1, U2, U3 of tile s+1, counted wait retires U4(s);   slot B: U4 of tile s+1,
 // counted wait retires U1..U3(s+1).  RAW: a unit is read one slot after the wait that retires it, by then every wave of both groups
 // has passed that wait and a barrier.  WAR: a stage is refilled two or more barriers after its last fragment read was consumed.
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false, int NPH = 4>
+// SCH = 1 (four phases, 128 x 320 tile): the SAME units on a re-balanced issue schedule.  Timing-only builds of the loop (MLSD_PP_DBG,
+// profiles/r3_gemm_loop_ablation.txt) price a fragment read at ~15 clocks and an LDS-DMA instruction at ~45 of the wave that issues it,
+// and show the loop bound by its load slots, not by the matrix pipe: a group's load slot runs beside the other group's MFMA section, and the
+// schedule above puts 10 reads + 3 DMA (~285 clocks) in P1's slot against a 192-clock section while P4's slot is nearly empty.  Here:
+//       P1: U4(s+1)     P2: U3(s+1)     P3: -     P4: U1(s+2), U2(s+2)         (U2 now two K tiles ahead, like U1: its rows are read in P1 only)
+//   counted waits (what may stay in flight):   P4: NU1+NU2+NU3+NU4 (retires U1, U2 of the next tile)    P1: NU1+NU2+NU4 (retires U4, U3 of this tile)
+//   RAW: P1 reads U1/U2 retired in the previous P4; P2 reads U3 retired in P1; P3 reads U4, older than U3, retired with it.  WAR: every
+//   unit is restaged >= 3 phases after the phase that read its rows.
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false, int NPH = 4, int SCH = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -546,9 +554,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     kenter = 0;                                    // every later tile is entered at its first K tile
     tcur = tnext;
     tnext = tile_at(ntile > 1 ? 1 : 0);            // past the end: any valid tile (staged, never read)
-    issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1);
-    if constexpr (NPH == 4) { issue_A(sa[0], 0); wait_vmcnt<W4>(); }      // U1 runs two K tiles ahead
-    else wait_vmcnt<NU1>();                                               // two phases: U1..U3(0) landed, U4(0) retired by slot A
+    if constexpr (NPH == 4 && SCH == 1) {          // the steady-state issue order: U1, U2 (0) | U4 (0) | U3 (0) | U1, U2 (1)
+        issue_A(sa[0], 0); issue_B2(); issue_A(sa[1], 1); issue_B3(); issue_A(sa[0], 0); issue_B2();
+        wait_vmcnt<NU1 + NU2 + NU3 + NU1>();
+    } else {
+        issue_A(sa[0], 0); issue_B2(); issue_B3(); issue_A(sa[1], 1);
+        if constexpr (NPH == 4) { issue_A(sa[0], 0); wait_vmcnt<W4>(); }      // U1 runs two K tiles ahead
+        else wait_vmcnt<NU1>();                                               // two phases: U1..U3(0) landed, U4(0) retired by slot A
+    }
     __builtin_amdgcn_s_barrier();
     stamp(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0 from here on
@@ -656,6 +669,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         if constexpr (NPH == 2) {
             MLSD_PP_PHASE2(0, (read_B(stage, 0), read_B(stage, 1), read_A(stage, 0)), (issue_A(sa[0], 0), issue_B2(), issue_B3()), NU1 + NU2 + NU3)
             MLSD_PP_PHASE2(1, read_A(stage, 1), issue_A(sa[1], 1), NU1)
+        } else if constexpr (SCH == 1) {
+        MLSD_PP_PHASE(0, 0, true, true, issue_A(sa[1], 1), NU1 + NU2 + NU1)
+        MLSD_PP_PHASE(0, 1, false, true, issue_B3(), -1)
+        MLSD_PP_PHASE(1, 1, true, false, (void)0, -1)
+        MLSD_PP_PHASE(1, 0, false, false, (issue_A(sa[0], 0), issue_B2()), NU1 + NU2 + NU3 + NU1)
         } else {
         MLSD_PP_PHASE(0, 0, true, true, issue_B2(), W1)
         MLSD_PP_PHASE(0, 1, false, true, issue_B3(), W2)

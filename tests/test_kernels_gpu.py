@@ -208,8 +208,8 @@ PP_SHAPES = [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768,
              (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640), (131072, 320, 320), (192, 960, 1280)]
 # the ping-pong tiles take whole wave blocks (128x64 of the 256x256 tile / 64x80 of the 128x320 tile): only those combinations are cases
 # 20 / 21: the same tiles with two phases per K tile instead of four (other staging schedule and counted waits: a sync structure of its own)
-PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21) for (M, N, Kd) in PP_SHAPES
-            if not ((pp in (18, 20) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)))]
+PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21, 22) for (M, N, Kd) in PP_SHAPES
+            if not ((pp in (18, 20, 22) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)))]
 
 
 @pytest.mark.parametrize("pp,M,N,Kd", PP_CASES)
@@ -320,8 +320,8 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
-@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
-                                     if not (pp in (18, 20) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
+@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
+                                     if not (pp in (18, 20, 22) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
@@ -376,7 +376,7 @@ def test_gemm_pingpong_epilogues(K, mode, pp):
     assert rel(dC16.download((M, nout), np.float16).astype(np.float32), ref) < 1e-3
 
 
-@pytest.mark.parametrize("pp", [17, 18, 20, 21])
+@pytest.mark.parametrize("pp", [17, 18, 20, 21, 22])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 16, 16, 64, 320, 3, 1), (1, 32, 32, 128, 640, 3, 2), (2, 16, 8, 192, 320, 1, 1),
                                                  (4, 32, 32, 64, 1280, 3, 1)])
 def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
