@@ -128,8 +128,11 @@ typedef struct mlsd_gemm_args {
 	float* colstats;
 	int colstats_rows;      /* > 0: the consumer was wired for statistics blocks of this many rows: mlsd_gemm FAILS unless this
 	                         * launch writes exactly those (a tile / epilogue knob changed between planning and launching) */
-	/* stream-K (tile variant 19): one zeroed 32-bit flag per persistent block (256 words; cleared again by their consumers) beside
-	 * the workspace `ws` (>= 256 fp32 slabs of 256 x 256: mlsd_gemm_streamk_ws_bytes()).  NULL: the launch runs as variant 17. */
+	/* 4096 zeroed 32-bit words that stay zero between launches (the kernels that use them clear them again):
+	 *  - stream-K (tile variant 19): a flag per persistent block beside the workspace `ws` (>= 256 fp32 slabs of 256 x 256:
+	 *    mlsd_gemm_streamk_ws_bytes()).  NULL: the launch runs as variant 17.
+	 *  - split-K (ksplit > 1): a ticket counter per output tile; the slices are then added inside the launch (no second launch).
+	 *    NULL, or more than 4096 tiles: the two-launch form. */
 	unsigned* sk_flags;
 } mlsd_gemm_args;
 
@@ -147,6 +150,10 @@ int mlsd_gemm_num_variants(void);
 void mlsd_gemm_set_epilogue(int e);
 /* timing-only builds of the main loop (needs -DMLSD_GEMM_EXPERIMENTS; otherwise ignored) */
 void mlsd_gemm_set_debug(int d);
+/* 1: split-K launches that were given ticket counters (mlsd_gemm_args.sk_flags) add their K slices INSIDE the launch (the block that
+ * finishes a tile last sums the slabs in slice order and runs the epilogue: bit-identical to the two-launch form).  Default 0: the
+ * two-launch form measured faster on MI355X (profiles/r3_gemm_splitk_inline.txt) */
+void mlsd_gemm_set_splitk_inline(int on);
 size_t mlsd_gemm_streamk_ws_bytes(void);   /* workspace of a stream-K launch (slabs); the flags are 256 x 4 bytes, zeroed once */
 void mlsd_gemm_set_cus(int n);      /* CUs a persistent GEMM launch occupies (default 256; 128 for half-chip partitions) */
 void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */

@@ -353,6 +353,66 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
     __syncthreads();   // every wave is done with the ring: it becomes the epilogue's staging space
 
+    // ---- split-K reduced IN the launch (p.sk_L = number of K slices, gridDim.y): every block writes its partial accumulators to
+    // its slab (register order: 1 KiB per wave-instruction, write-through), then takes a ticket on the tile's counter; the block
+    // that draws the last ticket adds ALL slabs of the tile in slice order 0, 1, ... (its own included, re-read: the sum does not
+    // depend on which block came last -> bit-reproducible and equal to the two-launch form) and runs the epilogue.  Saves the
+    // second launch (~6 us on an SD1.5-sized problem, where it is a third of the GEMM) and its round trip through HBM.
+    if (p.sk_L > 1) {
+        const int nsl = p.sk_L;
+        constexpr int SLAB4 = BM * BN / 4;                                  // float4 per slab
+        f32x4* const base = reinterpret_cast<f32x4*>(p.sk_ws) + (long)blockIdx.x * nsl * SLAB4 + wave * (TM * TN * 4) * 64 + lane;
+        {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)blockIdx.y * SLAB4 - lane), 0, (TM * TN * 4) * 64 * 16, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((i * TN + j) * 4 + q) * 64 + lane) * 16, 0, 16);   // aux 16 = sc1: write-through
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const tick = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.sk_flag + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(nsl - 1);
+            if (last) __hip_atomic_store(p.sk_flag + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            *tick = last;
+        }
+        __syncthreads();
+        const int last = *tick;
+        __syncthreads();                                                    // (the epilogue's staging space starts at smem[0])
+        if (!last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // NB slabs in flight at a time (a slab = TM TN 4 wave-loads of 1 KiB; one at a time is a chain of exposed memory latencies)
+        constexpr int NR = TM * TN * 4, NB = NR <= 8 ? 4 : 2;
+        for (int z0 = 0; z0 < nsl; z0 += NB) {
+            f32x4 t[NB][NR];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (z0 + b < nsl) {
+                    const f32x4* src = base + (long)(z0 + b) * SLAB4;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) t[b][r] = src[r * 64];
+                }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (z0 + b < nsl) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = acc[r / (TN * 4)][(r / 4) % TN][4 * (r & 3) + e];
+                            acc[r / (TN * 4)][(r / 4) % TN][4 * (r & 3) + e] = (z0 + b == 0) ? t[b][r][e] : d + t[b][r][e];   // slice 0 starts the sum (as the two-launch form does)
+                        }
+                }
+        }
+    }
+
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
     float* const C32 = p.C32 ? p.C32 + (long)blockIdx.y * p.ws_stride : nullptr;
@@ -572,6 +632,10 @@ int g_gemm_dbg = 0;
 unsigned long long* g_gemm_tbuf = nullptr;   // device buffer of 8 stamps per block (mlsd_gemm_set_trace)
 int g_gemm_panel = 8;   // tile-order panel width in tiles (0: row-major)
 int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (default)  1: scalar epilogue
+// split-K reduced inside the launch (needs the caller's ticket counters).  OFF by default: measured SLOWER than the two-launch form on every
+// SD1.5-sized problem (profiles/r3_gemm_splitk_inline.txt: 512x1280x5120 k/6 25.2 -> 29.0 us, 128x1280x5120 k/8 16.9 -> 20.3 us): the block that
+// finishes a tile last reads all of the tile's slabs alone, at one CU's load bandwidth, where the second launch spreads the same bytes over the chip.
+int g_gemm_sk_inline = 0;
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, bool REG = false>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
@@ -598,7 +662,11 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     p.kt_per = nsplit > 1 ? kt_per : (a->K + BK - 1) / BK;
     p.ws_stride = 0;
     GemmP pe = p;                                  // the epilogue as requested (second pass of a split-K launch)
-    if (nsplit > 1) {
+    // reduced inside the launch: one counter per output tile (a->sk_flags, 4096 words, zero between launches), one slab per (tile, slice)
+    const bool inl = nsplit > 1 && g_gemm_sk_inline && a->sk_flags && (long)p.nbm * p.nbn <= 4096 && !((uintptr_t)a->ws & 15) &&
+                     a->ws_bytes >= (size_t)nsplit * p.nbm * p.nbn * BM * BN * sizeof(float);
+    if (inl) { p.sk_L = nsplit; p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags; }
+    else if (nsplit > 1) {
         const size_t need = (size_t)nsplit * a->M * a->N * sizeof(float);
         if (a->ws_bytes < need || ((uintptr_t)a->ws & 15))
             return mlsd_set_error(-1, "mlsd_gemm: split-K workspace too small or misaligned (%zu < %zu)", (size_t)a->ws_bytes, need);
@@ -614,7 +682,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     auto go = [&](auto kfn) -> int {
         if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
-        if (nsplit > 1) {
+        if (nsplit > 1 && !inl) {
             const long n = (long)a->M * (a->N >> 2);
             hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
         }
@@ -767,6 +835,9 @@ const Variant kVariants[] = {
     {"128x320x64pp2", 128, 320, 256},   // 20: variant 18 with TWO phases per K tile (20 MFMAs per barrier-to-barrier section instead of 8 / 12)
     {"256x256x64pp2", 256, 256, 256},   // 21: variant 17 with two phases per K tile (32 MFMAs per section)
     {"128x320x64ppb", 128, 320, 256},   // 22: variant 18 on the re-balanced staging schedule (gemm_pp.hpp SCH = 1)
+    {"64x128x64s3", 64, 128, 512},      // 23: variant 1 with a 3-deep ring (72 KB, 2 blocks/CU): two K tiles in flight per block for grids that leave CUs half empty
+    {"64x128x64r2", 64, 128, 768},      // 24: variant 1 register-staged (global_load -> ds_write): small grids are bound by the per-CU LDS-DMA issue rate
+    {"256x128x64pp2", 256, 128, 256},   // 25: ping-pong tile for NARROW outputs (N = 128: the VAE's full-resolution convolutions), wave 128 x 32, two phases per K tile (16 MFMAs per section)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -811,6 +882,10 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
     case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);
+    case 23: return launch<64, 128, 64, 2, 2, 3>(a, st);
+    case 24: return launch<64, 128, 64, 2, 2, 2, true>(a, st);
+    case 14: return launch<128, 128, 64, 2, 2, 2, true>(a, st);
+    case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
@@ -830,13 +905,13 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, false, 4, 1>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
+    case 25: return pp_eligible(a, 256, 128) ? launch_pp<256, 128, 1, 1, false, false, 2>(a, st) : launch<256, 128, 64, 4, 2, 2>(a, st);
     case 21: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false, false, 2>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
 #ifdef MLSD_GEMM_EXPERIMENTS   /* variants that lost the tile study on MI355X (kept reproducible, not built by default) */
     case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
-    case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
     case 6: return launch<256, 256, 32, 2, 4, 3>(a, st);
     case 7: return launch<256, 128, 32, 4, 2, 4>(a, st);
     case 8: return launch<256, 256, 32, 4, 4, 3>(a, st);
@@ -844,7 +919,6 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 11: return launch<256, 256, 64, 2, 4, 2>(a, st);
     case 12: return launch<256, 256, 32, 2, 4, 4>(a, st);
     case 13: return launch<256, 256, 64, 4, 4, 2, true>(a, st);
-    case 14: return launch<128, 128, 64, 2, 2, 2, true>(a, st);
     case 15: return launch<256, 128, 64, 4, 2, 2, true>(a, st);
 #endif
     default: return launch<128, 128, 64, 2, 2, 2>(a, st);
@@ -856,6 +930,7 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+MLSD_API void mlsd_gemm_set_splitk_inline(int on) { g_gemm_sk_inline = on != 0; }
 MLSD_API void mlsd_gemm_set_cus(int n) { g_gemm_ncu = n > 0 && n <= 256 ? n : 256; }
 /* diagnostics: device buffer of 8 x uint64 per block (256 blocks) that the ping-pong kernels fill with s_memtime stamps:
  * [0] kernel entry, [1] prologue done, [2] first epilogue begins, [3] first epilogue issued, [4] last epilogue begins,
@@ -864,7 +939,10 @@ MLSD_API void mlsd_gemm_set_trace(void* buf) { g_gemm_tbuf = (unsigned long long
 
 MLSD_API int mlsd_gemm_num_variants(void) { return kNumVariants; }
 
-MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
+MLSD_API size_t mlsd_gemm_splitk_ws_bytes(int M, int N, int ksplit)
+{   /* whole 128 x 128 tiles: the in-launch reduction keeps one slab per (tile, slice) */
+    return ksplit > 1 ? (size_t)ksplit * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * sizeof(float) : 0;
+}
 
 MLSD_API size_t mlsd_gemm_streamk_ws_bytes(void) { return (size_t)256 * 256 * 256 * sizeof(float); }
 
@@ -875,6 +953,7 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     int bm, bn;
     if ((v == 17 || v == 19 || v == 21) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
     else if ((v == 18 || v == 20 || v == 22) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+    else if (v == 25 && pp_eligible(a, 256, 128)) { bm = 256; bn = 128; }
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
     return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
@@ -887,8 +966,9 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
     if ((v == 18 || v == 20 || v == 22) && !pp_eligible(a, 128, 320)) v = 16;
+    if (v == 25 && !pp_eligible(a, 256, 128)) v = 3;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
-    const int ns = v >= 17 ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
+    const int ns = ((v >= 17 && v <= 22) || v == 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

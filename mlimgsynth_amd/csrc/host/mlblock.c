@@ -633,12 +633,14 @@ static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
 }
 
 #define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile */
+#define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile */
 static int streamk_get(MLCtx* C, mlsd_gemm_args* g)
-{	/* slabs in the split-K workspace (ops run one at a time on the plan's stream) + the plan's flag words */
+{	/* slabs in the split-K workspace (ops run one at a time on the plan's stream) + the plan's flag words (zero between launches:
+	 * the kernels that use them clear them again) */
 	if (splitk_ws_get(C, g)) return -1;
 	if (!C->sk_flags) {
-		if (mlsd_malloc((void**)&C->sk_flags, 4096)) return -1;
-		if (mlsd_memset(C->sk_flags, 0, 4096, C->stream) || mlsd_stream_sync(C->stream)) return -1;
+		if (mlsd_malloc((void**)&C->sk_flags, SK_FLAG_WORDS * 4)) return -1;
+		if (mlsd_memset(C->sk_flags, 0, SK_FLAG_WORDS * 4, C->stream) || mlsd_stream_sync(C->stream)) return -1;
 	}
 	g->sk_flags = C->sk_flags;
 	return 0;
@@ -653,7 +655,7 @@ static int select_gemm(MLCtx* C, MLOp* op)
 	if (tune_lookup(&k, &best, &ks)) {
 		g->tile_variant = best; g->ksplit = ks;
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
-		if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+		if (g->ksplit > 1 && streamk_get(C, g)) return -1;
 		if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
 		return 1;
 	}
@@ -686,7 +688,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		int best = 0, ks = 1;
 		if (tune_lookup(&k, &best, &ks)) {
 			g->tile_variant = best; g->ksplit = ks;
-			if (g->ksplit > 1 && splitk_ws_get(C, g)) return -1;
+			if (g->ksplit > 1 && streamk_get(C, g)) return -1;
 			if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
 			return 1;
 		}
@@ -736,7 +738,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	for (int c=0;c<nc;++c) {
 		g->tile_variant = cv[c] + 1; g->ksplit = cs[c];
 		float ms;
-		if ((cs[c] > 1 && splitk_ws_get(C, g)) || time_gemm(C, g, e0, e1, &ms)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
+		if ((cs[c] > 1 && streamk_get(C, g)) || time_gemm(C, g, e0, e1, &ms)) { mlsd_event_destroy(e0); mlsd_event_destroy(e1); return -1; }
 		/* candidates are listed in order of preference: a later one must win by 3 % (keeps the choice, and with
 		 * it the kernel mix of a profile, stable against timing noise between near-equal variants) */
 		if (ms < (c ? 0.97f : 1.f) * best_ms) { best_ms = ms; best = cv[c] + 1; best_s = cs[c]; }

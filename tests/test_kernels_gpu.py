@@ -463,7 +463,7 @@ def test_gemm_split_k(K, M, N, Kd, ksplit, variant, act, post):
     dA, dW, dB, dR = dev(_lib, A.astype(np.float16)), dev(_lib, W.astype(np.float16)), dev(_lib, bias), dev(_lib, res)
     dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
     nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
-    assert nws == ksplit * M * N * 4
+    assert nws == ksplit * (-(-M // 128) * 128) * (-(-N // 128) * 128) * 4        # whole 128 x 128 tiles (the in-launch reduction's slabs)
     ws = _lib.DeviceBuffer(nws)
     a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, resid=dR.ptr, ldr=N,
                          act=act, act_after_resid=post, C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N,
@@ -482,6 +482,53 @@ def test_gemm_split_k(K, M, N, Kd, ksplit, variant, act, post):
     if min(ksplit, (Kd + 63) // 64) > 1:
         with pytest.raises(_lib.MlsdError):
             kernels.gemm(a)
+
+
+@pytest.mark.parametrize("M,N,Kd,ksplit,variant,conv", [
+    (512, 1280, 1280, 3, 2, 0), (128, 1280, 5120, 8, 2, 0), (128, 1280, 5120, 8, 1, 0), (100, 264, 1096, 5, 2, 0), (2048, 640, 2560, 3, 1, 0),
+    (512, 1280, 11520, 6, 2, 1), (128, 320, 2880, 12, 1, 1), (130, 132, 72, 64, 1, 0)])
+def test_gemm_split_k_reduced_in_the_launch(K, M, N, Kd, ksplit, variant, conv):
+    """Split-K with ticket counters: the block that finishes a tile last adds the slices (slice order) and runs the epilogue.
+    Bit-identical to the two-launch form (same summation order, same epilogue arithmetic), launch after launch (the counters
+    clear themselves), ragged tiles included; one launch instead of two."""
+    kernels, _lib = K
+    L = _lib.lib()
+    rng = np.random.default_rng(M + N + Kd)
+    if conv:
+        cin = Kd // 9
+        hw = {512: (2, 16, 16), 128: (2, 8, 8)}[M]
+        A = f16r(rng.standard_normal((hw[0], hw[1], hw[2], cin))).astype(np.float16)
+    else:
+        A = f16r(rng.standard_normal((M, Kd))).astype(np.float16)
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    dB, dR = dev(_lib, rng.standard_normal(N).astype(np.float32)), dev(_lib, rng.standard_normal((M, N)).astype(np.float32))
+    dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
+    ws = _lib.DeviceBuffer(nws)
+    flags = dev(_lib, np.zeros(4096, np.uint32))
+    a = kernels.GemmArgs(A=dA.ptr, lda=cin if conv else Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, resid=dR.ptr, ldr=N, act=kernels.ACT_SILU,
+                         C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N, tile_variant=variant, ksplit=ksplit, ws=ws.ptr, ws_bytes=nws)
+    if conv:
+        a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, hw[0], hw[1], hw[2], cin, hw[1], hw[2], 3, 3, 1, 1
+    L.mlsd_gemm_set_splitk_inline(0)
+    kernels.gemm(a)                                  # no counters: two launches
+    ref32, ref16 = dC32.download((M, N), np.float32), dC16.download((M, N), np.float16)
+    assert np.isfinite(ref32).all()
+    a.sk_flags = flags.ptr
+    L.mlsd_gemm_set_splitk_inline(1)
+    try:
+        for rep in range(3):
+            L.mlsd_memset(_lib.vp(dC32.ptr), 0xff, ctypes.c_size_t(M * N * 4), None)
+            L.mlsd_memset(_lib.vp(dC16.ptr), 0xff, ctypes.c_size_t(M * N * 2), None)
+            kernels.gemm(a)
+            assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32)), rep
+            assert np.array_equal(dC16.download((M, N), np.float16).view(np.uint16), ref16.view(np.uint16)), rep
+            assert not flags.download((4096,), np.uint32).any()          # the counters are zero again
+    finally:
+        L.mlsd_gemm_set_splitk_inline(0)                 # (the default: two launches even with counters)
+    kernels.gemm(a)
+    assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32))
 
 
 def test_conv2d_split_k(K):

@@ -10,7 +10,8 @@ ev = [vp(), vp()]
 for e in ev: L.mlsd_event_create(ctypes.byref(e))
 rng = np.random.default_rng(0)
 ws = _lib.DeviceBuffer(128 << 20)
-VARIANTS = (1, 0)          # 64x128x64s2, 128x128x64s2
+flags = _lib.from_numpy(np.zeros(4096, np.uint32)) if os.environ.get('INLINE', '1') == '1' else None    # ticket counters: slices added in the launch
+VARIANTS = tuple(int(v) for v in os.environ.get('VARIANTS', '1,0').split(','))          # 1: 64x128x64s2, 0: 128x128x64s2, 23 / 5: their 3-deep rings
 SHAPES = [(512, 1280, 1280), (2048, 640, 640), (8192, 320, 320), (512, 1280, 5120), (2048, 640, 2560), (128, 1280, 1280), (512, 3840, 1280),
           (2048, 1920, 640), (8192, 960, 320), (8192, 320, 1280), (128, 1280, 5120), (512, 1280, 11520), (128, 1280, 11520), (2048, 640, 5760), (8192, 320, 2880)]
 for (M, N, K) in SHAPES:
@@ -18,11 +19,12 @@ for (M, N, K) in SHAPES:
     R = _lib.from_numpy(rng.standard_normal((M, N)).astype(np.float32)); C = _lib.DeviceBuffer(M * N * 4)
     res = []
     for v in VARIANTS:
-        for ks in (1, 2, 3, 4, 6, 8, 12):
+        for ks in (1, 2, 3, 4, 6, 8, 12, 16):
             nkt = K // 64
-            if ks > 1 and (nkt // ks < 2 or ks * M * N * 4 > (128 << 20)): continue
+            if ks > 1 and (nkt // ks < 2 or kernels.gemm_splitk_ws_bytes(M, N, ks) > (128 << 20)): continue
             a = kernels.GemmArgs(A=A.ptr, lda=K, W_=W.ptr, ldb=K, M=M, N=N, K=K, resid=R.ptr, ldr=N, C32=C.ptr, ldc32=N, tile_variant=v + 1, ksplit=ks,
                                  ws=ws.ptr, ws_bytes=128 << 20)
+            if flags is not None: a.sk_flags = flags.ptr
             for _ in range(3): kernels.gemm(a)
             L.mlsd_event_record(ev[0], None)
             for _ in range(reps): kernels.gemm(a)
