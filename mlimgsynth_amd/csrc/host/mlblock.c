@@ -707,6 +707,9 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
 		}
 		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; cv[nc]=20; cs[nc++]=1; }   /* four / two phases per K tile */
+		/* (the narrow 256x128 ping-pong tile, variant 25, is NOT a candidate: it wins this warm, back-to-back timing on the VAE's N = 128
+		 * convolutions (+9..16 %) and loses in the plan (-16 %, profiles/r3_gemm_narrow_tile.txt): those launches are bound by their fp32
+		 * output + residual traffic, which two co-resident blocks overlap with each other's K loops and one persistent block cannot) */
 		cv[nc]=9; cs[nc++]=1; cv[nc]=3; cs[nc++]=1; cv[nc]=4; cs[nc++]=1; cv[nc]=0; cs[nc++]=1;
 	}
 	const long t128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128);

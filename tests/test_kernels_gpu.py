@@ -208,8 +208,9 @@ PP_SHAPES = [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768,
              (4352, 19968, 256), (640, 1984, 256), (1152, 320, 448), (32768, 640, 640), (131072, 320, 320), (192, 960, 1280)]
 # the ping-pong tiles take whole wave blocks (128x64 of the 256x256 tile / 64x80 of the 128x320 tile): only those combinations are cases
 # 20 / 21: the same tiles with two phases per K tile instead of four (other staging schedule and counted waits: a sync structure of its own)
-PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21, 22) for (M, N, Kd) in PP_SHAPES
-            if not ((pp in (18, 20, 22) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)))]
+# 25: the narrow 256x128 tile (wave 128x32), two phases
+PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21, 22, 25) for (M, N, Kd) in PP_SHAPES + [(65536, 128, 1152), (1152, 32, 448), (8192, 96, 256)]
+            if not ((pp in (18, 20, 22) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)) or (pp == 25 and (N % 32 or M % 128 or N > 1984)))]
 
 
 @pytest.mark.parametrize("pp,M,N,Kd", PP_CASES)
@@ -320,8 +321,8 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
-@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
-                                     if not (pp in (18, 20, 22) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
+@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22, 25) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
+                                     if not (pp in (18, 20, 22, 25) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
@@ -376,7 +377,7 @@ def test_gemm_pingpong_epilogues(K, mode, pp):
     assert rel(dC16.download((M, nout), np.float16).astype(np.float32), ref) < 1e-3
 
 
-@pytest.mark.parametrize("pp", [17, 18, 20, 21, 22])
+@pytest.mark.parametrize("pp", [17, 18, 20, 21, 22, 25])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 16, 16, 64, 320, 3, 1), (1, 32, 32, 128, 640, 3, 2), (2, 16, 8, 192, 320, 1, 1),
                                                  (4, 32, 32, 64, 1280, 3, 1)])
 def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
@@ -395,7 +396,7 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
     M = n * oh * ow
     rowb = rng.standard_normal((n, cout)).astype(np.float32)
     res = rng.standard_normal((M, cout)).astype(np.float32)
-    use_rb = (oh * ow) % (256 if pp in (17, 21) else 128) == 0
+    use_rb = (oh * ow) % (256 if pp in (17, 21, 25) else 128) == 0
     ref = ref + (rowb[:, :, None, None] if use_rb else 0) + res.reshape(n, oh, ow, cout).transpose(0, 3, 1, 2)
     dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
     dW, dB, dRB, dR = dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias), dev(_lib, rowb), dev(_lib, res)
@@ -403,7 +404,7 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
     a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=oh, OW=ow, KH=k, KW=k, stride=s, pad=pad,
                          W_=dW.ptr, ldb=k * k * cin, M=M, N=cout, K=k * k * cin, bias=dB.ptr, rowbias=dRB.ptr if use_rb else None,
                          rows_per_batch=oh * ow, ldrb=cout, resid=dR.ptr, ldr=cout, C32=dC.ptr, ldc32=cout, tile_variant=pp + 1)
-    if (M % (128 if pp in (17, 21) else 64)) or (cout % (64 if pp in (17, 21) else 80)) or k * k * cin < 192:
+    if (M % (128 if pp in (17, 21, 25) else 64)) or (cout % ({17: 64, 21: 64, 25: 32}.get(pp, 80))) or k * k * cin < 192:
         pytest.skip("not made of whole wave blocks for this tile")
     assert "pp" in kernels.gemm_variant(a)
     for rep in range(3):
@@ -921,7 +922,7 @@ def oracle_key(name, seed):
 
 
 @pytest.mark.parametrize("pp,conv,res", [(17, False, False), (17, False, True), (18, False, True), (18, True, False), (17, True, True), (18, False, False),
-                                          (20, False, True), (20, True, False), (21, True, True)])
+                                          (20, False, True), (20, True, False), (21, True, True), (25, True, True), (25, False, False)])
 def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     """mlsd_gemm_args.colstats: the ping-pong kernels built with a *_STATS epilogue also write, per block of
     mlsd_gemm_colstats_rows() rows and per column, the sum and the sum of squares of the fp32 output they store (the first
@@ -958,7 +959,7 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a0)) == 0
     kernels.gemm(a0)
     plain = dC0.download((M, N), np.float32)
-    rows = 128 if pp in (17, 21) else 64
+    rows = 128 if pp in (17, 21, 25) else 64
     dS = _lib.DeviceBuffer(M // rows * 2 * N * 4)
     a1 = args(dC, dS)
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a1)) == rows
