@@ -882,10 +882,6 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
     case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);
-    case 23: return launch<64, 128, 64, 2, 2, 3>(a, st);
-    case 24: return launch<64, 128, 64, 2, 2, 2, true>(a, st);
-    case 14: return launch<128, 128, 64, 2, 2, 2, true>(a, st);
-    case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
@@ -912,6 +908,10 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         return launch<128, 320, 64, 4, 2, 2>(a, st);
 #ifdef MLSD_GEMM_EXPERIMENTS   /* variants that lost the tile study on MI355X (kept reproducible, not built by default) */
     case 2: return launch<128, 128, 32, 2, 2, 4>(a, st);
+    case 5: return launch<128, 128, 64, 2, 2, 3>(a, st);
+    case 14: return launch<128, 128, 64, 2, 2, 2, true>(a, st);
+    case 23: return launch<64, 128, 64, 2, 2, 3>(a, st);      /* round 3 small-M study (profiles/r3_gemm_smallm_rings.txt): no gain */
+    case 24: return launch<64, 128, 64, 2, 2, 2, true>(a, st);
     case 6: return launch<256, 256, 32, 2, 4, 3>(a, st);
     case 7: return launch<256, 128, 32, 4, 2, 4>(a, st);
     case 8: return launch<256, 256, 32, 4, 4, 3>(a, st);
