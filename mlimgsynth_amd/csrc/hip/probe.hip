@@ -80,6 +80,58 @@ __global__ void probe_copy_f32(const float4* __restrict__ src, float4* __restric
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+
+// ---- operand-fill probe (round 3): how many bytes per clock a CU can pull from L2 / MALL when it does nothing else.
+// One 512-thread block per CU (128 KB of LDS requested so that two cannot share one); every thread issues 8 16-byte loads per
+// trip (64 KB per block and trip, the size of a 256x256x64 GEMM stage), rows of 128 bytes at stride `row_stride` bytes like a GEMM operand
+// panel; trip t of block b starts at row ((b * span_rows / nblocks) + t * 512) % span_rows of its XCD-shared panel, so `span_rows`
+// sets the working set (small: L2 hits; large: MALL / HBM).  mode 0: global_load_lds_dwordx4 (LDS-DMA); 1: global_load_dwordx4
+// into registers (consumed by an xor); 2: registers + ds_write_b128.
+template <int MODE>
+__global__ __launch_bounds__(512) void probe_fill_kernel(const unsigned char* __restrict__ src, long row_stride, int span_rows, int trips,
+                                                         unsigned long long* __restrict__ clocks, unsigned* __restrict__ sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = (int)((long)blockIdx.x * span_rows / gridDim.x);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < trips; ++t) {
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // wave-instruction = 8 rows x 128 bytes (lane l -> row l >> 3, chunk l & 7), like the GEMM staging
+            int row = r0 + t * 512 + (i * 8 + wave) * 8 + (lane >> 3);
+            row %= span_rows;
+            const unsigned char* p = src + (long)row * row_stride + (lane & 7) * 16;
+            if constexpr (MODE == 0) {
+                unsigned char* dst = smem + ((t & 1) * 65536) + (i * 8 + wave) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else {
+                v[i] = *reinterpret_cast<const uint4*>(p);
+            }
+        }
+        if constexpr (MODE == 0) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the previous trip's 8 loads have landed; this trip's stay in flight
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc.x ^= v[i].x; acc.y ^= v[i].y; acc.z ^= v[i].z; acc.w ^= v[i].w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<uint4*>(smem + ((t & 1) * 65536) + (i * 8 + wave) * 1024 + lane * 16) = v[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) clocks[blockIdx.x] = t1 - t0;
+    if (MODE != 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
+    if (MODE != 1 && smem[tid * 16] == 0x5a && smem[65536 + tid] == 0xa5) sink[1] = 1;
+}
+
 extern "C" {
 
 MLSD_API int mlsd_probe_mfma_raw(const void* A, const void* B, void* Craw, void* stream)
@@ -108,6 +160,20 @@ MLSD_API int mlsd_probe_copy(const void* src, void* dst, size_t nbytes, void* st
     hipLaunchKernelGGL(probe_copy_f32, dim3(2048), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (float4*)dst, nbytes / 16);
     return mlsd_check_launch("probe_copy");
+}
+
+/* operand-fill probe: nblocks x 512 threads, `trips` trips of 64 KB per block; clocks[nblocks] = s_memtime clocks of each block's loop */
+MLSD_API int mlsd_probe_fill(int mode, const void* src, long row_stride, int span_rows, int trips, int nblocks, void* clocks, void* sink, void* stream)
+{
+    if (mode < 0 || mode > 2 || span_rows < 512 || nblocks < 1) return mlsd_set_error(-1, "mlsd_probe_fill: bad arguments");
+    const size_t lds = 131072;
+    auto go = [&](auto k) -> int {
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(nblocks), dim3(512), lds, (hipStream_t)stream, (const unsigned char*)src, row_stride, span_rows, trips,
+                           (unsigned long long*)clocks, (unsigned*)sink);
+        return mlsd_check_launch("probe_fill");
+    };
+    return mode == 0 ? go(probe_fill_kernel<0>) : mode == 1 ? go(probe_fill_kernel<1>) : go(probe_fill_kernel<2>);
 }
 
 }  // extern "C"
