@@ -809,6 +809,8 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
+extern "C" int mlsd_gemm_w4_eligible(const mlsd_gemm_args* a, int tile);    // gemm_w4.hip (tile 0: 256 x 256, 1: 128 x 320)
+extern "C" int mlsd_gemm_w4(const mlsd_gemm_args* a, int tile, void* stream, int ncu);
 
 struct Variant { const char* name; int bm, bn, slots; };
 const Variant kVariants[] = {
@@ -838,6 +840,8 @@ const Variant kVariants[] = {
     {"64x128x64s3", 64, 128, 512},      // 23: variant 1 with a 3-deep ring (72 KB, 2 blocks/CU): two K tiles in flight per block for grids that leave CUs half empty
     {"64x128x64r2", 64, 128, 768},      // 24: variant 1 register-staged (global_load -> ds_write): small grids are bound by the per-CU LDS-DMA issue rate
     {"256x128x64pp2", 256, 128, 256},   // 25: ping-pong tile for NARROW outputs (N = 128: the VAE's full-resolution convolutions), wave 128 x 32, two phases per K tile (16 MFMAs per section)
+    {"256x256x64w4", 256, 256, 256},    // 26: ONE wave per SIMD (4 waves of 128 x 128, accumulators in AGPRs, software-pipelined inside the wave): gemm_w4.hip
+    {"128x320x64w4", 128, 320, 256},    // 27: the same on the 128 x 320 tile (4 waves of 64 x 160)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -885,6 +889,14 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 3: return launch<256, 128, 64, 4, 2, 2>(a, st);
     case 4: return launch<256, 128, 32, 4, 2, 3>(a, st);
     case 9: return launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 27:
+        if (mlsd_gemm_w4_eligible(a, 1)) return mlsd_gemm_w4(a, 1, st, g_gemm_ncu);
+        if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);      // anything else: the ping-pong tile of the same shape
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
+    case 26:
+        if (mlsd_gemm_w4_eligible(a, 0)) return mlsd_gemm_w4(a, 0, st, g_gemm_ncu);
+        [[fallthrough]];                                                    // anything else: the ping-pong tile of the same shape
     case 17: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 19:
         if (sk_eligible(a, 256, 256)) return launch_pp<256, 256, 2, 2, false, true>(a, st);
@@ -951,8 +963,8 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     if (!a || !a->colstats) return 0;
     const int v = pick_variant(a);
     int bm, bn;
-    if ((v == 17 || v == 19 || v == 21) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }
-    else if ((v == 18 || v == 20 || v == 22) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+    if ((v == 17 || v == 19 || v == 21 || v == 26) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }   // (26 never takes a launch that has colstats set: it runs as 17)
+    else if ((v == 18 || v == 20 || v == 22 || v == 27) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
     else if (v == 25 && pp_eligible(a, 256, 128)) { bm = 256; bn = 128; }
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
@@ -964,11 +976,13 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     static thread_local char buf[64];
     int v = pick_variant(a);
     if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
+    if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
+    if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
     if ((v == 18 || v == 20 || v == 22) && !pp_eligible(a, 128, 320)) v = 16;
     if (v == 25 && !pp_eligible(a, 256, 128)) v = 3;
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
-    const int ns = ((v >= 17 && v <= 22) || v == 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
+    const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

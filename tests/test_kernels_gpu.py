@@ -209,8 +209,10 @@ PP_SHAPES = [(2048, 1024, 4096), (256, 256, 192), (8192, 1280, 1280), (512, 768,
 # the ping-pong tiles take whole wave blocks (128x64 of the 256x256 tile / 64x80 of the 128x320 tile): only those combinations are cases
 # 20 / 21: the same tiles with two phases per K tile instead of four (other staging schedule and counted waits: a sync structure of its own)
 # 25: the narrow 256x128 tile (wave 128x32), two phases
-PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21, 22, 25) for (M, N, Kd) in PP_SHAPES + [(65536, 128, 1152), (1152, 32, 448), (8192, 96, 256)]
-            if not ((pp in (18, 20, 22) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)) or (pp == 25 and (N % 32 or M % 128 or N > 1984)))]
+# 26 / 27: one wave per SIMD (gemm_w4.hip), 256x256 (wave 128x128) and 128x320 (wave 64x160)
+PP_CASES = [(pp, M, N, Kd) for pp in (17, 18, 20, 21, 22, 25, 26, 27) for (M, N, Kd) in PP_SHAPES + [(65536, 128, 1152), (1152, 32, 448), (8192, 96, 256), (384, 640, 192), (8192, 1280, 5120)]
+            if not ((pp in (18, 20, 22) and (N % 80 or M % 64)) or (pp in (17, 21) and (N % 64 or M % 128)) or (pp == 25 and (N % 32 or M % 128 or N > 1984))
+                    or (pp == 26 and (N % 128 or M % 128)) or (pp == 27 and (N % 160 or M % 64)))]
 
 
 @pytest.mark.parametrize("pp,M,N,Kd", PP_CASES)
@@ -229,7 +231,7 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
     ref = d9.download((M, N), np.float32)
     exact = A.astype(np.float32) @ W.astype(np.float32).T
     assert rel(ref, exact) < 2e-5
-    assert "pp" in kernels.gemm_variant(mk(d17, pp))
+    assert ("w4" if pp >= 26 else "pp") in kernels.gemm_variant(mk(d17, pp))
     for rep in range(6):
         kernels.gemm(mk(d17, pp))
         got = d17.download((M, N), np.float32)
@@ -321,14 +323,14 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
-@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22, 25) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
-                                     if not (pp in (18, 20, 22, 25) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
+@pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22, 25, 26, 27) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
+                                     if not (pp in (18, 20, 22, 25, 27) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
     """Register-direct epilogue of the ping-pong tile (transposed accumulators, one activation formula) against the
     oracle linear + the graph's epilogue terms; 6 x 3 tiles per launch on < 256 blocks, so no block walks > 1 tile
     here -- the multi-tile stream is covered by test_gemm_pingpong_tile_matches_plain_tile."""
     kernels, _lib = K
-    M, N, Kd = (1536, 768, 448) if pp in (17, 21) else (1536, 960, 448)
+    M, N, Kd = (1536, 768, 448) if pp in (17, 21, 26) else (1536, 960, 448)
     rng = np.random.default_rng(len(mode))
     A = f16r(rng.standard_normal((M, Kd)))
     W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd))
@@ -979,7 +981,50 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
 
 
-@pytest.mark.parametrize("pp,geglu", [(17, False), (18, False), (17, True), (20, False), (21, True)])
+@pytest.mark.parametrize("w4,kind,M,N,Kd", [
+    (26, "f16", 4096, 5120, 320), (26, "geglu", 4096, 5120, 320), (26, "f32", 384, 640, 192), (26, "f32res", 4352, 4992, 192), (26, "f32res", 8192, 1280, 1280),
+    (27, "f16", 8192, 1280, 1280), (27, "f32", 192, 480, 192), (27, "f32res", 8192, 1280, 5120), (27, "f32res", 16448, 2080, 256), (27, "f16", 4160, 4960, 192)])
+def test_gemm_one_wave_per_simd_tiles(K, w4, kind, M, N, Kd):
+    """gemm_w4.hip (tile variants 26 / 27: four waves of 128x128 / 64x160, accumulators in AGPRs, software-pipelined inside the wave) against the
+    ping-pong tile of the same shape: same MFMA order -> bit-identical, on every epilogue it has, launches of more tiles than CUs (per-tile
+    prologue + the counted waits that leave the previous epilogue's stores in flight), ragged tiles, repeated (races would show as rare wrong tiles)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(M + N + Kd + w4)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dR = dev(_lib, rng.standard_normal((M, N)).astype(np.float32))
+    nout = N // 2 if kind == "geglu" else N
+    esz = 2 if kind in ("f16", "geglu") else 4
+    d0, d1 = _lib.DeviceBuffer(M * nout * esz), _lib.DeviceBuffer(M * nout * esz)
+
+    def mk(dst, v):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=v + 1)
+        if esz == 2: a.C16, a.ldc16 = dst.ptr, nout
+        else: a.C32, a.ldc32 = dst.ptr, nout
+        if kind == "geglu": a.act = kernels.ACT_GEGLU
+        if kind == "f32res": a.resid, a.ldr = dR.ptr, N
+        return a
+    ref_v = 17 if w4 == 26 else 18
+    assert "w4" in kernels.gemm_variant(mk(d1, w4))
+    same_order = "pp" in kernels.gemm_variant(mk(d0, ref_v))
+    assert same_order
+    kernels.gemm(mk(d0, ref_v))
+    dt = np.uint16 if esz == 2 else np.uint32
+    ref = d0.download((M, nout), dt)
+    y = A.astype(np.float32) @ W.astype(np.float32).T
+    if kind in ("f32", "f32res"):
+        exact = y + dB.download((N,), np.float32) + (dR.download((M, N), np.float32) if kind == "f32res" else 0)
+        assert rel(ref.view(np.float32), exact) < 2e-5
+    for rep in range(4):
+        _lib.check(_lib.lib().mlsd_memset(_lib.vp(d1.ptr), 0xff, ctypes.c_size_t(M * nout * esz), None))
+        kernels.gemm(mk(d1, w4))
+        got = d1.download((M, nout), dt)
+        if same_order: assert np.array_equal(got, ref), rep
+        else: assert rel(got.view(np.float32), exact) < 2e-5, rep
+
+
+@pytest.mark.parametrize("pp,geglu", [(17, False), (18, False), (17, True), (20, False), (21, True), (26, False), (26, True), (27, False)])
 @pytest.mark.parametrize("misalign", ["none", "base+8B", "ld%8=4"])
 def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
     """The fp16 fast epilogues store 16 bytes per lane (v_permlane16_swap pairs of column blocks): they need 16-byte aligned
@@ -989,7 +1034,7 @@ def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
     L, vp = _lib.lib(), _lib.vp
     rng = np.random.default_rng(pp + geglu)
     M, Kd = 512, 256
-    N = 1024 if pp in (17, 21) else 960
+    N = 1024 if pp in (17, 21, 26) else 960
     nout = N // 2 if geglu else N
     A = rng.standard_normal((M, Kd)).astype(np.float16)
     W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
@@ -1001,7 +1046,7 @@ def test_gemm_pingpong_fp16_store_width_and_alignment(K, pp, geglu, misalign):
     _lib.check(L.mlsd_memset(vp(buf.ptr), 0x7C, ctypes.c_size_t(buf.nbytes), None))     # 0x7C7C = a large fp16 sentinel
     a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C16=buf.ptr + 2 * off, ldc16=ld,
                          act=kernels.ACT_GEGLU if geglu else kernels.ACT_NONE, tile_variant=pp + 1)
-    assert "pp" in kernels.gemm_variant(a)
+    assert ("pp" in kernels.gemm_variant(a)) or ("w4" in kernels.gemm_variant(a) and misalign == "none")
     kernels.gemm(a)
     raw = buf.download((M * ld + 16,), np.float16)
     got = raw[off:off + M * ld].reshape(M, ld)
