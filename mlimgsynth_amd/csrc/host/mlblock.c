@@ -679,22 +679,10 @@ static int time_gemm(MLCtx* C, mlsd_gemm_args* g, void* e0, void* e1, float* ms_
 	return 0;
 }
 
-/* offline timing mode (tools/tune_all.py): called for shapes the table does not hold */
-static int tune_gemm(MLCtx* C, MLOp* op)
+/* candidates of one GEMM: (tile variant, K slices), in order of preference; returns their number (<= 32) */
+static int gemm_candidates(MLCtx* C, mlsd_gemm_args* g, int cv[32], int cs[32])
 {
-	mlsd_gemm_args *g = &op->u.gemm;
-	TuneKey k = tune_key(g);
-	{
-		int best = 0, ks = 1;
-		if (tune_lookup(&k, &best, &ks)) {
-			g->tile_variant = best; g->ksplit = ks;
-			if (g->ksplit > 1 && streamk_get(C, g)) return -1;
-			if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
-			return 1;
-		}
-	}
-	/* candidates: (tile variant, K slices) */
-	int cv[32], cs[32], nc = 0;
+	int nc = 0;
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
 		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
@@ -735,6 +723,26 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 			}
 		}
 	}
+	return nc;
+}
+
+/* offline timing mode (tools/tune_all.py): called for shapes the table does not hold */
+static int tune_gemm(MLCtx* C, MLOp* op)
+{
+	mlsd_gemm_args *g = &op->u.gemm;
+	TuneKey k = tune_key(g);
+	{
+		int best = 0, ks = 1;
+		if (tune_lookup(&k, &best, &ks)) {
+			g->tile_variant = best; g->ksplit = ks;
+			if (g->ksplit > 1 && streamk_get(C, g)) return -1;
+			if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
+			return 1;
+		}
+	}
+	/* candidates: (tile variant, K slices) */
+	int cv[32], cs[32];
+	const int nc = gemm_candidates(C, g, cv, cs);
 	void *e0 = NULL, *e1 = NULL;
 	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
 	float best_ms = 1e30f; int best = 0, best_s = 1;
@@ -755,6 +763,89 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 	return 1;
 }
 
+
+/* IN-PLAN tile tuning (round 3; tools/tune_inplan.py).  tune_gemm() above times a candidate back to back on warm operands; in the plan a launch
+ * meets cold weights, a residual that comes from HBM and whatever clock the previous launches left, and round 3 measured tiles that win the
+ * warm timing by 7-16 % and lose in the plan (profiles/r3_gemm_narrow_tile.txt, r3_gemm_w4.txt).  This pass times the candidates WHERE THEY RUN:
+ * round r puts candidate r of every GEMM shape into all launches of that shape and times the whole plan op by op (HIP events, `reps` passes, the
+ * smallest per-shape sum counts); a challenger replaces the current choice of a shape when it wins by 3 %.  Launches whose column statistics a
+ * GroupNorm was wired to keep their tile.  Winners go to the process table (mlsd_tune_dump writes them).  Returns the number of shapes changed. */
+MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
+{
+	if (!C->prepared) return mlctx_fail(C, "mlctx_tune_inplan before mlctx_prep");
+	enum { MAXS = 256 };
+	typedef struct { TuneKey k; int cv[33], cs[33], nc; double t[33]; } Shape;
+	Shape *sh = calloc(MAXS, sizeof(Shape));
+	int *op_shape = malloc(sizeof(int) * (size_t)C->n_ops);
+	float *ms = malloc(sizeof(float) * (size_t)C->n_ops);
+	if (!sh || !op_shape || !ms) { free(sh); free(op_shape); free(ms); return -1; }
+	int ns = 0, maxnc = 0, changed = -1;
+	for (int i=0;i<C->n_ops;++i) {
+		op_shape[i] = -1;
+		MLOp *op = &C->ops[i];
+		if (op->kind != OP_GEMM || op->u.gemm.colstats) continue;
+		mlsd_gemm_args *g = &op->u.gemm;
+		const TuneKey k = tune_key(g);
+		int j = 0;
+		for (; j<ns; ++j) if (!memcmp(&sh[j].k, &k, offsetof(TuneKey, best))) break;
+		if (j == ns) {
+			if (ns == MAXS) continue;
+			sh[j].k = k;
+			sh[j].cv[0] = g->tile_variant - 1; sh[j].cs[0] = g->ksplit > 0 ? g->ksplit : 1;     /* candidate 0: the current choice (-1: the static rule) */
+			int cv[32], cs[32];
+			const int nc = gemm_candidates(C, g, cv, cs);
+			sh[j].nc = 1;
+			for (int c=0;c<nc;++c) if (cv[c] != sh[j].cv[0] || cs[c] != sh[j].cs[0]) { sh[j].cv[sh[j].nc] = cv[c]; sh[j].cs[sh[j].nc] = cs[c]; sh[j].nc++; }
+			if (sh[j].nc > maxnc) maxnc = sh[j].nc;
+			++ns;
+		}
+		op_shape[i] = j;
+	}
+	for (int r=0; r<maxnc; ++r) {
+		for (int i=0;i<C->n_ops;++i) {
+			const int j = op_shape[i];
+			if (j < 0) continue;
+			const int c = r < sh[j].nc ? r : 0;
+			mlsd_gemm_args *g = &C->ops[i].u.gemm;
+			g->tile_variant = sh[j].cv[c] + 1; g->ksplit = sh[j].cs[c];
+			if ((g->ksplit > 1 || g->tile_variant == VARIANT_STREAMK) && streamk_get(C, g)) goto done;
+		}
+		for (int j=0;j<ns;++j) if (r < sh[j].nc) sh[j].t[r] = 1e30;
+		for (int rep=0; rep<reps+1; ++rep) {             /* (the first pass warms the instruction caches of this round's kernels) */
+			if (mlctx_profile_ops(C, ms, C->n_ops) < 0) goto done;
+			if (!rep) continue;
+			double sum[MAXS] = {0};
+			for (int i=0;i<C->n_ops;++i) if (op_shape[i] >= 0) sum[op_shape[i]] += ms[i];
+			for (int j=0;j<ns;++j) if (r < sh[j].nc && sum[j] < sh[j].t[r]) sh[j].t[r] = sum[j];
+		}
+	}
+	changed = 0;
+	for (int j=0;j<ns;++j) {
+		int best = 0;
+		for (int c=1;c<sh[j].nc;++c) if (sh[j].t[c] < 0.97 * sh[j].t[0] && sh[j].t[c] < sh[j].t[best]) best = c;
+		sh[j].k.best = sh[j].cv[best] + 1; sh[j].k.ksplit = sh[j].cs[best];
+		if (best) {
+			++changed;
+			pthread_mutex_lock(&g_tune_mu);
+			int q = 0;
+			for (; q<g_ntune; ++q) if (!memcmp(&g_tune[q], &sh[j].k, offsetof(TuneKey, best))) break;
+			if (q < 1024) { g_tune[q] = sh[j].k; if (q == g_ntune) ++g_ntune; }
+			pthread_mutex_unlock(&g_tune_mu);
+			fprintf(stderr, "[tune_inplan] %s M=%d N=%d K=%d out=%d: variant %d k/%d %.3f ms -> variant %d k/%d %.3f ms per evaluation\n", sh[j].k.conv ? "conv" : "linear",
+				sh[j].k.M, sh[j].k.N, sh[j].k.K, sh[j].k.out, sh[j].cv[0], sh[j].cs[0], sh[j].t[0], sh[j].cv[best], sh[j].cs[best], sh[j].t[best]);
+		}
+	}
+	for (int i=0;i<C->n_ops;++i) {
+		const int j = op_shape[i];
+		if (j < 0) continue;
+		mlsd_gemm_args *g = &C->ops[i].u.gemm;
+		g->tile_variant = sh[j].k.best; g->ksplit = sh[j].k.ksplit;
+		if ((g->ksplit > 1 || g->tile_variant == VARIANT_STREAMK) && streamk_get(C, g)) { changed = -1; break; }
+	}
+done:
+	free(sh); free(op_shape); free(ms);
+	return changed;
+}
 
 /* GroupNorm statistics from the producers: when every source of a GroupNorm is the fp32 output of a
  * ping-pong GEMM / conv launch that can emit column statistics (mlsd_gemm_colstats_rows > 0: fp32 output, no activation),
