@@ -727,13 +727,24 @@ int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 // launcher of the ping-pong kernels (gemm_pp.hpp): same argument handling as launch<>
 // stream-K needs: the ping-pong conditions, a workspace of one fp32 slab per block + a zeroed flag word per block (cleared again by
 // their consumers), at least 4 K-tile units per block and a tile count the blocks do not divide (otherwise nothing is gained)
+// K tiles per stream-K block.  The even share ceil(units / blocks) would cut every output tile at different K positions, so the fp32 summation
+// order of a row would depend on which tile it lands in -- and an image's bits on its batch slot (tests/test_determinism_gpu.py).  The share is
+// therefore rounded UP to a divisor of the tile's K-tile count: every tile is cut at the same positions (a split-K whose slices are dealt over the
+// persistent blocks), at the price of some idle blocks (96 tiles x 90 K tiles on 256 blocks: 45 per block = 192 busy blocks instead of 34 on all).
+int sk_share(long ntiles, int nkt, int ncu)
+{
+    const long even = (ntiles * nkt + ncu - 1) / ncu;
+    for (int L = (int)(even < 4 ? 4 : even); L < nkt; ++L) if (nkt % L == 0) return L;      // (>= 4 K tiles per block)
+    return nkt;
+}
+
 bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
     if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15)) return false;
     if (a->conv && a->colstats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
     const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
-    const long L = (tiles * nkt + g_gemm_ncu - 1) / g_gemm_ncu;
-    return nkt >= 3 && L >= 4 && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);
+    const long L = sk_share(tiles, (int)nkt, g_gemm_ncu);
+    return nkt >= 3 && L >= 4 && L < nkt && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);    // (L == nkt: nothing to split)
 }
 
 template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool SK = false, int NPH = 4, int SCH = 0>
@@ -756,7 +767,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     const int ntiles = p.nbm * p.nbn;
     p.sk_L = 0; p.sk_ws = nullptr; p.sk_flag = nullptr;
     if constexpr (SK) {
-        p.sk_L = (int)(((long)ntiles * (a->K / BK) + g_gemm_ncu - 1) / g_gemm_ncu);
+        p.sk_L = sk_share(ntiles, a->K / BK, g_gemm_ncu);
         p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags;
     }
     const dim3 grid(SK ? g_gemm_ncu : (ntiles < g_gemm_ncu ? ntiles : g_gemm_ncu)), block(512);   // persistent: one block per CU walks tiles b, b+G, ... (stream-K: K-tile units)

@@ -239,15 +239,15 @@ def test_gemm_pingpong_tile_matches_plain_tile(K, M, N, Kd, pp):
         assert np.abs(got - ref).max() < 1e-3, rep
 
 
-SK_CASES = [(8192, 1280, 1280, 0), (8192, 1280, 5120, 1), (2560, 768, 4096, 0), (8192, 3840, 1280, 2), (1280, 1024, 8192, 1), (33024, 256, 512, 0), (512, 512, 16384, 3)]
+SK_CASES = [(4096, 1280, 1280, 0), (4096, 1280, 5120, 1), (2560, 768, 4096, 0), (2048, 3840, 1280, 2), (1280, 1024, 8192, 1), (16384, 256, 512, 0), (512, 512, 16384, 3)]
 
 
 @pytest.mark.parametrize("M,N,Kd,mode", SK_CASES)
 def test_gemm_stream_k_matches_plain_pingpong_tile(K, M, N, Kd, mode):
-    """Stream-K (tile variant 19: the launch's K-tile units dealt evenly over the 256 persistent blocks, partial tiles combined in-launch
-    through write-through slabs + flags) against the same tile without it (17) and the exact product: segments that start in the
-    middle of a tile, whole tiles inside a stream, streams that end in the middle of a tile, one to four contributors per tile,
-    streams of under one tile and of many tiles; fp32 / fp32 + residual / fp16 / bias + SiLU (generic) epilogues.  Repeated: the
+    """Stream-K (tile variant 19: the launch's K-tile units dealt over the persistent blocks in shares that divide a tile's K-tile count, so
+    every tile is cut at the same K positions and a row's summation order does not depend on its tile; partial tiles combined in-launch
+    through write-through slabs + flags) against the same tile without it (17) and the exact product: 2 to 64 contributors per tile,
+    launches that leave blocks idle; fp32 / fp32 + residual / fp16 / bias + SiLU (generic) epilogues.  Repeated: the
     hand-off is flag-ordered and the slabs are added in block order, so every launch gives the same bits, and the flags must come
     back cleared (a second launch would hang on a stale one or skip a wait)."""
     kernels, _lib = K
@@ -280,6 +280,9 @@ def test_gemm_stream_k_matches_plain_pingpong_tile(K, M, N, Kd, mode):
     ref = dC.download((M, N), dt).astype(np.float32)
     assert rel(ref, exact) < tol
     assert "ppsk" in kernels.gemm_variant(mk(19))
+    # (no share that divides the tile's K tiles: 160 tiles x 20 K tiles on 256 blocks -> the launch runs as the plain ping-pong tile)
+    assert "ppsk" not in kernels.gemm_variant(kernels.GemmArgs(A=dA.ptr, lda=1280, W_=dW.ptr, ldb=1280, M=8192, N=1280, K=1280, C32=dC.ptr, ldc32=1280,
+                                                                 tile_variant=20, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr))
     first = None
     for rep in range(5):
         _lib.check(L.mlsd_memset(_lib.vp(dC.ptr), 0x7C, ctypes.c_size_t(M * N * 4), None))
@@ -291,6 +294,30 @@ def test_gemm_stream_k_matches_plain_pingpong_tile(K, M, N, Kd, mode):
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
         assert not fl.download((1024,), np.uint32).any(), rep           # every flag consumed and cleared
+
+
+def test_gemm_stream_k_rows_do_not_depend_on_their_tile(K):
+    """The stream-K shares divide a tile's K-tile count, so every output tile is cut at the same K positions: identical rows in different
+    tiles (what an image in another batch slot is) come out bit-identical -- with the even share ceil(units / blocks) they did not."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(77)
+    Kd, N, reps = 4096, 768, 10
+    A0 = rng.standard_normal((256, Kd)).astype(np.float16)
+    A = np.ascontiguousarray(np.tile(A0, (reps, 1)))
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    M = A.shape[0]
+    dC = _lib.DeviceBuffer(M * N * 4)
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = dev(_lib, np.zeros(1024, np.uint32))
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=20, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr)
+    assert "ppsk" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    out = dC.download((reps, 256, N), np.uint32)
+    for r in range(1, reps):
+        assert np.array_equal(out[r], out[0]), r
 
 
 def test_conv2d_stream_k(K):
