@@ -13,12 +13,20 @@ def label(name):
         bm, bn, bk, wm, wn, conv, ns = m.groups()
         w16 = "w16" if int(wm) * int(wn) == 16 else ""
         return f"gemm<{bm}x{bn}x{bk}s{ns}{w16},{'conv' if conv == 'true' else 'linear'}>"
-    m = re.search(r"gemm_pp_kernel<(\d+), (\d+), \d+, \d+, (?:true|false), (true|false)(?:, \d+)?>", name)   # (+ the epilogue variant)
+    # gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, CONV, EPI[, SK[, NPH[, SCH]]]>: labels as mlsd_gemm_variant() prints them
+    m = re.search(r"gemm_pp_kernel<(\d+), (\d+), \d+, \d+, (?:true|false), (true|false)(?:, \d+)?(?:, (true|false))?(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
-        return f"gemm<{m.group(1)}x{m.group(2)}x64pp,{'conv' if m.group(3) == 'true' else 'linear'}>"
+        kind = "ppsk" if m.group(4) == "true" else "pp2" if m.group(5) == "2" else "ppb" if m.group(6) == "1" else "pp"
+        return f"gemm<{m.group(1)}x{m.group(2)}x64{kind},{'conv' if m.group(3) == 'true' else 'linear'}>"
+    m = re.search(r"gemm_w4_kernel<(\d+), (\d+),", name)
+    if m:
+        return f"gemm<{m.group(1)}x{m.group(2)}x64w4,linear>"
     m = re.search(r"attn_kernel<(\d+)(?:, (?:true|false))?>", name)
     if m:
         return f"attention<{m.group(1)}>"
+    m = re.search(r"attn_tk96_kernel<(\d+)", name)
+    if m:
+        return f"attention<{m.group(1)},one pass>"
     if "attn64x2_kernel" in name:
         return "attention<64,64 rows/wave>"
     for k in ("gn_stats", "gn_apply", "ln_kernel", "splitk_reduce", "softmax_rows"):
