@@ -271,6 +271,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const W4P p)
     }
 }
 
+
+// (The same loop on v_mfma_f32_32x32x16_f16 -- twice the FLOPs per instruction, half the operand-register reads per FLOP -- was built for one measurement
+// and removed: 1094 - 1133 TFLOP/s on 8192^3 against 1330 - 1345 for the 16x16x32 form, bit-identical results; profiles/r3_gemm_w4.txt.)
+
 int g_w4_panel = 8;
 
 }  // namespace

@@ -23,7 +23,9 @@ def timeit(a):
 # (label, M, N, K, residual, output: 0 f32 1 f16 2 geglu-f16)
 CASES = [("GEGLU 8192x10240x1280", 8192, 10240, 1280, 0, 2), ("QKV 8192x3840x1280 f16", 8192, 3840, 1280, 0, 1), ("GEGLU 32768x5120x640", 32768, 5120, 640, 0, 2),
          ("QKV 32768x1920x640 f16", 32768, 1920, 640, 0, 1), ("FF-out 8192x1280x5120 f32+res", 8192, 1280, 5120, 1, 0), ("FF-out 32768x640x2560 f32+res", 32768, 640, 2560, 1, 0),
-         ("q-proj 8192x1280x1280 f16", 8192, 1280, 1280, 0, 1), ("square 8192^3 f16", 8192, 8192, 8192, 0, 1), ("4096x4096x16384 f32", 4096, 4096, 16384, 0, 0)]
+         ("q-proj 8192x1280x1280 f16", 8192, 1280, 1280, 0, 1), ("square 8192^3 f16", 8192, 8192, 8192, 0, 1), ("4096x4096x16384 f32", 4096, 4096, 16384, 0, 0), ("square 8192^3 f32", 8192, 8192, 8192, 0, 0),
+         ("8192x10240x1280 f32", 8192, 10240, 1280, 0, 0)]
+if len(sys.argv) > 2: CASES = [c for c in CASES if sys.argv[2] in c[0]]
 for label, M, N, Kd, res, out in CASES:
     A = rng.standard_normal((M, Kd)).astype(np.float16)
     W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
@@ -49,4 +51,5 @@ for label, M, N, Kd, res, out in CASES:
         outs[v] = dC.download((M, No), np.float16 if out else np.float32).astype(np.float32)
         line.append(f"{kernels.gemm_variant(a).split('<')[1].split(',')[0]:>13s} {ts[0]:8.1f} us {2.0 * M * N * Kd / ts[0] / 1e6:7.1f} TF/s")
     d = max(np.abs(outs[26] - outs[17]).max(), np.abs(outs[27] - outs[18]).max() if 27 in outs else 0.0)
+    if 28 in outs: line.append(f"rel |w4m32 - pp| {np.linalg.norm(outs[28] - outs[17]) / np.linalg.norm(outs[17]):.1e}")
     print(f"{label:32s} | " + " | ".join(line) + f" | max |w4 - pp| {d:.1e} (|pp| max {np.abs(outs[17]).max():.1f})", flush=True)
