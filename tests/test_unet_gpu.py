@@ -114,6 +114,35 @@ def test_unet_sdxl_eval_is_bit_repeatable_and_finite():
         assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
 
 
+def test_in_plan_tile_tuning_keeps_the_result():
+    """mlctx_tune_inplan (offline tool, tools/tune_inplan.py) swaps tile variants of whole shapes while it times them and leaves the plan on the
+    winners: the evaluation afterwards agrees with the one before within the per-evaluation parity tolerance, is bit-repeatable, and the process table holds
+    one line per changed shape (mlsd_tune_dump)."""
+    import ctypes, os, tempfile
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    L.mlctx_tune_inplan.argtypes = [_lib.vp, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    n, lat = 2, 32
+    un = engine.Unet("sdxl", lat, lat, n)
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.array([7.0, 0.5], np.float32)
+    before = un.run(x, cond, label, sigma)
+    changed = L.mlctx_tune_inplan(un.ctx.h, 1)
+    assert changed >= 0, _lib.last_error()
+    after = un.run(x, cond, label, sigma)
+    # (other tiles = other fp32 summation orders, amplified by the fp16 operand roundings of 70 layers: the same size as the distance to the oracle, 1e-3)
+    assert np.isfinite(after).all() and rel(after, before) < 3e-3
+    assert np.array_equal(un.run(x, cond, label, sigma).view(np.uint32), after.view(np.uint32))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.inc")
+        nl = L.mlsd_tune_dump(path.encode())
+        assert nl >= changed and len(open(path).read().splitlines()) == nl
+
+
 def test_unet_sdxl_headline_size_parity():
     """BASELINE.json's headline shape itself: ONE SDXL UNet evaluation at the 128x128 latent of a 1024x1024 image (2567.5 M
     synthetic parameters, 6.76 TFLOP) against the oracle's CPU restatement (about half a minute of host time on the
