@@ -48,6 +48,7 @@ void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
+int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K) of this plan gave up waiting since the last check: results invalid */
 /* GEMM tile selection is a pure function of the shape (compiled-in table, csrc/host/tune_table.inc), so every process
  * runs the same kernels in the same summation order.  mlctx_set_autotune(1) (or MLSD_AUTOTUNE=1) turns on the OFFLINE
  * timing mode used by tools/tune_all.py to produce that table; mlsd_tune_dump writes the shapes timed in this process. */

@@ -619,8 +619,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             int c = skw + 1;
             for (int rem = nkt - end_k; rem > 0; rem -= p.sk_L, ++c) {
                 if (tid == 0) {
-                    unsigned spins = 0;                            // bounded: a lost contribution must not hang the device (the result is then wrong, tests catch it)
+                    unsigned spins = 0;                            // bounded: a lost contribution must not hang the device; the give-up is REPORTED through the
+                    // sticky word sk_flag[4095], which the host reads with the results (mlctx_handoff_check): a contributor block that is not resident (CUs taken
+                    // by another process) would otherwise turn into a silently wrong tile
                     while (__hip_atomic_load(p.sk_flag + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+                    if (spins >= (1u << 22)) __hip_atomic_store(p.sk_flag + 4095, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(p.sk_flag + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one consumer per flag: clear it for the next launch

@@ -469,6 +469,7 @@ MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 	}
 	int32_t nan_count = 0;
 	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;
+	if (mlctx_handoff_check(S->unet_ctx) < 0) return -1;                     /* a stream-K hand-off of the plan gave up waiting: results invalid */
 	float tot = 0;
 	for (int i=0; i<S->i_eval; ++i) { float ms = 0; mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &ms); tot += ms; }
 	S->last_unet_ms = tot;
@@ -683,6 +684,7 @@ MLB_API int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* late
 	if (mlis_amd_decode(S) < 0) return -1;
 	if (images_out && mlsd_memcpy(images_out, S->d_img, (size_t)S->B*3*S->c.width*S->c.height*4, 1, S->stream)) return -1;
 	if (mlsd_stream_sync(S->stream)) return -1;
+	if (mlctx_handoff_check(S->dec_ctx) < 0) return -1;
 	return 1;
 }
 

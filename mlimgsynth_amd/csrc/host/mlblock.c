@@ -103,6 +103,19 @@ MLB_API void mlctx_set_wtype(MLCtx* C, int t) { C->wtype = t; }
 MLB_API MLTensor* mlctx_result(MLCtx* C) { return C->result; }
 MLB_API int mlctx_sync(MLCtx* C) { return mlsd_stream_sync(C->stream) ? -1 : 1; }
 
+/* Stream-K launches hand partial tiles over inside the launch; an owner block that gives up waiting (bounded spin: a contributor never became resident,
+ * e.g. the CUs are shared with another process) raises a sticky word beside the flags.  Called by the drivers where they read their results back:
+ * 0 = clean, < 0 = at least one hand-off of this plan timed out since the last check (the word is cleared). */
+MLB_API int mlctx_handoff_check(MLCtx* C)
+{
+	if (!C || !C->sk_flags) return 0;
+	unsigned w = 0;
+	if (mlsd_memcpy(&w, C->sk_flags + 4095, 4, 1, C->stream) || mlsd_stream_sync(C->stream)) return -1;
+	if (!w) return 0;
+	mlsd_memset(C->sk_flags + 4095, 0, 4, C->stream);
+	return mlsd_set_error(-8, "a stream-K hand-off timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid");
+}
+
 /* ------------------------------------------------------------------ device memory */
 /* A released block may be handed out again only to a writer that runs AFTER the block's last reader.
  * Ops run in recorded order, so a block released when `rel_op` ops had been recorded is safe for any op

@@ -137,6 +137,8 @@ def test_in_plan_tile_tuning_keeps_the_result():
     # (other tiles = other fp32 summation orders, amplified by the fp16 operand roundings of 70 layers: the same size as the distance to the oracle, 1e-3)
     assert np.isfinite(after).all() and rel(after, before) < 3e-3
     assert np.array_equal(un.run(x, cond, label, sigma).view(np.uint32), after.view(np.uint32))
+    L.mlctx_handoff_check.argtypes = [_lib.vp]
+    assert L.mlctx_handoff_check(un.ctx.h) == 0          # no in-launch hand-off (stream-K) of the plan gave up waiting
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "t.inc")
         nl = L.mlsd_tune_dump(path.encode())
