@@ -49,6 +49,7 @@ int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
 int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K) of this plan gave up waiting since the last check: results invalid */
+int    mlctx_ln_fused(const MLCtx* C);  /* number of LayerNorms of the plan that run at the END of their producers' launches (mlsd_gemm_args.ln_*; MLSD_NO_LN_FOLD=1: none) */
 /* GEMM tile selection is a pure function of the shape (compiled-in table, csrc/host/tune_table.inc), so every process
  * runs the same kernels in the same summation order.  mlctx_set_autotune(1) (or MLSD_AUTOTUNE=1) turns on the OFFLINE
  * timing mode used by tools/tune_all.py to produce that table; mlsd_tune_dump writes the shapes timed in this process. */

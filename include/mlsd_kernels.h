@@ -134,11 +134,24 @@ typedef struct mlsd_gemm_args {
 	 *  - split-K (ksplit > 1): a ticket counter per output tile; the slices are then added inside the launch (no second launch).
 	 *    NULL, or more than 4096 tiles: the two-launch form. */
 	unsigned* sk_flags;
+	/* LayerNorm at the END of the launch (round 3): when ln_y16 is set and mlsd_gemm_ln_fused(args) says so, the launch also writes
+	 * ln_y16[m][n] = fp16(LayerNorm(C32 row m) * ln_gamma + ln_beta) (row stride ldln halfs, eps ln_eps): the LayerNorm that would follow
+	 * (ggml_norm + mul + add, src/mlblock_nn.c:65-71) needs no launch of its own.  Linear launches on the 128x320 ping-pong tile whose tiles are all
+	 * resident at once (M % 128 == 0, N % 320 == 0, (M/128)(N/320) <= 256), fp32 output (+ residual).  ln_ws: >= (M/128)(N/320) * 128 * 8 bytes of scratch;
+	 * ln_cnt: 8192 zeroed 32-bit words that stay zero between launches (word 8191 is a sticky give-up indicator like sk_flags[4095]).
+	 * mlsd_gemm FAILS when ln_y16 is set and the launch cannot honour it. */
+	void* ln_y16; int64_t ldln;
+	const float *ln_gamma, *ln_beta;
+	float ln_eps;
+	float* ln_ws;
+	unsigned* ln_cnt;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
 /* rows per statistics block (64 or 128) if this launch would write a->colstats, 0 if its kernel cannot */
 int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
+/* 1 if this launch (ln_* fields set) ends with the LayerNorm of its output (see mlsd_gemm_args.ln_y16) */
+int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
 /* tile order inside an XCD's range: column panels `mode` tiles wide (default 8; 0 = row-major).  A/B timing knob. */

@@ -76,6 +76,13 @@ struct GemmP {
     int sk_L;
     float* sk_ws;
     unsigned* sk_flag;
+    // LayerNorm at the end of the launch (gemm_pp.hpp *_LN epilogues): gamma, beta, eps, fp16 output, per-(row block, tile column, row) partials, counters
+    const float *ln_g, *ln_b;
+    float ln_eps;
+    _Float16* ln_y;
+    long ldln;
+    float* ln_ws;
+    unsigned* ln_cnt;
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -709,6 +716,16 @@ bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
            (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
 }
 
+// launches that can END with the LayerNorm of their output (gemm_pp.hpp *_LN): linear, 128 x 320 ping-pong tile made of WHOLE tiles, all of them resident at
+// once (single round: the tiles of a row block exchange their partial row statistics inside the launch), fp32 output (+ residual), no activation / statistics / row bias
+bool ln_eligible(const mlsd_gemm_args* a)
+{
+    if (!a->ln_y16 || !a->ln_gamma || !a->ln_beta || !a->ln_ws || !a->ln_cnt || a->conv || a->colstats || a->rowbias || a->bias_m || a->act != MLSD_ACT_NONE) return false;
+    if (!a->C32 || a->C16 || (a->M % 128) || (a->N % 320) || (a->ldln & 7) || ((uintptr_t)a->ln_y16 & 15) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return false;
+    const long tiles = (long)(a->M / 128) * (a->N / 320);
+    return tiles <= g_gemm_ncu && a->M / 128 <= 127 && pp_eligible(a, 128, 320);      // (counters: one 128-byte line per (row block, wave row) in 8192 words)
+}
+
 // which epilogue body a ping-pong launch of these arguments uses (gemm_pp.hpp PP_EPI_*)
 int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 {
@@ -717,6 +734,7 @@ int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
     if (a->act == MLSD_ACT_NONE) {
         if (a->C16 && !a->C32 && !a->resid) return c16_wide ? PP_EPI_F16 : PP_EPI_GENERIC;
         if (a->C32 && !a->C16) {
+            if (a->ln_y16 && ln_eligible(a)) return a->resid ? PP_EPI_F32_RES_LN : PP_EPI_F32_LN;
             const bool st = a->colstats != nullptr && !((uintptr_t)a->colstats & 15) && !(a->N & 3);
             return a->resid ? (st ? PP_EPI_F32_RES_STATS : PP_EPI_F32_RES) : (st ? PP_EPI_F32_STATS : PP_EPI_F32);
         }
@@ -766,6 +784,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
     p.sk_L = 0; p.sk_ws = nullptr; p.sk_flag = nullptr;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt;
     if constexpr (SK) {
         p.sk_L = sk_share(ntiles, a->K / BK, g_gemm_ncu);
         p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags;
@@ -775,6 +794,11 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_pp_kernel");
+    };
+    auto go_ln = [&](auto kfn) -> int {              // + 4 KB beyond the ring for the wave columns' partial row statistics
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS + 4096)));
+        hipLaunchKernelGGL(kfn, grid, block, LDS + 4096, st, p);
+        return mlsd_check_launch("gemm_pp_kernel(+LN)");
     };
     // the epilogue the kernel is built with (gemm_pp.hpp): the bulk launches of the UNet / VAE have no activation in the GEMM
     const int epi = pp_epilogue_kind(a, BN);
@@ -811,6 +835,12 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES, false, NPH, SCH>);
     case PP_EPI_F32_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_STATS, false, NPH, SCH>);
     case PP_EPI_F32_RES_STATS: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES_STATS, false, NPH, SCH>);
+    case PP_EPI_F32_LN:
+        if constexpr (BM == 128 && BN == 320 && NPH == 4 && SCH == 0) return go_ln(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_LN, false, 4, 0>);
+        break;
+    case PP_EPI_F32_RES_LN:
+        if constexpr (BM == 128 && BN == 320 && NPH == 4 && SCH == 0) return go_ln(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES_LN, false, 4, 0>);
+        break;
     case PP_EPI_GEGLU16:
         if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16, false, NPH, SCH>);
         break;
@@ -894,6 +924,8 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     if (a->colstats && a->colstats_rows > 0 && mlsd_gemm_colstats_rows(a) != a->colstats_rows)
         return mlsd_set_error(-1, "mlsd_gemm: a GroupNorm was planned on this launch's column statistics (blocks of %d rows) but the launch "
                               "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
+    if (a->ln_y16 && !mlsd_gemm_ln_fused(a))
+        return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a LayerNorm for this launch's *_LN epilogue but the launch would not run it (tile or epilogue settings changed after planning)");
     hipStream_t st = (hipStream_t)stream;
     switch (pick_variant(a)) {
     case 1: return launch<64, 128, 64, 2, 2, 2>(a, st);
@@ -980,6 +1012,16 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
     return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
+}
+
+/* 1 if this launch (with its ln_* fields set) would end with the LayerNorm of its output: the plan builder then drops the LayerNorm launch */
+MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
+{
+    if (!a || !a->ln_y16) return 0;
+    const int v = pick_variant(a);
+    if (v != 18 || !ln_eligible(a)) return 0;
+    const int e = pp_epilogue_kind(a, 320);
+    return e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN;
 }
 
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)

@@ -99,7 +99,16 @@ __device__ __forceinline__ PPTile pp_tile_plain(const GemmP& p, int bid)
 // EPI selects the epilogue the kernel is BUILT with (launch_pp picks it from the arguments): 0 = generic (any activation,
 // per-row bias, any output combination: decided per element at run time), 1 = fp16 out, 2 = fp32 out, 3 = fp32 out + fp32
 // residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
-enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6 };
+enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6,
+       PP_EPI_F32_LN = 7, PP_EPI_F32_RES_LN = 8 };
+// *_LN (round 3, 128 x 320 tile, single-round linear launches): the launch ENDS with the LayerNorm of its fp32 output instead of being followed by one.  The 4 (N = 1280)
+// column tiles of a row block run at the same time on CUs of one XCD; each computes, per row, the mean and the centred sum of squares of its 320 columns (4 lanes by shuffles,
+// 4 wave columns through 4 KB of LDS, Chan's pairwise combination: no cancellation), publishes them (1 KB per wave row, write-through), takes a ticket on the row block's
+// counter; ONE wave per (block, wave row) polls it until all tiles have published (every wave polling starved the arrivals: 30 us per launch), the others wait at a
+// barrier; then every wave reads the partials with agent-scope loads (an acquire fence in 2048 waves cost 15 us), combines them in tile order (bit-repeatable), normalises
+// the values it still holds in its accumulators and writes the fp16 rows.  A second counter (departures) clears both for the next launch.  Bounded polling; a give-up
+// raises a sticky word (ln_cnt[8191]) that the host reads with the results.  Measured (tools/ln_fold_bench.py): 8192x1280x1280 GEMM 40.3 + LayerNorm 12.0 = 53.3 us as two
+// launches, 50.9 us as one (46.6 without the exchange); K = 5120: 135.4 -> 128.1; SDXL b4 evaluation 65.50 -> 65.05 ms (same box, MLSD_NO_LN_FOLD=1 for the A/B).
 // *_STATS: additionally the column sums / sums of squares of the wave's rows (GemmP::colstats) for a consuming GroupNorm
 // NPH = 2: TWO phases per K tile instead of four (round 3).  In-kernel stamps of the four-phase loop on the 128 x 320 tile: 2075 clocks
 // per K tile against 1280 of matrix work, the same with the staging switched off (profiles/r2_gemm_trace_*: the loop is not fill-bound
@@ -495,6 +504,146 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             }
         }
     };
+    // ---- *_LN epilogue (see the enum): fp32 output (+ residual) AND the LayerNorm of the finished rows as fp16
+    auto epi_ln = [&](auto RES_, int wrow0, int wcol0) __attribute__((always_inline)) {
+        if constexpr (BM == 128 && BN == 320 && !CONV && !SK) {
+            constexpr bool RES = decltype(RES_)::value;
+            constexpr int NR = 2 * RA;                              // 16-row blocks of the wave's 64 rows
+            auto row_of = [&](int r) __attribute__((always_inline)) { return (r / RA) * (WM / 2) + (r % RA) * 16; };
+            // 1. v = acc + bias (+ residual) -> C32, kept in the accumulators
+            f32x4 rr[RES ? NR : 1][RES ? NCB : 1];
+            if constexpr (RES) {
+                const float* rbase = p.resid + (long)(wrow0 + l15) * p.ldr + wcol0 + 4 * lg;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) rr[r][c] = *reinterpret_cast<const f32x4*>(rbase + (long)row_of(r) * p.ldr + c * 16);
+            }
+            float* c32b = p.C32 + (long)(wrow0 + l15) * p.ldc32 + wcol0 + 4 * lg;
+            float mean_w[NR], m2_w[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int qa = r / RA, i = r % RA;
+                float s1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    f32x4 v = acc[qa][i][c] + cb[c];
+                    if constexpr (RES) v += rr[r][c];
+                    acc[qa][i][c] = v;                              // (stored to C32 after the ticket: the publish must not wait behind the tile's 160 KB of stores)
+                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                // 2. the row's 80 columns of this wave sit in the 4 lanes l15 + 16 lg: mean, then the centred sum of squares
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                const float mu = s1 * (1.0f / WN);
+                float q = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    const f32x4 d = acc[qa][i][c] - mu;
+                    q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                }
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                mean_w[r] = mu; m2_w[r] = q;
+            }
+            // 3. the 4 wave columns of a wave row through LDS (beyond the ring: its tail stages may still be landing), combined in wave-column order
+            f32x2* red = reinterpret_cast<f32x2*>(smem + 2 * STAGE);          // [wave row][64 rows][4 wave columns]
+            if (lg == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) red[(wr * 64 + row_of(r) + l15) * 4 + wc] = f32x2{mean_w[r], m2_w[r]};
+            }
+            __builtin_amdgcn_s_barrier();                                    // (the groups run their epilogues side by side: an ordinary block barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto chan = [&](float& n, float& mu, float& m2, float nb, float mub, float m2b) __attribute__((always_inline)) {
+                const float d = mub - mu, nn = n + nb;
+                mu += d * (nb / nn); m2 += m2b + d * d * (n * nb / nn); n = nn;
+            };
+            float mean_t[NR], m2_t[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const f32x2* e = red + (wr * 64 + row_of(r) + l15) * 4;
+                float n = (float)WN, mu = e[0][0], m2 = e[0][1];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) chan(n, mu, m2, (float)WN, e[w][0], e[w][1]);
+                mean_t[r] = mu; m2_t[r] = m2;
+            }
+            // 4. publish (wave column 0 of each wave row), ticket, poll
+            const int rbk = tcur.m0 / BM, bnk = tcur.n0 / BN, nbn = p.nbn;
+            f32x2* gws = reinterpret_cast<f32x2*>(p.ln_ws) + ((long)rbk * nbn * BM);          // [tile column][128 rows]
+            unsigned* cnt = p.ln_cnt + (rbk * 2 + wr) * 32;                                    // [row block][wave row]{arrivals, departures}: one 128-byte line each
+            if (wc == 0) {
+                if (lg == 0) {
+                    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gws + (long)bnk * BM), 0, BM * 8, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const f32x2 t = {mean_t[r], m2_t[r]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rs, (wr * 64 + row_of(r) + l15) * 8, 0, 16);   // sc1: write-through
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the fp32 output goes out while the other tiles' partials arrive
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    *reinterpret_cast<f32x4*>(c32b + (long)row_of(r) * p.ldc32 + c * 16) = acc[r / RA][r % RA][c];
+            // ONE wave per (block, wave row) polls (2048 polling waves on a few lines starved the arrivals themselves: 30 us per launch); the others wait at the barrier
+            if (wc == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
+                if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // departures: the last of the nbn pollers of this (row block, wave row) clears both counters for the next launch
+                if (lane == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == (unsigned)(nbn - 1)) {
+                        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            // (no acquire fence: 2048 waves invalidating their caches cost 15 us per launch; the partials are read with agent-scope loads instead)
+            // 5. all tiles' partials in tile order -> mean, 1 / sqrt(var + eps)
+            float mean_r[NR], rstd_r[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const f32x2* e = gws + wr * 64 + row_of(r) + l15;
+                auto ld2 = [&](const f32x2* q) __attribute__((always_inline)) {
+                    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return __builtin_bit_cast(f32x2, u);
+                };
+                f32x2 t = ld2(e);
+                float n = (float)BN, mu = t[0], m2 = t[1];
+                for (int b = 1; b < nbn; ++b) { t = ld2(e + (long)b * BM); chan(n, mu, m2, (float)BN, t[0], t[1]); }
+                mean_r[r] = mu; rstd_r[r] = 1.0f / sqrtf(m2 / n + p.ln_eps);
+            }
+            // 6. y = (v - mean) rstd gamma + beta -> fp16, 16-byte stores (pairs of column blocks exchange halves, as epi_fast)
+            f32x4 gm[NCB], bt[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                gm[c] = *reinterpret_cast<const f32x4*>(p.ln_g + wcol0 + c * 16 + 4 * lg);
+                bt[c] = *reinterpret_cast<const f32x4*>(p.ln_b + wcol0 + c * 16 + 4 * lg);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int qa = r / RA, i = r % RA;
+                _Float16* rowp = p.ln_y + (long)(wrow0 + l15 + row_of(r)) * p.ldln + wcol0 + 8 * (lg >> 1) + 16 * (lg & 1);
+                auto y4 = [&](int c) __attribute__((always_inline)) {
+                    const f32x4 y = (acc[qa][i][c] - mean_r[r]) * rstd_r[r] * gm[c] + bt[c];
+                    return f16x4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+                };
+#pragma unroll
+                for (int c = 0; c + 1 < NCB; c += 2) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, y4(c)), b = __builtin_bit_cast(u32x2, y4(c + 1));
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    *reinterpret_cast<u32x4*>(rowp + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+                if constexpr (NCB & 1)
+                    *reinterpret_cast<f16x4*>(p.ln_y + (long)(wrow0 + l15 + row_of(r)) * p.ldln + wcol0 + (NCB - 1) * 16 + 4 * lg) = y4(NCB - 1);
+            }
+        }
+    };
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int wrow0 = tcur.m0 + wr * WM, wcol0 = tcur.n0 + wc * WN;
         if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % WM == 0, N % WN == 0: a wave's block is all in or all out
@@ -516,6 +665,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         if constexpr (EPI == PP_EPI_F32_STATS) { epi_fast(T{}, F{}, F{}, T{}, wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_F32_RES_STATS) { epi_fast(T{}, F{}, T{}, T{}, wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_GEGLU16) { epi_fast_geglu(wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_LN) { epi_ln(F{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_F32_RES_LN) { epi_ln(T{}, wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_GENERIC) {
         if constexpr (RESBATCH) {
             if (p.resid) {

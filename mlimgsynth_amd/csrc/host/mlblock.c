@@ -69,6 +69,8 @@ static void ctx_reset_(MLCtx* C)
 	for (int i=0;i<C->n_chunks;++i) mlsd_free(C->chunks[i]);
 	if (C->splitk_ws) { mlsd_free(C->splitk_ws); C->splitk_ws = NULL; C->splitk_ws_bytes = 0; }
 	if (C->sk_flags) { mlsd_free(C->sk_flags); C->sk_flags = NULL; }
+	if (C->ln_cnt) { mlsd_free(C->ln_cnt); C->ln_cnt = NULL; }
+	if (C->ln_ws) { mlsd_free(C->ln_ws); C->ln_ws = NULL; C->ln_ws_bytes = 0; }
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
@@ -103,17 +105,22 @@ MLB_API void mlctx_set_wtype(MLCtx* C, int t) { C->wtype = t; }
 MLB_API MLTensor* mlctx_result(MLCtx* C) { return C->result; }
 MLB_API int mlctx_sync(MLCtx* C) { return mlsd_stream_sync(C->stream) ? -1 : 1; }
 
+MLB_API int mlctx_ln_fused(const MLCtx* C) { return C ? C->n_ln_fused : 0; }   /* LayerNorms of the plan that run at the end of their producers' launches */
+
 /* Stream-K launches hand partial tiles over inside the launch; an owner block that gives up waiting (bounded spin: a contributor never became resident,
  * e.g. the CUs are shared with another process) raises a sticky word beside the flags.  Called by the drivers where they read their results back:
  * 0 = clean, < 0 = at least one hand-off of this plan timed out since the last check (the word is cleared). */
 MLB_API int mlctx_handoff_check(MLCtx* C)
 {
-	if (!C || !C->sk_flags) return 0;
-	unsigned w = 0;
-	if (mlsd_memcpy(&w, C->sk_flags + 4095, 4, 1, C->stream) || mlsd_stream_sync(C->stream)) return -1;
-	if (!w) return 0;
-	mlsd_memset(C->sk_flags + 4095, 0, 4, C->stream);
-	return mlsd_set_error(-8, "a stream-K hand-off timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid");
+	if (!C) return 0;
+	unsigned w = 0, w2 = 0;
+	if (C->sk_flags && (mlsd_memcpy(&w, C->sk_flags + 4095, 4, 1, C->stream) || mlsd_stream_sync(C->stream))) return -1;
+	if (C->ln_cnt && (mlsd_memcpy(&w2, C->ln_cnt + 8191, 4, 1, C->stream) || mlsd_stream_sync(C->stream))) return -1;
+	if (!w && !w2) return 0;
+	if (w) mlsd_memset(C->sk_flags + 4095, 0, 4, C->stream);
+	if (w2) mlsd_memset(C->ln_cnt + 8191, 0, 4, C->stream);
+	return mlsd_set_error(-8, "an in-launch hand-off (%s) timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid",
+	                      w ? "stream-K" : "LayerNorm statistics");
 }
 
 /* ------------------------------------------------------------------ device memory */
@@ -540,7 +547,8 @@ static int run_op(MLCtx* C, MLOp* op)
 	case OP_GEMM: return mlsd_gemm(&op->u.gemm, st);
 	case OP_ATTN: return mlsd_attention(&op->u.attn, st);
 	case OP_GN:   return mlsd_groupnorm(&op->u.gn, st);
-	case OP_LN:   return mlsd_layernorm(op->u.ln.x, op->u.ln.ldx, op->u.ln.rows, op->u.ln.d, op->u.ln.eps, op->u.ln.g, op->u.ln.b,
+	case OP_LN:   if (op->fused) return 0;                    /* its producer ends with it (wire_ln_fold) */
+	              return mlsd_layernorm(op->u.ln.x, op->u.ln.ldx, op->u.ln.rows, op->u.ln.d, op->u.ln.eps, op->u.ln.g, op->u.ln.b,
 	                                   op->u.ln.y16, op->u.ln.y32, st);
 	case OP_NCHW2NHWC: return mlsd_nchw_to_nhwc_f16(op->u.n2h.src, op->u.n2h.n_src, op->u.n2h.C, op->u.n2h.HW, op->u.n2h.dst,
 	                                   op->u.n2h.n_dst, op->u.n2h.Cpad, op->u.n2h.scale, op->u.n2h.scale0, op->u.n2h.mode, st);
@@ -796,7 +804,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 	for (int i=0;i<C->n_ops;++i) {
 		op_shape[i] = -1;
 		MLOp *op = &C->ops[i];
-		if (op->kind != OP_GEMM || op->u.gemm.colstats) continue;
+		if (op->kind != OP_GEMM || op->u.gemm.colstats || op->u.gemm.ln_y16) continue;     /* (tiles bound by a consumer's wiring stay) */
 		mlsd_gemm_args *g = &op->u.gemm;
 		const TuneKey k = tune_key(g);
 		int j = 0;
@@ -870,7 +878,8 @@ static int op_outputs(const MLOp* o, const void* out[3])
 {
 	int n = 0;
 	switch (o->kind) {
-	case OP_GEMM: if (o->u.gemm.C32) out[n++] = o->u.gemm.C32; if (o->u.gemm.C16) out[n++] = o->u.gemm.C16; break;
+	case OP_GEMM: if (o->u.gemm.C32) out[n++] = o->u.gemm.C32; if (o->u.gemm.C16) out[n++] = o->u.gemm.C16;
+		if (o->u.gemm.ln_y16 && n < 3) out[n++] = o->u.gemm.ln_y16; break;
 	case OP_ATTN: out[n++] = o->u.attn.out; break;
 	case OP_GN: out[n++] = o->u.gn.y16; if (o->u.gn.raw16) out[n++] = o->u.gn.raw16; break;
 	case OP_LN: if (o->u.ln.y16) out[n++] = o->u.ln.y16; if (o->u.ln.y32) out[n++] = o->u.ln.y32; break;
@@ -945,6 +954,48 @@ static void wire_gn_stats(MLCtx* C)
 	}
 }
 
+/* LayerNorm at the end of its producer (round 3).  A LayerNorm whose input is the fp32 output of a linear launch that qualifies (mlsd_gemm_ln_fused: single-round
+ * 128x320 ping-pong launch, fp32 (+ residual) epilogue) is handed to that launch -- gamma, beta, eps, the fp16 output buffer, scratch for the row blocks' partial
+ * statistics and the plan's ticket counters -- and its own op is skipped (MLOp.fused).  Same producer rule as the GroupNorm statistics: the op that DEFINES the input
+ * tensor, still writing exactly this matrix, no writer in between.  MLSD_NO_LN_FOLD=1 keeps the separate launches (A/B timing, reference of the parity test). */
+static void wire_ln_fold(MLCtx* C)
+{
+	const char *e = getenv("MLSD_NO_LN_FOLD");
+	if (e && *e && *e != '0') return;
+	for (int i=0;i<C->n_ops;++i) {
+		MLOp *l = &C->ops[i];
+		if (l->kind != OP_LN || !l->u.ln.y16 || l->u.ln.y32 || !l->u.ln.b) continue;
+		const int j = l->gn_src[0];
+		if (j < 0 || j >= i) continue;
+		MLOp *o = &C->ops[j];
+		mlsd_gemm_args *g = &o->u.gemm;
+		if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
+		const char *lo = (const char*)l->u.ln.x, *hi = lo + (size_t)g->M * g->ldc32 * sizeof(float);
+		int clean = 1;
+		for (int k=j+1; k<i && clean; ++k) {
+			const void *out[3];
+			const int n = op_outputs(&C->ops[k], out);
+			for (int q=0;q<n;++q) if ((const char*)out[q] >= lo && (const char*)out[q] < hi) clean = 0;
+			/* the fp16 output is written EARLIER now (by op j instead of op i): nothing in between may still read or write that buffer */
+			for (int q=0;q<n;++q) if ((const char*)out[q] >= (const char*)l->u.ln.y16 && (const char*)out[q] < (const char*)l->u.ln.y16 + (size_t)g->M * g->N * 2) clean = 0;
+		}
+		if (!clean || i != j + 1) continue;                      /* (adjacent ops only: the arena may have handed the fp16 block to a reader that runs in between) */
+		if (!C->ln_cnt) {
+			if (mlsd_malloc((void**)&C->ln_cnt, 8192 * 4)) return;
+			if (mlsd_memset(C->ln_cnt, 0, 8192 * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
+		}
+		const size_t need = (size_t)(g->M / 128 > 0 ? g->M / 128 : 1) * (g->N / 320 > 0 ? g->N / 320 : 1) * 128 * 8;
+		if (C->ln_ws_bytes < need) {
+			if (C->ln_ws) continue;                              /* one scratch block per plan, sized by the first (largest) user: later larger ones keep their launch */
+			if (mlsd_malloc((void**)&C->ln_ws, need)) return;
+			C->ln_ws_bytes = need; C->mem_compute += need;
+		}
+		g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
+		if (mlsd_gemm_ln_fused(g) == 1) { l->fused = 1; C->n_ln_fused++; }
+		else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
+	}
+}
+
 MLB_API int mlctx_prep(MLCtx* C)
 {
 	if (C->err) return C->err;
@@ -966,7 +1017,7 @@ MLB_API int mlctx_prep(MLCtx* C)
 		char path[96]; snprintf(path, sizeof(path), "dump-graph-%s.txt", C->name[0] ? C->name : "ctx");
 		if (mlctx_block_graph_dump_path(C, path) < 0) return -1;
 	}
-	if (!autotune_on()) wire_gn_stats(C);   /* (needs the tiles: the offline tuning mode runs the two-pass form) */
+	if (!autotune_on()) { wire_gn_stats(C); wire_ln_fold(C); }   /* (need the tiles: the offline tuning mode runs the two-pass / separate forms) */
 	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;
 	C->info.mem_params = C->mem_params; C->info.mem_compute = C->mem_compute; C->info.mem_total = C->mem_params + C->mem_compute;
 	if (C->err) return C->err;
@@ -1103,7 +1154,8 @@ MLB_API double mlctx_op_bytes(const MLCtx* C, int i)
 		const double n = (double)a->n_img * a->HW * (a->C1 + a->C2);
 		return n * (4.0 + 2.0 + (a->raw16 ? 2.0 : 0.0));
 	}
-	case OP_LN: return (double)op->u.ln.rows * op->u.ln.d * (4.0 + (op->u.ln.y16 ? 2.0 : 0.0) + (op->u.ln.y32 ? 4.0 : 0.0));
+	case OP_LN: if (op->fused) return 0.0;
+		return (double)op->u.ln.rows * op->u.ln.d * (4.0 + (op->u.ln.y16 ? 2.0 : 0.0) + (op->u.ln.y32 ? 4.0 : 0.0));
 	case OP_SOFTMAX: return (double)op->u.smax.rows * op->u.smax.cols * 6.0;
 	case OP_ACT: return (double)op->u.act.n * 6.0;
 	case OP_COPY_F32: return 2.0 * op->u.copy.nbytes;

@@ -20,6 +20,7 @@ typedef struct MLOp {
 	double flops;
 	char label[56];
 	int gn_src[2];          /* OP_GN: index of the op that PRODUCES each fp32 source (MLTensor.prod), -1 = not a GEMM/conv output */
+	int fused;              /* OP_LN: the producer's launch ends with this LayerNorm (wire_ln_fold): the op itself does nothing */
 	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
 	                         * re-runs it only after such an input was written (mlctx_input_set / mlctx_input_device_ptr) */
 	union {
@@ -104,6 +105,7 @@ struct MLCtx {
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums / stream-K slabs (one buffer: ops run in order on one stream) */
 	unsigned* sk_flags;                        /* stream-K: one flag per persistent block, zeroed once (consumers clear them) */
+	unsigned* ln_cnt; float* ln_ws; size_t ln_ws_bytes; int n_ln_fused;   /* LayerNorms ended in their producers (wire_ln_fold): counters, scratch, count */
 	MLCtxInfo info;
 };
 

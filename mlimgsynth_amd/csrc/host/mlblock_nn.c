@@ -176,6 +176,7 @@ MLTensor* mlb_layer_norm_ex(MLCtx* C, MLTensor* x, float eps, int out32)
 	MLOp *op = mlctx_op_new(C, OP_LN, "layernorm");
 	op->u.ln.x = xd; op->u.ln.ldx = x->ld32; op->u.ln.rows = (int)rows; op->u.ln.d = d; op->u.ln.eps = eps;
 	op->u.ln.g = wd; op->u.ln.b = bd; op->u.ln.y16 = y->d16; op->u.ln.y32 = y->d32;
+	op->gn_src[0] = x->prod; op->gn_src[1] = -1;                          /* the defining op of the input (wire_ln_fold) */
 	return y;
 }
 

@@ -561,6 +561,57 @@ def test_gemm_split_k_reduced_in_the_launch(K, M, N, Kd, ksplit, variant, conv):
     assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,N,Kd,res", [(8192, 1280, 1280, 1), (8192, 1280, 5120, 1), (1024, 1280, 320, 0), (2048, 640, 640, 1), (4096, 320, 256, 0), (128, 1280, 192, 1)])
+def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
+    """mlsd_gemm_args.ln_*: a single-round linear launch on the 128x320 ping-pong tile also writes LayerNorm(C32 row) * gamma + beta as fp16: the tiles of a
+    row block exchange their partial row statistics inside the launch (write-through partials, ticket counter, bounded polling).  Against the same launch
+    followed by mlsd_layernorm: the fp32 output is bit-identical, the fp16 rows agree to the last fp16 digit (other reduction tree for mean / variance),
+    repeated launches give the same bits and leave the counters at zero."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_ln_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, (rng.standard_normal(N) * 2).astype(np.float32))
+    dR = dev(_lib, (rng.standard_normal((M, N)) * 3 + 1.5).astype(np.float32))            # a residual stream with a mean
+    dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    dY0, dY1 = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
+    ws = _lib.DeviceBuffer((M // 128) * (N // 320) * 128 * 8)
+    cnt = dev(_lib, np.zeros(8192, np.uint32))
+
+    def mk(dst, ln):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=19)
+        if res: a.resid, a.ldr = dR.ptr, N
+        if ln:
+            a.ln_y16, a.ldln, a.ln_gamma, a.ln_beta, a.ln_eps, a.ln_ws, a.ln_cnt = dY1.ptr, N, dG.ptr, dBt.ptr, 1e-5, ws.ptr, cnt.ptr
+        return a
+    a0, a1 = mk(dC0, False), mk(dC1, True)
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(a0)) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(a1)) == 1
+    kernels.gemm(a0)
+    kernels.layernorm(dC0.ptr, N, M, N, 1e-5, dG.ptr, dBt.ptr, dY0.ptr)
+    c_ref, y_ref = dC0.download((M, N), np.uint32), dY0.download((M, N), np.float16).astype(np.float32)
+    first = None
+    for rep in range(4):
+        _lib.check(L.mlsd_memset(_lib.vp(dC1.ptr), 0xff, ctypes.c_size_t(M * N * 4), None))
+        _lib.check(L.mlsd_memset(_lib.vp(dY1.ptr), 0xff, ctypes.c_size_t(M * N * 2), None))
+        kernels.gemm(a1)
+        assert np.array_equal(dC1.download((M, N), np.uint32), c_ref), rep
+        raw = dY1.download((M, N), np.uint16)
+        y = raw.view(np.float16).astype(np.float32)
+        assert np.isfinite(y).all(), rep
+        assert np.abs(y - y_ref).max() <= 2.0 ** -9 * np.maximum(1.0, np.abs(y_ref)).max(), rep      # one fp16 digit
+        assert rel(y, y_ref) < 2e-4, rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+        assert not cnt.download((8192,), np.uint32).any(), rep
+    # a launch that cannot honour the request fails instead of silently skipping the LayerNorm
+    a2 = mk(dC1, True); a2.act = kernels.ACT_SILU
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a2)
+
+
 def test_conv2d_split_k(K):
     """3x3 implicit-GEMM conv at the SD1.5 8x8-latent shape class (M=128, long K): slices start mid-(kh,kw)."""
     kernels, _lib = K

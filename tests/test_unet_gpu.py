@@ -145,6 +145,35 @@ def test_in_plan_tile_tuning_keeps_the_result():
         assert nl >= changed and len(open(path).read().splitlines()) == nl
 
 
+def test_layernorms_ended_in_their_producers_keep_the_result(monkeypatch):
+    """The headline plan (SDXL, 128x128 latent, batch 8): the out-projection / feed-forward output launches at the 1280-channel level END with the
+    LayerNorm that follows them (the 4 column tiles of a row block exchange their row statistics inside the launch).  Against the same plan with the
+    separate LayerNorm launches (MLSD_NO_LN_FOLD=1): same result to LayerNorm-rounding level, bit-repeatable, no hand-off gave up."""
+    import ctypes
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    L.mlctx_ln_fused.argtypes = [_lib.vp]; L.mlctx_handoff_check.argtypes = [_lib.vp]
+    rng = np.random.default_rng(11)
+    n, lat = 8, 128
+    monkeypatch.setenv("MLSD_NO_LN_FOLD", "1")
+    ref = engine.Unet("sdxl", lat, lat, n)
+    assert L.mlctx_ln_fused(ref.ctx.h) == 0
+    monkeypatch.delenv("MLSD_NO_LN_FOLD")
+    un = engine.Unet("sdxl", lat, lat, n)
+    assert L.mlctx_ln_fused(un.ctx.h) >= 100
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.linspace(9.0, 0.3, n).astype(np.float32)
+    a = ref.run(x, cond, label, sigma)
+    b = un.run(x, cond, label, sigma)
+    assert np.isfinite(b).all() and rel(b, a) < 1e-3
+    for _ in range(3):
+        assert np.array_equal(un.run(x, cond, label, sigma).view(np.uint32), b.view(np.uint32))
+    assert L.mlctx_handoff_check(un.ctx.h) == 0
+
+
 def test_unet_sdxl_headline_size_parity():
     """BASELINE.json's headline shape itself: ONE SDXL UNet evaluation at the 128x128 latent of a 1024x1024 image (2567.5 M
     synthetic parameters, 6.76 TFLOP) against the oracle's CPU restatement (about half a minute of host time on the
