@@ -722,8 +722,12 @@ bool ln_eligible(const mlsd_gemm_args* a)
 {
     if (!a->ln_y16 || !a->ln_gamma || !a->ln_beta || !a->ln_ws || !a->ln_cnt || a->conv || a->colstats || a->rowbias || a->bias_m || a->act != MLSD_ACT_NONE) return false;
     if (!a->C32 || a->C16 || (a->M % 128) || (a->N % 320) || (a->ldln & 7) || ((uintptr_t)a->ln_y16 & 15) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return false;
-    const long tiles = (long)(a->M / 128) * (a->N / 320);
-    return tiles <= g_gemm_ncu && a->M / 128 <= 127 && pp_eligible(a, 128, 320);      // (counters: one 128-byte line per (row block, wave row) in 8192 words)
+    // the tiles of a row block must run at the same time.  One round (tiles <= blocks): all of them do.  Several rounds on the full chip: the tile order hands the nbn
+    // tiles of a row block to blocks b, b + 8, ... of ONE round when whole rounds of 256 tiles are made of whole groups of 8 nbn tiles (nbn = 1, 2, 4)
+    const long nbn = a->N / 320, tiles = (long)(a->M / 128) * nbn;
+    const bool one_round = tiles <= g_gemm_ncu;
+    const bool whole_rounds = g_gemm_ncu == 256 && !(tiles % 256) && (nbn == 1 || nbn == 2 || nbn == 4);
+    return (one_round || whole_rounds) && a->M / 128 <= 256 && pp_eligible(a, 128, 320);      // (counters: 16 words per (row block, wave row) in 8192 words)
 }
 
 // which epilogue body a ping-pong launch of these arguments uses (gemm_pp.hpp PP_EPI_*)
@@ -1037,6 +1041,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
+    else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;
 }

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             // 4. publish (wave column 0 of each wave row), ticket, poll
             const int rbk = tcur.m0 / BM, bnk = tcur.n0 / BN, nbn = p.nbn;
             f32x2* gws = reinterpret_cast<f32x2*>(p.ln_ws) + ((long)rbk * nbn * BM);          // [tile column][128 rows]
-            unsigned* cnt = p.ln_cnt + (rbk * 2 + wr) * 32;                                    // [row block][wave row]{arrivals, departures}: one 128-byte line each
+            unsigned* cnt = p.ln_cnt + (rbk * 2 + wr) * 16;                                    // [row block][wave row]{arrivals, departures}, 64 bytes apart (8192 words: 256 row blocks)
             if (wc == 0) {
                 if (lg == 0) {
                     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gws + (long)bnk * BM), 0, BM * 8, 0x00020000);

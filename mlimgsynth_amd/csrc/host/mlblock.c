@@ -878,8 +878,11 @@ static int op_outputs(const MLOp* o, const void* out[3])
 {
 	int n = 0;
 	switch (o->kind) {
-	case OP_GEMM: if (o->u.gemm.C32) out[n++] = o->u.gemm.C32; if (o->u.gemm.C16) out[n++] = o->u.gemm.C16;
-		if (o->u.gemm.ln_y16 && n < 3) out[n++] = o->u.gemm.ln_y16; break;
+	case OP_GEMM:
+		if (o->u.gemm.C32) out[n++] = o->u.gemm.C32;
+		if (o->u.gemm.C16) out[n++] = o->u.gemm.C16;
+		if (o->u.gemm.ln_y16 && n < 3) out[n++] = o->u.gemm.ln_y16;
+		break;
 	case OP_ATTN: out[n++] = o->u.attn.out; break;
 	case OP_GN: out[n++] = o->u.gn.y16; if (o->u.gn.raw16) out[n++] = o->u.gn.raw16; break;
 	case OP_LN: if (o->u.ln.y16) out[n++] = o->u.ln.y16; if (o->u.ln.y32) out[n++] = o->u.ln.y32; break;
@@ -962,37 +965,39 @@ static void wire_ln_fold(MLCtx* C)
 {
 	const char *e = getenv("MLSD_NO_LN_FOLD");
 	if (e && *e && *e != '0') return;
-	for (int i=0;i<C->n_ops;++i) {
-		MLOp *l = &C->ops[i];
-		if (l->kind != OP_LN || !l->u.ln.y16 || l->u.ln.y32 || !l->u.ln.b) continue;
-		const int j = l->gn_src[0];
-		if (j < 0 || j >= i) continue;
-		MLOp *o = &C->ops[j];
-		mlsd_gemm_args *g = &o->u.gemm;
-		if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
-		const char *lo = (const char*)l->u.ln.x, *hi = lo + (size_t)g->M * g->ldc32 * sizeof(float);
-		int clean = 1;
-		for (int k=j+1; k<i && clean; ++k) {
-			const void *out[3];
-			const int n = op_outputs(&C->ops[k], out);
-			for (int q=0;q<n;++q) if ((const char*)out[q] >= lo && (const char*)out[q] < hi) clean = 0;
-			/* the fp16 output is written EARLIER now (by op j instead of op i): nothing in between may still read or write that buffer */
-			for (int q=0;q<n;++q) if ((const char*)out[q] >= (const char*)l->u.ln.y16 && (const char*)out[q] < (const char*)l->u.ln.y16 + (size_t)g->M * g->N * 2) clean = 0;
+	/* pass 0 sizes the scratch block (largest user), pass 1 hands the LayerNorms over */
+	for (int pass=0; pass<2; ++pass) {
+		size_t need_max = 0;
+		for (int i=1;i<C->n_ops;++i) {
+			MLOp *l = &C->ops[i];
+			if (l->kind != OP_LN || !l->u.ln.y16 || l->u.ln.y32 || !l->u.ln.b) continue;
+			const int j = l->gn_src[0];
+			if (j != i - 1) continue;                                /* adjacent ops only: the fp16 output is written one op EARLIER now, and the arena may have lent that
+			                                                          * block to something that runs in between */
+			MLOp *o = &C->ops[j];
+			mlsd_gemm_args *g = &o->u.gemm;
+			if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
+			if ((g->M % 128) || (g->N % 320)) continue;
+			const size_t need = (size_t)(g->M / 128) * (g->N / 320) * 128 * 8;
+			if (!pass) { if (need > need_max) need_max = need; continue; }
+			if (need > C->ln_ws_bytes) continue;
+			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
+			if (mlsd_gemm_ln_fused(g) == 1) { l->fused = 1; C->n_ln_fused++; }
+			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
-		if (!clean || i != j + 1) continue;                      /* (adjacent ops only: the arena may have handed the fp16 block to a reader that runs in between) */
-		if (!C->ln_cnt) {
-			if (mlsd_malloc((void**)&C->ln_cnt, 8192 * 4)) return;
-			if (mlsd_memset(C->ln_cnt, 0, 8192 * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
+		if (!pass) {
+			if (!need_max) return;
+			if (!C->ln_cnt) {
+				if (mlsd_malloc((void**)&C->ln_cnt, 8192 * 4)) return;
+				if (mlsd_memset(C->ln_cnt, 0, 8192 * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
+			}
+			if (C->ln_ws_bytes < need_max) {
+				if (C->ln_ws) mlsd_free(C->ln_ws);
+				C->ln_ws = NULL; C->ln_ws_bytes = 0;
+				if (mlsd_malloc((void**)&C->ln_ws, need_max)) return;
+				C->ln_ws_bytes = need_max; C->mem_compute += need_max;
+			}
 		}
-		const size_t need = (size_t)(g->M / 128 > 0 ? g->M / 128 : 1) * (g->N / 320 > 0 ? g->N / 320 : 1) * 128 * 8;
-		if (C->ln_ws_bytes < need) {
-			if (C->ln_ws) continue;                              /* one scratch block per plan, sized by the first (largest) user: later larger ones keep their launch */
-			if (mlsd_malloc((void**)&C->ln_ws, need)) return;
-			C->ln_ws_bytes = need; C->mem_compute += need;
-		}
-		g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
-		if (mlsd_gemm_ln_fused(g) == 1) { l->fused = 1; C->n_ln_fused++; }
-		else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 	}
 }
 

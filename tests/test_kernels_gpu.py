@@ -561,7 +561,8 @@ def test_gemm_split_k_reduced_in_the_launch(K, M, N, Kd, ksplit, variant, conv):
     assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32))
 
 
-@pytest.mark.parametrize("M,N,Kd,res", [(8192, 1280, 1280, 1), (8192, 1280, 5120, 1), (1024, 1280, 320, 0), (2048, 640, 640, 1), (4096, 320, 256, 0), (128, 1280, 192, 1)])
+@pytest.mark.parametrize("M,N,Kd,res", [(8192, 1280, 1280, 1), (8192, 1280, 5120, 1), (1024, 1280, 320, 0), (2048, 640, 640, 1), (4096, 320, 256, 0), (128, 1280, 192, 1),
+                                        (32768, 640, 640, 1), (32768, 640, 2560, 0), (16384, 1280, 320, 1)])     # two rounds of tiles (whole rounds: partner tiles share a round)
 def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
     """mlsd_gemm_args.ln_*: a single-round linear launch on the 128x320 ping-pong tile also writes LayerNorm(C32 row) * gamma + beta as fp16: the tiles of a
     row block exchange their partial row statistics inside the launch (write-through partials, ticket counter, bounded polling).  Against the same launch

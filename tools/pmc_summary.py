@@ -17,6 +17,9 @@ def label(name):
     m = re.search(r"gemm_pp_kernel<(\d+), (\d+), \d+, \d+, (?:true|false), (true|false)(?:, \d+)?(?:, (true|false))?(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
         kind = "ppsk" if m.group(4) == "true" else "pp2" if m.group(5) == "2" else "ppb" if m.group(6) == "1" else "pp"
+        epi = re.search(r"gemm_pp_kernel<\d+, \d+, \d+, \d+, (?:true|false), (?:true|false), (\d+)", name)
+        if epi and epi.group(1) in ("7", "8"):
+            return f"gemm<{m.group(1)}x{m.group(2)}x64{kind},linear+layernorm>"
         return f"gemm<{m.group(1)}x{m.group(2)}x64{kind},{'conv' if m.group(3) == 'true' else 'linear'}>"
     m = re.search(r"gemm_w4_kernel<(\d+), (\d+),", name)
     if m:
