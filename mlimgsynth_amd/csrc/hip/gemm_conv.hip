@@ -702,6 +702,21 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
+// CUs of the current device (cached per device id).  The in-launch hand-offs (stream-K, LayerNorm statistics) wait for blocks of the SAME launch: all
+// blocks of the persistent grid must be resident at once, i.e. the device must have at least g_gemm_ncu CUs (a partitioned or masked device does not).
+int device_cus()
+{
+    static int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (mlsd_runtime_is_dry() || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev != cached_dev) {
+        hipDeviceProp_t pr;
+        cached = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 0;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 // problems the ping-pong kernels take (gemm_pp.hpp); everything else asked of variants 17 / 18 runs on the LDS-transposing
 // tile of the same shape (9 / 16)
 bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
@@ -727,7 +742,7 @@ bool ln_eligible(const mlsd_gemm_args* a)
     const long nbn = a->N / 320, tiles = (long)(a->M / 128) * nbn;
     const bool one_round = tiles <= g_gemm_ncu;
     const bool whole_rounds = g_gemm_ncu == 256 && !(tiles % 256) && (nbn == 1 || nbn == 2 || nbn == 4);
-    return (one_round || whole_rounds) && a->M / 128 <= 256 && pp_eligible(a, 128, 320);      // (counters: 16 words per (row block, wave row) in 8192 words)
+    return (one_round || whole_rounds) && a->M / 128 <= 256 && pp_eligible(a, 128, 320) && device_cus() >= g_gemm_ncu;      // (counters: 16 words per (row block, wave row) in 8192 words)
 }
 
 // which epilogue body a ping-pong launch of these arguments uses (gemm_pp.hpp PP_EPI_*)
@@ -762,7 +777,7 @@ int sk_share(long ntiles, int nkt, int ncu)
 
 bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
-    if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15)) return false;
+    if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15) || device_cus() < g_gemm_ncu) return false;
     if (a->conv && a->colstats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
     const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
     const long L = sk_share(tiles, (int)nkt, g_gemm_ncu);
