@@ -394,7 +394,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         const int last = *tick;
         __syncthreads();                                                    // (the epilogue's staging space starts at smem[0])
         if (!last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (the slabs are read with agent-scope loads instead of an acquire fence: the fence alone costs microseconds, profiles/r3_ln_fold.txt)
+        const auto rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(base - lane), 0, nsl * SLAB4 * 16, 0x00020000);
         // NB slabs in flight at a time (a slab = TM TN 4 wave-loads of 1 KiB; one at a time is a chain of exposed memory latencies)
         constexpr int NR = TM * TN * 4, NB = NR <= 8 ? 4 : 2;
         for (int z0 = 0; z0 < nsl; z0 += NB) {
@@ -402,9 +403,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 if (z0 + b < nsl) {
-                    const f32x4* src = base + (long)(z0 + b) * SLAB4;
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) t[b][r] = src[r * 64];
+                    for (int r = 0; r < NR; ++r)
+                        t[b][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsl, (((z0 + b) * SLAB4 + r * 64 + lane) * 16), 0, 16));   // aux 16 = sc1
                 }
 #pragma unroll
             for (int b = 0; b < NB; ++b)

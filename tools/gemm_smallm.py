@@ -10,7 +10,8 @@ ev = [vp(), vp()]
 for e in ev: L.mlsd_event_create(ctypes.byref(e))
 rng = np.random.default_rng(0)
 ws = _lib.DeviceBuffer(128 << 20)
-flags = _lib.from_numpy(np.zeros(4096, np.uint32)) if os.environ.get('INLINE', '0') == '1' else None    # ticket counters: slices added in the launch
+flags = _lib.from_numpy(np.zeros(4096, np.uint32)) if os.environ.get('INLINE', '0') == '1' else None
+if flags is not None: L.mlsd_gemm_set_splitk_inline(1)    # ticket counters: slices added in the launch
 VARIANTS = tuple(int(v) for v in os.environ.get('VARIANTS', '1,0').split(','))          # 1: 64x128x64s2, 0: 128x128x64s2, 23 / 5: their 3-deep rings
 SHAPES = [(512, 1280, 1280), (2048, 640, 640), (8192, 320, 320), (512, 1280, 5120), (2048, 640, 2560), (128, 1280, 1280), (512, 3840, 1280),
           (2048, 1920, 640), (8192, 960, 320), (8192, 320, 1280), (128, 1280, 5120), (512, 1280, 11520), (128, 1280, 11520), (2048, 640, 5760), (8192, 320, 2880)]
