@@ -992,7 +992,7 @@ static void wire_ln_fold(MLCtx* C)
 				if (mlsd_memset(C->ln_cnt, 0, 8192 * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
 			}
 			if (C->ln_ws_bytes < need_max) {
-				if (C->ln_ws) mlsd_free(C->ln_ws);
+				if (C->ln_ws) { mlsd_free(C->ln_ws); C->mem_compute -= C->ln_ws_bytes; }
 				C->ln_ws = NULL; C->ln_ws_bytes = 0;
 				if (mlsd_malloc((void**)&C->ln_ws, need_max)) return;
 				C->ln_ws_bytes = need_max; C->mem_compute += need_max;
