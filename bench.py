@@ -82,7 +82,7 @@ def kernel_roofline(g, workload, B):
     # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
     traffic, traffic_src, mfma_busy = None, None, None
     for kind in ("traffic", "mfma"):
-        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r3", "r2", "r1")) if os.path.exists(p_)), "")
+        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r4", "r3", "r2", "r1")) if os.path.exists(p_)), "")
         if not pmc:
             continue
         try:
@@ -117,12 +117,13 @@ def eval_mfma(agg):
             "by_family": {k: {"share": round(t / tot_ms, 3), "tflops": round(fl / (t * 1e-3) / 1e12, 1)} for k, (t, fl) in top}}
 
 
-def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps):
+def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, batch=0):
     """A secondary workload of the BASELINE metric on the same GPU (after the headline's timed region): `steps` timed steps
     (text encode + denoise + decode) after one warm-up; returns {value, ms_per_step, unet_eval_ms, roofline, ...}."""
     import numpy as np
     import torch
     model, width, height, B = WORKLOADS[workload]
+    B = batch or B
     g = engine.Generator(model, width, height, B, n_step=denoise_steps, cfg_scale=cfg, s_ancestral=1.0, use_tae=tae,
                          use_hipgraph=(workload == "sd15"), weight_seed=1234)
     tc = text.TextConditioner(model, width, height, seed=1234)
@@ -151,7 +152,7 @@ def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps):
            "unet_eval_ms": round(um / (steps * denoise_steps), 3), "tflop_per_image": round(flop_per_img / 1e12, 3),
            "job_tflops": round(value * flop_per_img / 1e12, 1),
            "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
-           "roofline": roof, "unet_eval_mfma": eval_mfma(agg)}
+           "roofline": roof, "unet_eval_mfma": eval_mfma(agg), "tile_table_misses": g.unet_ctx().tune_misses()}
     aux = {"plist": g.unet_ctx().param_list(), "unet_flops_b1": info["unet_flops"] / (2 * B if cfg > 1 else B), "flop_per_img": flop_per_img}
     g.destroy()
     return res, aux
@@ -297,6 +298,7 @@ def main():
     roof, agg, ms = kernel_roofline(g, a.workload, B)
     out["roofline"] = roof
     out["unet_eval_mfma"] = eval_mfma(agg)
+    out["tile_table_misses"] = g.unet_ctx().tune_misses()     # GEMM shapes of this plan not in the compiled-in tile table (0 on the bench plans)
     if a.kernel_table:
         with open(a.kernel_table, "w") as f:
             f.write(f"# one UNet evaluation, {a.workload} batch {B} (N={2 * B if a.cfg > 1 else B}); per-launch HIP events\n")
@@ -311,9 +313,12 @@ def main():
     aux15 = None
     if extras:
         g.destroy()
-        for key, wl, tae_ in (("sd15", "sd15", False), ("sdxl_tae", "sdxl", True)):
+        # sdxl_b8 = ONE RANK's share of BASELINE configs[3] (8 GPUs x 8 images: the batch-16 UNet plan): the per-GPU number the
+        # 8-GPU job multiplies, measured on this GPU with its own roofline
+        for key, wl, tae_, b_, st_ in (("sd15", "sd15", False, 0, a.extra_steps), ("sdxl_tae", "sdxl", True, 0, a.extra_steps),
+                                       ("sdxl_b8", "sdxl", False, 8, min(a.extra_steps, 2))):
             try:
-                out[key], aux = run_extra(engine, text, Lh, _lib, wl, tae_, a.extra_steps, a.cfg, a.denoise_steps)
+                out[key], aux = run_extra(engine, text, Lh, _lib, wl, tae_, st_, a.cfg, a.denoise_steps, batch=b_)
                 if key == "sd15":
                     aux15 = aux
             except Exception as e:
@@ -326,7 +331,7 @@ def main():
             s_per_nfe, nfe = cpu_sample(model, width, height, a.cfg, a.denoise_steps, threads, a.cpu_nfe, plist)
             unet_flops_1 = info["unet_flops"] / (2 * B if a.cfg > 1 else B)
             s_per_img = s_per_nfe * (flop_per_img / unet_flops_1)      # decode priced at the UNet's measured FLOP rate
-            out["cpu_baseline"] = {"value": round(1.0 / s_per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
+            out["cpu_baseline"] = {"value": round(1.0 / s_per_img, 6), "unit": "images/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
                                    "s_per_unet_eval": round(s_per_nfe, 3),
                                    "sample": f"{nfe} of {nfe_per_img} batch-1 UNet evaluations of one {a.workload} image "
                                              f"(oracle/, fp32 CPU restatement of the reference path, OpenMP {threads} threads), "

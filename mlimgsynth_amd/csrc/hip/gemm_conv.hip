@@ -776,10 +776,10 @@ int sk_share(long ntiles, int nkt, int ncu)
     return nkt;
 }
 
-bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN)
+bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN, bool ignore_stats = false)
 {
     if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15) || device_cus() < g_gemm_ncu) return false;
-    if (a->conv && a->colstats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
+    if (a->conv && a->colstats && !ignore_stats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
     const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
     const long L = sk_share(tiles, (int)nkt, g_gemm_ncu);
     return nkt >= 3 && L >= 4 && L < nkt && a->ws_bytes >= (size_t)g_gemm_ncu * BM * BN * sizeof(float);    // (L == nkt: nothing to split)
@@ -903,6 +903,8 @@ const Variant kVariants[] = {
     {"256x128x64pp2", 256, 128, 256},   // 25: ping-pong tile for NARROW outputs (N = 128: the VAE's full-resolution convolutions), wave 128 x 32, two phases per K tile (16 MFMAs per section)
     {"256x256x64w4", 256, 256, 256},    // 26: ONE wave per SIMD (4 waves of 128 x 128, accumulators in AGPRs, software-pipelined inside the wave): gemm_w4.hip
     {"128x320x64w4", 128, 320, 256},    // 27: the same on the 128 x 320 tile (4 waves of 64 x 160)
+    {"128x320x64ppsk", 128, 320, 256},  // 28: variant 18 as STREAM-K (round 4): N = 320 / 640 / 1280 outputs with FEW tiles and long K -- the 3x3 convolutions of SD1.5 batch 1
+                                        //     (8192x320x2880: 64 tiles, 2048x640x5760: 32, 512x1280x11520: 16) -- dealt over all 256 CUs in K-tile units
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -964,6 +966,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 19:
         if (sk_eligible(a, 256, 256)) return launch_pp<256, 256, 2, 2, false, true>(a, st);
         return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 28:
+        if (sk_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, true>(a, st);
+        [[fallthrough]];
     case 18:
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
@@ -1026,8 +1031,12 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     if (!a || !a->colstats) return 0;
     const int v = pick_variant(a);
     int bm, bn;
+    /* a stream-K convolution has no statistics epilogue: handing it a GroupNorm's statistics would silently turn it into the plain 256 x 256 launch (round 3 shipped
+     * exactly that: 24 tiles on 256 CUs, SD1.5's 2048x640x17280 at 366 us).  It keeps its tile; the GroupNorm keeps its first pass. */
+    if (v == 19 && a->conv && sk_eligible(a, 256, 256, true)) return 0;
+    if (v == 28 && a->conv && sk_eligible(a, 128, 320, true)) return 0;
     if ((v == 17 || v == 19 || v == 21 || v == 26) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }   // (26 never takes a launch that has colstats set: it runs as 17)
-    else if ((v == 18 || v == 20 || v == 22 || v == 27) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+    else if ((v == 18 || v == 20 || v == 22 || v == 27 || v == 28) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
     else if (v == 25 && pp_eligible(a, 256, 128)) { bm = 256; bn = 128; }
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
@@ -1049,6 +1058,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     static thread_local char buf[64];
     int v = pick_variant(a);
     if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
+    if (v == 28 && !sk_eligible(a, 128, 320)) v = 18;
     if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;

@@ -767,12 +767,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     };
     auto sk_gather = [&](int end_k) __attribute__((always_inline)) {   // owner of an unfinished tile: add the slabs of the blocks holding K tiles end_k .. nkt-1
         if constexpr (SK) {
+            // Round 4: ALL contributors' flags first, then the slabs GB at a time per accumulator row group.  The first form walked the slabs one by one (flag, barrier,
+            // 2 RA rounds of NCB loads each waiting for the previous): 4 exposed memory round trips per slab, ~4 us each -- with 5..14 contributors per tile (the small-M,
+            // long-K convolutions of SD1.5: 2048x640x5760, 512x1280x11520) the gather was longer than the K loop.  Here a row group costs ceil(nc / GB) round trips for all slabs.
+            // The order of the additions per accumulator is unchanged (owner's part, then contributors in block order): results are bit-identical to the first form.
+            if constexpr (BM == 256) {
+            // (256 x 256 tile: 128 accumulator registers leave no room for a second slab in flight -- the batched form below spills 84..136 bytes per lane there -- so it keeps
+            // the slab-by-slab walk; its launches have 2..3 contributors per tile)
             int c = skw + 1;
             for (int rem = nkt - end_k; rem > 0; rem -= p.sk_L, ++c) {
                 if (tid == 0) {
-                    unsigned spins = 0;                            // bounded: a lost contribution must not hang the device; the give-up is REPORTED through the
-                    // sticky word sk_flag[4095], which the host reads with the results (mlctx_handoff_check): a contributor block that is not resident (CUs taken
-                    // by another process) would otherwise turn into a silently wrong tile
+                    unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flag + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
                     if (spins >= (1u << 22)) __hip_atomic_store(p.sk_flag + 4095, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -794,6 +799,53 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                         for (int cc = 0; cc < NCB; ++cc) acc[a][i][cc] += t[cc];
                         __builtin_amdgcn_sched_barrier(0);
                     }
+            }
+            } else {
+            const int nc = (nkt - end_k + p.sk_L - 1) / p.sk_L;        // contributors: blocks skw + 1 .. skw + nc
+            if (tid < nc && tid < 64) {
+                unsigned spins = 0;                                // bounded: a lost contribution must not hang the device; the give-up is REPORTED through the
+                // sticky word sk_flag[4095], which the host reads with the results (mlctx_handoff_check): a contributor block that is not resident (CUs taken
+                // by another process) would otherwise turn into a silently wrong tile
+                while (__hip_atomic_load(p.sk_flag + skw + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+                if (spins >= (1u << 22)) __hip_atomic_store(p.sk_flag + 4095, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sk_flag + skw + 1 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one consumer per flag: clear it for the next launch
+            }
+            for (int c = 64; c < nc; ++c) {                        // (more than 64 contributors per tile: never chosen by sk_share's >= 4 K tiles per block on real shapes, but correct)
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.sk_flag + skw + 1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+                    if (spins >= (1u << 22)) __hip_atomic_store(p.sk_flag + 4095, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sk_flag + skw + 1 + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            // the slabs are read with agent-scope (sc1) loads: they were written through by blocks of other XCDs (no acquire fence: invalidating the caches of 8 waves costs more)
+            constexpr int GB = 4;                                                  // slabs in flight per row group: GB * NCB float4 beside the accumulators
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_ws + (long)(skw + 1) * (BM * BN)), 0, 0x7fffffff, 0x00020000);
+            const int lofs = (wave * (2 * RA * NCB) * 64 + lane) * 16;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    for (int c0 = 0; c0 < nc; c0 += GB) {
+                        f32x4 t[GB][NCB];
+#pragma unroll
+                        for (int b = 0; b < GB; ++b) {
+                            const int cs = min(c0 + b, nc - 1);           // (past the last slab: re-read it, never added)
+#pragma unroll
+                            for (int cc = 0; cc < NCB; ++cc)
+                                t[b][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lofs + ((a * RA + i) * NCB + cc) * 64 * 16, cs * (BM * BN * 4), 16));
+                        }
+#pragma unroll
+                        for (int b = 0; b < GB; ++b) {
+                            if (c0 + b < nc) {
+#pragma unroll
+                                for (int cc = 0; cc < NCB; ++cc) acc[a][i][cc] += t[b][cc];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     };

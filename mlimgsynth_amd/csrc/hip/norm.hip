@@ -275,6 +275,82 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnP p, float* __restric
     }
 }
 
+// ONE-DISPATCH GroupNorm for small maps (round 4): SD1.5 batch 1 is bound by its dispatch count (~4.5 us per dependent dispatch, 498 per evaluation), and on
+// the 8x8 .. 32x32 levels an (image, group) slab is 10..80 KB.  One block per (image, group) holds its slab in registers (each element read ONCE), takes the mean
+// and the centred sum of squares with two block reductions (fixed order: deterministic, and better conditioned than single-pass sums), normalises and stores.
+// A slab row is cg*4 bytes of one pixel (160 B at C = 1280), so this form is for cg % 4 == 0 and slabs of <= GN1_MAXI float4 per thread; the two-kernel form
+// keeps everything else (its 1024 blocks stream the big maps better than 64 blocks can: measured in round 2).
+constexpr int GN1_MAXI = 20;      // float4 per thread: slabs of up to 256 * 20 * 4 = 20480 elements
+__global__ __launch_bounds__(256) void gn_small_kernel(const GnP p)
+{
+    __shared__ float red[8];
+    const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Q4 = p.cg >> 2, items = p.HW * Q4, c0 = g * p.cg;
+    float4 v[GN1_MAXI];
+    // all loads first, unconditionally (clamped item index: a branch per load would serialise them behind one s_waitcnt each -- the first version of this
+    // kernel took 13 us for an 80 KB slab that way); NI = the trips this slab needs (block-uniform)
+    const int NI = (items + 255) >> 8;
+#pragma unroll
+    for (int i = 0; i < GN1_MAXI; ++i) {
+        if (i < NI) {
+            const int it = min(tid + i * 256, items - 1);
+            const int pix = it / Q4, c = c0 + 4 * (it - pix * Q4);
+            v[i] = *reinterpret_cast<const float4*>(gn_src(p, img, pix, c));
+        } else v[i] = make_float4(0, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN1_MAXI; ++i) {
+        const bool in = tid + i * 256 < items;
+        s += in ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float cnt = (float)p.cg * (float)p.HW;
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN1_MAXI; ++i) {
+        if (tid + i * 256 < items) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[4 + wave] = s2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / cnt + p.eps);
+#pragma unroll
+    for (int i = 0; i < GN1_MAXI; ++i) {
+        const int it = tid + i * 256;
+        if (it < items) {
+            const int pix = it / Q4, c = c0 + 4 * (it - pix * Q4);
+            const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c), be = *reinterpret_cast<const float4*>(p.beta + c);
+            float y0 = (v[i].x - mean) * rstd * ga.x + be.x, y1 = (v[i].y - mean) * rstd * ga.y + be.y;
+            float y2 = (v[i].z - mean) * rstd * ga.z + be.z, y3 = (v[i].w - mean) * rstd * ga.w + be.w;
+            if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+            const long o = ((long)img * p.HW + pix) * p.C + c;
+            f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+            *reinterpret_cast<f16x4*>(p.y16 + o) = h;
+            if (p.raw16) {
+                f16x4 r = {(_Float16)v[i].x, (_Float16)v[i].y, (_Float16)v[i].z, (_Float16)v[i].w};
+                *reinterpret_cast<f16x4*>(p.raw16 + o) = r;
+            }
+        }
+    }
+}
+
+int g_gn_single = -1;     // -1: not decided (environment MLSD_GN_SINGLE, default on), 0 / 1
+bool gn_single_ok(int n_img, int HW, int C, int n_grp)
+{
+    if (g_gn_single < 0) { const char* e = getenv("MLSD_GN_SINGLE"); g_gn_single = (e && *e == '0') ? 0 : 1; }
+    if (!g_gn_single || n_grp <= 0 || C % n_grp) return false;
+    const int cg = C / n_grp;
+    // few images only: with n_img * n_grp >= 256 blocks of the two-kernel form already fill the chip, and big batches are not dispatch-bound
+    return !(cg & 3) && (long)HW * (cg >> 2) <= 256L * GN1_MAXI && n_img * n_grp <= 128;
+}
+
 // pixel chunks per image: enough blocks (n_img * chunks ~ 1024) to occupy 256 CUs at batch 1, down to ONE pixel per block
 // on the 8x8 / 16x16 maps of the UNet's inner levels (a block walks its pixels serially, one memory round trip per
 // 4-pixel trip: with 16-pixel chunks those maps ran 8 blocks x 4 dependent trips)
@@ -501,6 +577,10 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
     const bool from_producers = a->cs1 && a->rb_rows1 > 0 && !(a->HW % a->rb_rows1) &&
                                 (a->C2 == 0 || (a->cs2 && a->rb_rows2 > 0 && !(a->HW % a->rb_rows2)));
     int rc;
+    if (gn_single_ok(a->n_img, a->HW, C, a->n_grp) && !from_producers && !((uintptr_t)a->gamma & 15) && !((uintptr_t)a->beta & 15)) {
+        hipLaunchKernelGGL(gn_small_kernel, dim3(p.G, a->n_img), dim3(256), 0, (hipStream_t)stream, p);
+        return mlsd_check_launch("gn_small_kernel");
+    }
     if (from_producers) {
         hipLaunchKernelGGL(gn_finalize, dim3(p.G, a->n_img), dim3(256), 0, (hipStream_t)stream, p, p.ws);
         rc = mlsd_check_launch("gn_finalize");
@@ -513,6 +593,11 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
     hipLaunchKernelGGL(gn_apply, grid, dim3(256), (size_t)C * 2 * sizeof(float), (hipStream_t)stream, p);
     return mlsd_check_launch("gn_apply");
 }
+
+/* 1 if mlsd_groupnorm runs these dimensions as ONE dispatch (slab of an (image, group) held in registers): the plan builder then leaves the producers' column
+ * statistics off for this GroupNorm (finalize + apply would be two dispatches) */
+MLSD_API int mlsd_groupnorm_single_pass(int n_img, int HW, int C, int n_grp) { return gn_single_ok(n_img, HW, C, n_grp) ? 1 : 0; }
+MLSD_API void mlsd_groupnorm_set_single(int on) { g_gn_single = on ? 1 : 0; }   /* diagnostics / A-B timing */
 
 MLSD_API int mlsd_layernorm(const float* x, int64_t ldx, int rows, int d, float eps, const float* gamma,
                             const float* beta, void* y16, float* y32, void* stream)

@@ -594,6 +594,7 @@ static int autotune_on(void)
 
 MLB_API void mlctx_set_autotune(int on) { g_autotune = on ? 1 : 0; }
 MLB_API int mlctx_tune_misses(void) { return g_tune_miss; }
+MLB_API int mlctx_plan_tune_misses(const MLCtx* C) { return C ? C->n_tune_miss : 0; }   /* GEMM shapes of THIS plan the table does not list */
 
 static TuneKey tune_key(const mlsd_gemm_args* g)
 {
@@ -653,7 +654,9 @@ static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
 	return 0;
 }
 
-#define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile */
+#define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile (256 x 256) */
+#define VARIANT_STREAMK2 29     /* the same on the 128 x 320 tile (round 4) */
+#define IS_STREAMK(v) ((v) == VARIANT_STREAMK || (v) == VARIANT_STREAMK2)
 #define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile */
 static int streamk_get(MLCtx* C, mlsd_gemm_args* g)
 {	/* slabs in the split-K workspace (ops run one at a time on the plan's stream) + the plan's flag words (zero between launches:
@@ -677,7 +680,7 @@ static int select_gemm(MLCtx* C, MLOp* op)
 		g->tile_variant = best; g->ksplit = ks;
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
 		if (g->ksplit > 1 && streamk_get(C, g)) return -1;
-		if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
+		if (IS_STREAMK(best) && streamk_get(C, g)) return -1;
 		return 1;
 	}
 	g->tile_variant = 0; g->ksplit = 1;
@@ -715,7 +718,12 @@ static int gemm_candidates(MLCtx* C, mlsd_gemm_args* g, int cv[32], int cs[32])
 			const long t256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256);
 			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
 		}
-		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) { cv[nc]=18; cs[nc++]=1; cv[nc]=20; cs[nc++]=1; }   /* four / two phases per K tile */
+		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) {
+			cv[nc]=18; cs[nc++]=1; cv[nc]=20; cs[nc++]=1;   /* four / two phases per K tile */
+			/* stream-K on that tile: few tiles (not whole rounds of the 256 blocks) and K long enough to deal out */
+			const long t320 = (long)((g->M + 127) / 128) * ((g->N + 319) / 320);
+			if (t320 % 256 && t320 < 256 && t320 * (g->K / 64) >= 256 * 4 && !streamk_get(C, g)) { cv[nc]=28; cs[nc++]=1; }
+		}
 		/* (the narrow 256x128 ping-pong tile, variant 25, is NOT a candidate: it wins this warm, back-to-back timing on the VAE's N = 128
 		 * convolutions (+9..16 %) and loses in the plan (-16 %, profiles/r3_gemm_narrow_tile.txt): those launches are bound by their fp32
 		 * output + residual traffic, which two co-resident blocks overlap with each other's K loops and one persistent block cannot) */
@@ -757,7 +765,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		if (tune_lookup(&k, &best, &ks)) {
 			g->tile_variant = best; g->ksplit = ks;
 			if (g->ksplit > 1 && streamk_get(C, g)) return -1;
-			if (best == VARIANT_STREAMK && streamk_get(C, g)) return -1;
+			if (IS_STREAMK(best) && streamk_get(C, g)) return -1;
 			return 1;
 		}
 	}
@@ -829,7 +837,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 			const int c = r < sh[j].nc ? r : 0;
 			mlsd_gemm_args *g = &C->ops[i].u.gemm;
 			g->tile_variant = sh[j].cv[c] + 1; g->ksplit = sh[j].cs[c];
-			if ((g->ksplit > 1 || g->tile_variant == VARIANT_STREAMK) && streamk_get(C, g)) goto done;
+			if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant)) && streamk_get(C, g)) goto done;
 		}
 		for (int j=0;j<ns;++j) if (r < sh[j].nc) sh[j].t[r] = 1e30;
 		for (int rep=0; rep<reps+1; ++rep) {             /* (the first pass warms the instruction caches of this round's kernels) */
@@ -861,7 +869,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 		if (j < 0) continue;
 		mlsd_gemm_args *g = &C->ops[i].u.gemm;
 		g->tile_variant = sh[j].k.best; g->ksplit = sh[j].k.ksplit;
-		if ((g->ksplit > 1 || g->tile_variant == VARIANT_STREAMK) && streamk_get(C, g)) { changed = -1; break; }
+		if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant)) && streamk_get(C, g)) { changed = -1; break; }
 	}
 done:
 	free(sh); free(op_shape); free(ms);
@@ -936,6 +944,7 @@ static void wire_gn_stats(MLCtx* C)
 		if (C->ops[i].kind != OP_GN) continue;
 		mlsd_gn_args *g = &C->ops[i].u.gn;
 		const int64_t rows = (int64_t)g->n_img * g->HW;
+		if (mlsd_groupnorm_single_pass(g->n_img, g->HW, g->C1 + g->C2, g->n_grp)) continue;      /* one dispatch, reads x once: nothing to gain from producer statistics */
 		MLOp *p1 = gn_producer(C, i, 0, g->x1, g->ld1, g->C1, rows);
 		MLOp *p2 = g->C2 ? gn_producer(C, i, 1, g->x2, g->ld2, g->C2, rows) : NULL;
 		if (!p1 || (g->C2 && !p2)) continue;

@@ -139,6 +139,12 @@ class MLCtx:
         check1(L().mlctx_profile_ops(self.h, fptr(ms), n), "mlctx_profile_ops")
         return ms
 
+    def tune_misses(self):
+        """GEMM shapes of this plan that the compiled-in tile table does not list (they run on the static rule)."""
+        f = L().mlctx_plan_tune_misses
+        f.argtypes = [vp]
+        return int(f(self.h))
+
     def compute(self):
         check1(L().mlctx_compute(self.h), "mlctx_compute")
 

@@ -126,7 +126,7 @@ def test_hip_unet_bench_plan_sdxl_batch8_vs_independent_golden(slot):
     sig = r.uniform(0.1, 14.0, n).astype(np.float32)
     x[slot], cond[slot], label[slot], sig[slot] = x1[0], c1[0], l1[0], 3.0
     un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
-    print("tile-table misses so far:", engine.L().mlctx_tune_misses())
+    assert un.ctx.tune_misses() == 0, "a GEMM of bench.py's SDXL plan is not in the tile table (static rule used)"
     got = un.run(x, cond, label, sig)
     assert np.isfinite(got).all()
     e = rel(got[slot], HEAD[key][0])
@@ -149,9 +149,36 @@ def test_hip_unet_bench_plan_sd15_batch2_hipgraph_vs_independent_golden(slot):
     st = _lib.vp()
     _lib.check(_lib.lib().mlsd_stream_create(ctypes.byref(st)), "stream")     # (stream capture is not permitted on the NULL stream)
     un = engine.Unet(model, lat, lat, n, stream=st.value, seed=G.WEIGHT_SEED, flags=8)      # MLB_F_HIPGRAPH: what bench.py --workload sd15 replays
+    assert un.ctx.tune_misses() == 0, "a GEMM of bench.py's SD1.5 plan is not in the tile table (static rule used)"
     got = un.run(x, cond, None, sig)
     again = un.run(x, cond, None, sig)                                      # second call = graph replay
     assert np.array_equal(got, again)
     e = rel(got[slot], HEAD[key][0])
     print(key, "batch 2 hipGraph, slot", slot, e)
     assert e < TOL
+
+
+# ---- BASELINE configs[3]: 8 GPUs x 8 images.  One rank's workload is 8 images x cond/uncond = the BATCH-16 SDXL plan
+# (M = 16384 / 65536 / 262144 rows: other tile-table rows again), with the reference's batch semantic (N independent
+# generations, /root/reference/generate.sh:56-59).  The N > 1 RCCL run itself is the driver's; what one GPU can
+# prove is that the per-rank plan is built, is served by the tile table, and reproduces the independent vector in every slot.
+def test_hip_unet_config3_per_rank_plan_sdxl_batch16_vs_independent_golden():
+    from mlimgsynth_amd import engine
+    key, model, lat, n = "unet_sdxl_128", "sdxl", 128, 16
+    slots = (0, 7, 15)
+    x1, c1, l1 = G.unet_inputs(key, model, lat, 1)
+    r = np.random.default_rng(3000)
+    x = (r.standard_normal((n, 4, lat, lat)) * 3).astype(np.float32)
+    cond = r.standard_normal((n, 77, c1.shape[2])).astype(np.float32)
+    label = r.standard_normal((n, l1.shape[1])).astype(np.float32)
+    sig = r.uniform(0.1, 14.0, n).astype(np.float32)
+    for s in slots:
+        x[s], cond[s], label[s], sig[s] = x1[0], c1[0], l1[0], 3.0
+    un = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
+    assert un.ctx.tune_misses() == 0, "a GEMM of the per-rank batch-16 plan is not in the tile table (static rule used)"
+    got = un.run(x, cond, label, sig)
+    assert np.isfinite(got).all()
+    errs = [rel(got[s], HEAD[key][0]) for s in slots]
+    print(key, "batch 16, slots", slots, errs)
+    assert max(errs) < TOL
+    assert np.array_equal(got[slots[0]], got[slots[1]]) and np.array_equal(got[slots[0]], got[slots[2]])     # bits do not depend on the slot

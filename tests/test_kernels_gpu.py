@@ -350,6 +350,114 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
+# ---- stream-K on the 128 x 320 tile (round 4, tile variant 28): the few-tile, long-K launches of SD1.5 batch 1 (N = 320 / 640 / 1280)
+SK320_CASES = [(8192, 320, 2880, 0), (2048, 640, 5760, 1), (512, 1280, 11520, 1), (128, 1280, 11520, 0), (512, 1280, 1280, 2), (1024, 960, 4096, 3), (2048, 640, 2560, 1)]
+
+
+@pytest.mark.parametrize("M,N,Kd,mode", SK320_CASES)
+def test_gemm_stream_k_128x320_matches_plain_pingpong_tile(K, M, N, Kd, mode):
+    """Variant 28 against the same tile without stream-K (18) and the exact product: 3 to 45 contributors per tile (the owner reads the slabs of ALL
+    its contributors in batches of 4 per accumulator row group, added in block order); fp32 / fp32 + residual / fp16 / bias + SiLU epilogues; repeated launches
+    give the same bits and leave every flag cleared."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(M + Kd + mode)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA, dW, dR, dB = dev(_lib, A), dev(_lib, W), dev(_lib, R), dev(_lib, bias)
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = _lib.DeviceBuffer(4096 * 4)
+    _lib.check(L.mlsd_memset(_lib.vp(fl.ptr), 0, ctypes.c_size_t(4096 * 4), None))
+    dC = _lib.DeviceBuffer(M * N * 4)
+    def mk(v):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, conv=0, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, tile_variant=v + 1, ws=ws.ptr, ws_bytes=ws.nbytes,
+                             sk_flags=fl.ptr)
+        if mode == 2: a.C16, a.ldc16 = dC.ptr, N
+        else: a.C32, a.ldc32 = dC.ptr, N
+        if mode == 1: a.resid, a.ldr = dR.ptr, N
+        if mode == 3: a.bias, a.act = dB.ptr, kernels.ACT_SILU
+        return a
+    exact = A.astype(np.float32) @ W.astype(np.float32).T
+    if mode == 1: exact = exact + R
+    if mode == 3: exact = (exact + bias) / (1 + np.exp(-(exact + bias)))
+    dt = np.float16 if mode == 2 else np.float32
+    tol = 1e-3 if mode == 2 else 3e-5
+    kernels.gemm(mk(18))
+    ref = dC.download((M, N), dt).astype(np.float32)
+    assert rel(ref, exact) < tol
+    assert "128x320x64ppsk" in kernels.gemm_variant(mk(28))
+    first = None
+    for rep in range(5):
+        _lib.check(L.mlsd_memset(_lib.vp(dC.ptr), 0x7C, ctypes.c_size_t(M * N * 4), None))
+        kernels.gemm(mk(28))
+        raw = dC.download((M, N), dt)
+        got = raw.astype(np.float32)
+        assert np.isfinite(got).all() and rel(got, exact) < tol, rep
+        assert np.abs(got - ref).max() < (2e-2 if mode == 2 else 1e-3) * max(1.0, np.abs(ref).max()), rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+        assert not fl.download((4096,), np.uint32).any(), rep           # every flag consumed and cleared (the sticky give-up word included)
+
+
+def test_gemm_stream_k_128x320_rows_do_not_depend_on_their_tile(K):
+    """Same property as the 256 x 256 stream-K: every tile is cut at the same K positions, so an image's rows give the same bits in any batch slot."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(78)
+    Kd, N, reps = 5760, 640, 6
+    A0 = rng.standard_normal((256, Kd)).astype(np.float16)
+    A = np.ascontiguousarray(np.tile(A0, (reps, 1)))
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    M = A.shape[0]
+    dC = _lib.DeviceBuffer(M * N * 4)
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = dev(_lib, np.zeros(4096, np.uint32))
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=29, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr)
+    assert "128x320x64ppsk" in kernels.gemm_variant(a)
+    kernels.gemm(a)
+    out = dC.download((reps, 256, N), np.uint32)
+    for r in range(1, reps):
+        assert np.array_equal(out[r], out[0]), r
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [(2, 64, 64, 320, 320, True), (2, 32, 32, 640, 640, False), (2, 16, 16, 1280, 1280, True), (2, 8, 8, 2560, 1280, False)])
+def test_conv2d_stream_k_128x320(K, n, h, w, cin, cout, res):
+    """The 3x3 convolutions of SD1.5 batch 1 (both images of the cfg pair) as stream-K on the 128 x 320 tile, against the plain tile."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(h + cin)
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin))
+    dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    dW = dev(_lib, repack_conv_w(wt, cin).astype(np.float16))
+    M = n * h * w
+    R = rng.standard_normal((M, cout)).astype(np.float32)
+    dR = dev(_lib, R)
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = _lib.DeviceBuffer(4096 * 4)
+    _lib.check(L.mlsd_memset(_lib.vp(fl.ptr), 0, ctypes.c_size_t(4096 * 4), None))
+    outs = {}
+    for v in (18, 28):
+        dC = _lib.DeviceBuffer(M * cout * 4)
+        a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=h, OW=w, KH=3, KW=3, stride=1, pad=1, W_=dW.ptr,
+                             ldb=9 * cin, M=M, N=cout, K=9 * cin, C32=dC.ptr, ldc32=cout, tile_variant=v + 1, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr)
+        if res: a.resid, a.ldr = dR.ptr, cout
+        assert ("ppsk" in kernels.gemm_variant(a)) == (v == 28)
+        for rep in range(3):
+            kernels.gemm(a)
+            o = dC.download((M, cout), np.float32)
+            assert rep == 0 or np.array_equal(o, outs[v])
+            outs[v] = o
+    assert rel(outs[28], outs[18]) < 1e-5 and np.abs(outs[28] - outs[18]).max() < 1e-3
+    assert not fl.download((4096,), np.uint32).any()
+
+
 @pytest.mark.parametrize("mode,pp", [(m, pp) for pp in (17, 18, 20, 21, 22, 25, 26, 27) for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
                                      if not (pp in (18, 20, 22, 25, 27) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
