@@ -117,7 +117,7 @@ def eval_mfma(agg):
             "by_family": {k: {"share": round(t / tot_ms, 3), "tflops": round(fl / (t * 1e-3) / 1e12, 1)} for k, (t, fl) in top}}
 
 
-def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, batch=0):
+def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, batch=0, split=0):
     """A secondary workload of the BASELINE metric on the same GPU (after the headline's timed region): `steps` timed steps
     (text encode + denoise + decode) after one warm-up; returns {value, ms_per_step, unet_eval_ms, roofline, ...}."""
     import numpy as np
@@ -125,7 +125,7 @@ def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, 
     model, width, height, B = WORKLOADS[workload]
     B = batch or B
     g = engine.Generator(model, width, height, B, n_step=denoise_steps, cfg_scale=cfg, s_ancestral=1.0, use_tae=tae,
-                         use_hipgraph=(workload == "sd15"), weight_seed=1234)
+                         use_hipgraph=(workload == "sd15" and not split), weight_seed=1234, unet_split=split)
     tc = text.TextConditioner(model, width, height, seed=1234)
     prompt = np.random.default_rng(7).integers(0, 49405, 8).astype(np.int32)
     pp = prompt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
@@ -153,6 +153,13 @@ def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, 
            "job_tflops": round(value * flop_per_img / 1e12, 1),
            "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
            "roofline": roof, "unet_eval_mfma": eval_mfma(agg), "tile_table_misses": g.unet_ctx().tune_misses()}
+    si = g.unet_ctx().streaming_info()
+    if si:      # BASELINE configs[4]: the reference's --unet-split (weights streamed from pinned host memory through two device slabs, every evaluation)
+        nseg, per_eval, slab, host = si
+        evals_per_s = (steps * denoise_steps) / (um / 1e3) if um > 0 else 0.0
+        res["weight_streaming"] = {"segments": nseg, "slab_mib": slab >> 20, "host_master_mib": host >> 20, "streamed_mib_per_eval": per_eval >> 20,
+                                   "h2d_gb_per_s_sustained": round(per_eval * evals_per_s / 1e9, 1),
+                                   "unet_params_on_device_mib": int(g.unet_ctx().info().mem_params) >> 20}
     aux = {"plist": g.unet_ctx().param_list(), "unet_flops_b1": info["unet_flops"] / (2 * B if cfg > 1 else B), "flop_per_img": flop_per_img}
     g.destroy()
     return res, aux
@@ -316,9 +323,11 @@ def main():
         # sdxl_b8 = ONE RANK's share of BASELINE configs[3] (8 GPUs x 8 images: the batch-16 UNet plan): the per-GPU number the
         # 8-GPU job multiplies, measured on this GPU with its own roofline
         for key, wl, tae_, b_, st_ in (("sd15", "sd15", False, 0, a.extra_steps), ("sdxl_tae", "sdxl", True, 0, a.extra_steps),
-                                       ("sdxl_b8", "sdxl", False, 8, min(a.extra_steps, 2))):
+                                       ("sdxl_b8", "sdxl", False, 8, min(a.extra_steps, 2)),
+                                       # configs[4] as the reference runs it: TAESD decode + --unet-split (UNet weights streamed, not resident)
+                                       ("sdxl_tae_split", "sdxl", True, 0, min(a.extra_steps, 2))):
             try:
-                out[key], aux = run_extra(engine, text, Lh, _lib, wl, tae_, st_, a.cfg, a.denoise_steps, batch=b_)
+                out[key], aux = run_extra(engine, text, Lh, _lib, wl, tae_, st_, a.cfg, a.denoise_steps, batch=b_, split=1 if key == "sdxl_tae_split" else 0)
                 if key == "sd15":
                     aux15 = aux
             except Exception as e:

@@ -48,7 +48,20 @@ void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
-int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K) of this plan gave up waiting since the last check: results invalid */
+int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K, LayerNorm statistics) of this plan gave up waiting since the last check: results
+                                        * invalid; the flag / counter blocks are zeroed again before the error is returned */
+/* WEIGHT STREAMING (the reference's --unet-split, src/unet.c:390-458; BASELINE configs[4]): the plan's weights live in pinned host memory and pass through two device
+ * slabs of slab_bytes each (0 = 512 MiB), uploaded segment by segment under the previous segment's launches.  Call before the graph is built; excludes MLB_F_HIPGRAPH.
+ * Results are bit-identical to the resident plan. */
+int    mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes);
+int    mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes);   /* 0: the plan does not stream */
+void   mlctx_set_cus(MLCtx* C, int n);   /* CUs the plan's stream may use (CU-masked stream); < 256: the plan is built without in-launch hand-offs.  Before mlctx_prep */
+int    mlctx_ln_alias_refused(const MLCtx* C);
+int    mlctx_handoff_ops(const MLCtx* C);   /* launches of the plan that hand data over inside the launch (0: nothing to check) */
+int    mlctx_handoffs_off(MLCtx* C);        /* the plan without in-launch hand-offs (plain tiles, separate LayerNorm launches); returns the ops changed; one-way */
+int    mlctx_compute_checked(MLCtx* C);     /* compute + (if the plan has hand-offs) drain, check, and ONE re-run on the hand-off-free plan after a give-up */
+int    mlctx_handoff_retries(void);         /* evaluations / generations re-run on the hand-off-free plan in this process */
+int    mlctx_debug_raise_giveup(MLCtx* C, int what);   /* test hook: raise the sticky word as a timed-out launch would (0 stream-K, 1 LayerNorm) */
 int    mlctx_ln_fused(const MLCtx* C);  /* number of LayerNorms of the plan that run at the END of their producers' launches (mlsd_gemm_args.ln_*; MLSD_NO_LN_FOLD=1: none) */
 /* GEMM tile selection is a pure function of the shape (compiled-in table, csrc/host/tune_table.inc), so every process
  * runs the same kernels in the same summation order.  mlctx_set_autotune(1) (or MLSD_AUTOTUNE=1) turns on the OFFLINE

@@ -256,6 +256,8 @@ typedef struct {
 	float s_noise;           /* stochastic sampling noise level (src/sampling.c:139-151) */
 	float f_t_ini, f_t_end;  /* relative initial / final time: 0,0 -> 1,0 (txt2img); f_t_ini < 1 = img2img */
 	int defer_weights;       /* 1: do not synthesise weights: the caller loads them (mlctx_param_set on the *_ctx handles) */
+	int unet_split;          /* > 0: the UNet's weights are STREAMED (the reference's --unet-split / MLIS_OPT_UNET_SPLIT, src/unet.c:390-458): master copy in pinned host
+	                          * memory, two device slabs of `unet_split` MiB each (1 = the default 512 MiB) filled under the launches; excludes use_hipgraph */
 } MLIS_AmdConfig;
 
 /* progress callback (MLIS_Callback, include/mlimgsynth.h:405): called after every COMPLETED step (the stream is
@@ -297,6 +299,9 @@ int mlis_amd_set_vae_tile(MLIS_AmdCtx* S, int tile_px);
 MLCtx* mlis_amd_decoder_tile_prepare(MLIS_AmdCtx* S);
 MLCtx* mlis_amd_encoder_tile_prepare(MLIS_AmdCtx* S);                            /* build the encoder plan now (weights: synth or caller-loaded) */
 int mlis_amd_last_n_step(MLIS_AmdCtx* S);
+/* passes (denoising loop, decode, encode) that were run AGAIN on the hand-off-free plan after an in-launch hand-off (stream-K slab, LayerNorm statistics) timed out --
+ * the GPU was shared or the stream CU-masked.  The call that hit it still succeeds; results then come from plain tiles / separate LayerNorm launches. */
+int mlis_amd_handoff_retries(const MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */
 int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device; asynchronous */

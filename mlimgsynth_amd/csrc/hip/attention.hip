@@ -710,6 +710,7 @@ __global__ __launch_bounds__(256, WPS) void attn_tk96_kernel(const AttnP p, cons
 }
 
 
+#ifdef MLSD_GEMM_EXPERIMENTS   /* built, correct and SLOWER than the tile-loop kernels (profiles/NOTES.md "ping-pong attention"): kept reproducible, not in the product build */
 // ---------------------------------------------------------------------------------------------------------------------
 // d_head = 64, no causal mask: the PING-PONG kernel.
 //   PMC on the kernels above: matrix pipes busy 28-39 % + vector ALU ~55 % ~ 94 %: a wave's QK^T -> softmax -> P.V chain runs
@@ -1043,13 +1044,16 @@ __global__ __launch_bounds__(512, WPS) void attn64pp_kernel(const AttnP p)
             }
     }
 }
+#endif  // MLSD_GEMM_EXPERIMENTS
 
 int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_kernel
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
+#ifdef MLSD_GEMM_EXPERIMENTS
 int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity with the tile-loop kernels; off by default): 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
+#endif
 int g_attn_tk96 = 1;        // Tk <= 96 without a causal mask: the one-pass kernel (0 = the general kernels; A/B timing)
 int g_attn_tk96_qb = 0;     // query blocks of 128 rows per workgroup (0 = by the launch size)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
@@ -1088,8 +1092,9 @@ int launch_attn(const mlsd_attn_args* a, hipStream_t st)
 }
 
 
-int g_attn_pp_prio = 0, g_attn_pp_dbg = 0;
 unsigned long long* g_attn_tbuf = nullptr;
+#ifdef MLSD_GEMM_EXPERIMENTS
+int g_attn_pp_prio = 0, g_attn_pp_dbg = 0;
 template <int NB, int WPS>
 int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
 {
@@ -1107,6 +1112,7 @@ int launch_attn64pp(const mlsd_attn_args* a, hipStream_t st)
     else hipLaunchKernelGGL((attn64pp_kernel<NB, WPS, 0>), grid, dim3(512), 0, st, p);
     return mlsd_check_launch("attn64pp_kernel");
 }
+#endif
 
 template <int DH>
 int launch_attn_tk96(const mlsd_attn_args* a, hipStream_t st)
@@ -1154,6 +1160,7 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
     case 32: return launch_attn<32>(a, st);
     case 40: return launch_attn<40>(a, st);
     case 64:
+#ifdef MLSD_GEMM_EXPERIMENTS
         if (g_attn_pp && !g_attn_force_old && !a->causal && !(a->Tq & 255) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) &&
             (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30)) {
             const bool big = !(a->Tq & 511) && a->Tq >= 2048;
@@ -1161,6 +1168,7 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
             if (g_attn_pp == 4) return launch_attn64pp<1, 2>(a, st);
             return launch_attn64pp<1, 4>(a, st);
         }
+#endif
         // every q/k/v row must be 16-byte aligned for the LDS-DMA pieces (strides are multiples of 8 halfs: checked above)
         if (!g_attn_force_old && !a->causal && a->Tq >= g_attn_x2_min_tq && !(a->Tq & 255) &&
             !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15)) return launch_attn64x2(a, st);
@@ -1175,7 +1183,11 @@ MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
+#ifdef MLSD_GEMM_EXPERIMENTS
 MLSD_API void mlsd_attention_pp(int mode) { g_attn_pp = mode & 15; g_attn_pp_prio = (mode >> 4) & 3; g_attn_pp_dbg = (mode >> 8) & 3; }
+#else
+MLSD_API void mlsd_attention_pp(int mode) { (void)mode; }       /* the ping-pong attention kernel is not in the product build (make EXPERIMENTS=1) */
+#endif
 MLSD_API void mlsd_attention_set_trace(void* buf) { g_attn_tbuf = (unsigned long long*)buf; }   /* 8 waves x 16 tiles x 5 stamps of block 0 */
 MLSD_API void mlsd_attention_tk96(int on, int qb) { g_attn_tk96 = on; g_attn_tk96_qb = qb; }
 

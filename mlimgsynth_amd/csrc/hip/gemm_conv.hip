@@ -365,6 +365,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // that draws the last ticket adds ALL slabs of the tile in slice order 0, 1, ... (its own included, re-read: the sum does not
     // depend on which block came last -> bit-reproducible and equal to the two-launch form) and runs the epilogue.  Saves the
     // second launch (~6 us on an SD1.5-sized problem, where it is a third of the GEMM) and its round trip through HBM.
+#ifdef MLSD_GEMM_EXPERIMENTS
     if (p.sk_L > 1) {
         const int nsl = p.sk_L;
         constexpr int SLAB4 = BM * BN / 4;                                  // float4 per slab
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 }
         }
     }
+#endif  // MLSD_GEMM_EXPERIMENTS (split-K reduced in the launch)
 
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = lr  (probe-verified map)
     const bool geglu = p.act == MLSD_ACT_GEGLU;
@@ -671,7 +673,8 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     p.ws_stride = 0;
     GemmP pe = p;                                  // the epilogue as requested (second pass of a split-K launch)
     // reduced inside the launch: one counter per output tile (a->sk_flags, 4096 words, zero between launches), one slab per (tile, slice)
-    const bool inl = nsplit > 1 && g_gemm_sk_inline && a->sk_flags && (long)p.nbm * p.nbn <= 4096 && !((uintptr_t)a->ws & 15) &&
+    const bool inl = nsplit > 1 && g_gemm_sk_inline && a->sk_flags && (long)p.nbm * p.nbn <= 4095 &&        /* (word 4095 is the sticky give-up indicator of the stream-K hand-offs) */
+                     !((uintptr_t)a->ws & 15) &&
                      a->ws_bytes >= (size_t)nsplit * p.nbm * p.nbn * BM * BN * sizeof(float);
     if (inl) { p.sk_L = nsplit; p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags; }
     else if (nsplit > 1) {
@@ -707,7 +710,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
 // blocks of the persistent grid must be resident at once, i.e. the device must have at least g_gemm_ncu CUs (a partitioned or masked device does not).
 int device_cus()
 {
-    static int cached_dev = -1, cached = 0;
+    static thread_local int cached_dev = -1, cached = 0;     // (per thread: MLCtx objects are used from several threads)
     int dev = 0;
     if (mlsd_runtime_is_dry() || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (dev != cached_dev) {
@@ -870,8 +873,13 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
 }
 
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
+#ifdef MLSD_GEMM_EXPERIMENTS
 extern "C" int mlsd_gemm_w4_eligible(const mlsd_gemm_args* a, int tile);    // gemm_w4.hip (tile 0: 256 x 256, 1: 128 x 320)
 extern "C" int mlsd_gemm_w4(const mlsd_gemm_args* a, int tile, void* stream, int ncu);
+#else   /* the one-wave-per-SIMD tiles (variants 26 / 27) are not in the product build: the variants run as the ping-pong tile of the same shape */
+static int mlsd_gemm_w4_eligible(const mlsd_gemm_args*, int) { return 0; }
+static int mlsd_gemm_w4(const mlsd_gemm_args*, int, void*, int) { return -1; }
+#endif
 
 struct Variant { const char* name; int bm, bn, slots; };
 const Variant kVariants[] = {
@@ -977,11 +985,19 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, false, 2>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
+#ifdef MLSD_GEMM_EXPERIMENTS   /* measured and not adopted (profiles/NOTES.md): the re-balanced staging schedule, the narrow 256x128 ping-pong tile */
     case 22:
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, false, 4, 1>(a, st);
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
     case 25: return pp_eligible(a, 256, 128) ? launch_pp<256, 128, 1, 1, false, false, 2>(a, st) : launch<256, 128, 64, 4, 2, 2>(a, st);
+#else
+    case 22:
+        if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
+    case 25: return launch<256, 128, 64, 4, 2, 2>(a, st);
+#endif
     case 21: return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false, false, 2>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
     case 16:
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: tile variant 16 (odd slab count) does not support GEGLU");
@@ -1010,7 +1026,21 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+#ifdef MLSD_GEMM_EXPERIMENTS
 MLSD_API void mlsd_gemm_set_splitk_inline(int on) { g_gemm_sk_inline = on != 0; }
+#else
+MLSD_API void mlsd_gemm_set_splitk_inline(int on) { (void)on; }      /* measured slower (profiles/NOTES.md): the code path is not in the product build */
+#endif
+/* 1 if the library was built with -DMLSD_GEMM_EXPERIMENTS (variants that lost their study: one-wave tiles, narrow / re-balanced ping-pong tiles, split-K reduced in
+ * the launch, ping-pong attention); their tests skip otherwise */
+MLSD_API int mlsd_has_experiments(void)
+{
+#ifdef MLSD_GEMM_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 MLSD_API void mlsd_gemm_set_cus(int n) { g_gemm_ncu = n > 0 && n <= 256 ? n : 256; }
 /* diagnostics: device buffer of 8 x uint64 per block (256 blocks) that the ping-pong kernels fill with s_memtime stamps:
  * [0] kernel entry, [1] prologue done, [2] first epilogue begins, [3] first epilogue issued, [4] last epilogue begins,
@@ -1037,7 +1067,9 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
     if (v == 28 && a->conv && sk_eligible(a, 128, 320, true)) return 0;
     if ((v == 17 || v == 19 || v == 21 || v == 26) && pp_eligible(a, 256, 256)) { bm = 256; bn = 256; }   // (26 never takes a launch that has colstats set: it runs as 17)
     else if ((v == 18 || v == 20 || v == 22 || v == 27 || v == 28) && pp_eligible(a, 128, 320)) { bm = 128; bn = 320; }
+#ifdef MLSD_GEMM_EXPERIMENTS
     else if (v == 25 && pp_eligible(a, 256, 128)) { bm = 256; bn = 128; }
+#endif
     else return 0;
     const int e = pp_epilogue_kind(a, bn);
     return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
@@ -1063,7 +1095,12 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
     if ((v == 18 || v == 20 || v == 22) && !pp_eligible(a, 128, 320)) v = 16;
+#ifdef MLSD_GEMM_EXPERIMENTS
     if (v == 25 && !pp_eligible(a, 256, 128)) v = 3;
+#else
+    if (v == 25) v = 3;
+    if (v == 22) v = 18;
+#endif
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);

@@ -162,7 +162,7 @@ MLB_API int clip_encoder_run_ex(ClipEncoder* E, unsigned n_used, const int* n_to
 	float *tmp = NULL;
 	const size_t ne = (size_t)n_used * NT * d;
 	if (mlctx_input_set(C, E->t_tokens, tokens, sizeof(int32_t)*NT*n_prompt) < 0) { R = -1; goto end; }
-	if (mlctx_compute(C) < 0) { R = -1; goto end; }
+	if (mlctx_compute_checked(C) < 0) { R = -1; goto end; }
 	tmp = (float*)malloc((size_t)n_prompt * NT * d * 4);
 	if (mlctx_output_get(C, E->t_embed, tmp, (size_t)n_prompt*NT*d*4) < 0) { R = -1; goto end; }
 	if (embed) memcpy(embed, tmp, ne*4);

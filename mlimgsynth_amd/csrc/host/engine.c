@@ -38,6 +38,8 @@ struct MLIS_AmdCtx {
 	MLTensor *t_lat_dec, *t_img_enc;
 	/* device state */
 	float *d_x;                 /* latent [B][4][hw] NCHW fp32 */
+	float *d_xsave;             /* copy of a caller-given initial latent while the denoising loop may have to be re-run (hand-off retry) */
+	int n_handoff_retries;      /* denoise / decode / encode passes re-run on the hand-off-free plan after a timed-out in-launch hand-off */
 	float *d_xin;               /* what the UNet plan reads (1 MB d2d copy per evaluation; keeps the plan independent of the solver) */
 	float *d_dx;                /* dxdt */
 	float *d_tmp[N_TMP];        /* solver state vectors (solver_tmp_get, solvers.c:54-76) */
@@ -79,7 +81,7 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	if (S->dect_ctx) mlctx_destroy(S->dect_ctx);
 	if (S->enct_ctx) mlctx_destroy(S->enct_ctx);
 	mlsd_free(S->d_lat_tile); mlsd_free(S->d_img_tile); mlsd_free(S->d_imgin_tile); mlsd_free(S->d_mom_tile); mlsd_free(S->d_mom);
-	mlsd_free(S->d_xin);
+	mlsd_free(S->d_xin); mlsd_free(S->d_xsave);
 	mlsd_free(S->d_x); mlsd_free(S->d_dx); mlsd_free(S->d_x0); mlsd_free(S->d_lmask); mlsd_free(S->d_img); mlsd_free(S->d_img_in);
 	for (int i=0;i<N_TMP;++i) mlsd_free(S->d_tmp[i]);
 	mlsd_free(S->d_cin); mlsd_free(S->d_noise); mlsd_free(S->d_nan);
@@ -156,7 +158,9 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 
 	/* ---- UNet plan, x bound to the resident evaluation point (c_in scaling + cond/uncond duplication in the gather) */
 	S->unet_ctx = mlctx_new(stream);
-	if (S->c.use_hipgraph) mlctx_set_flags(S->unet_ctx, MLB_F_HIPGRAPH);
+	if (S->c.unet_split > 0) {     /* --unet-split: the UNet's weights are streamed through two slabs (mlblock.c "weight streaming"); one evaluation = one pass over them */
+		if (mlctx_set_weight_streaming(S->unet_ctx, S->c.unet_split > 1 ? (size_t)S->c.unet_split << 20 : 0) < 0) goto err;
+	} else if (S->c.use_hipgraph) mlctx_set_flags(S->unet_ctx, MLB_F_HIPGRAPH);
 	if (unet_denoise_init_n(&S->unet, S->unet_ctx, &S->unet_p, S->lw, S->lh, N) < 0) goto err;
 	if (mlctx_input_bind(S->unet.t_x, S->d_xin, B, S->d_cin, 1.0f, 0) < 0) { fail("input bind failed"); goto err; }
 	if (unet_denoise_build(&S->unet) < 0) goto err;
@@ -347,7 +351,7 @@ static int dxdt_finish(MLIS_AmdCtx* S, const float* x_eval, float sigma, float* 
 	return mlsd_dxdt_cfg(eps, ld, x_eval, dx, S->B, 4, S->hw, S->c.cfg_scale, S->unet_p.vparam, c_out, c_skip, S->stream) ? -1 : 1;
 }
 
-MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
+static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 {
 	if (!S->cond_set) return fail("mlis_amd_denoise: conditioning not set");
 	const UnetParams *P = &S->unet_p;
@@ -469,7 +473,7 @@ MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 	}
 	int32_t nan_count = 0;
 	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;
-	if (mlctx_handoff_check(S->unet_ctx) < 0) return -1;                     /* a stream-K hand-off of the plan gave up waiting: results invalid */
+	if (mlctx_handoff_check(S->unet_ctx) < 0) return -8;                     /* an in-launch hand-off of the plan gave up waiting: results invalid (mlis_amd_denoise retries) */
 	float tot = 0;
 	for (int i=0; i<S->i_eval; ++i) { float ms = 0; mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &ms); tot += ms; }
 	S->last_unet_ms = tot;
@@ -477,6 +481,34 @@ MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 	S->have_init_latent = 0;                /* f_t_ini / latent use flags are cleared after a generation (mlimgsynth.c:700-706) */
 	if (nan_count) return mlsd_set_error(-7 /* MLIS_E_NAN */, "NaN found in UNet output (%d values)", nan_count);
 	return 1;
+}
+
+/* The denoising loop with ONE retry on the hand-off-free plan: a timed-out in-launch hand-off (stream-K slab, LayerNorm statistics: a partner block
+ * was not resident -- CUs shared with another process, CU-masked stream) is detected when the results are read back; the loop is deterministic in (initial latent,
+ * Philox states, conditioning), so those are kept and the whole loop runs again with plain tiles and separate LayerNorm launches.  Never by restarting the process. */
+MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
+{
+	if (seeds) mlis_amd_seed(S, seeds);
+	const int guard = mlctx_handoff_ops(S->unet_ctx) > 0;
+	const int had_init = S->have_init_latent;
+	const size_t xbytes = (size_t)S->B * 4 * S->hw * 4;
+	RngPhilox keep[MAX_BATCH];
+	if (guard) {
+		memcpy(keep, S->rng, sizeof(S->rng[0]) * (size_t)S->B);
+		if (had_init) {
+			if (!S->d_xsave && mlsd_malloc((void**)&S->d_xsave, xbytes)) return -1;
+			if (mlsd_memcpy(S->d_xsave, S->d_x, xbytes, 2, S->stream)) return -1;
+		}
+	}
+	int r = denoise_once(S, NULL);
+	if (r != -8 || !guard) return r;
+	mlctx_handoffs_off(S->unet_ctx);
+	S->n_handoff_retries++;
+	memcpy(S->rng, keep, sizeof(S->rng[0]) * (size_t)S->B);
+	S->have_init_latent = had_init;
+	if (had_init && mlsd_memcpy(S->d_x, S->d_xsave, xbytes, 2, S->stream)) return -1;
+	r = denoise_once(S, NULL);
+	return r == -8 ? -1 : r;
 }
 
 /* ------------------------------------------------------------------ VAE tiling
@@ -599,10 +631,35 @@ static int encode_tiled(MLIS_AmdCtx* S)
 	return 1;
 }
 
+/* after the launches of a decode / encode were enqueued: if the plan hands data over inside launches, drain and check; 1 = clean, 0 = gave up -> the plan is now
+ * hand-off-free and the caller runs its launches again, < 0 = error */
+static int handoffs_clean(MLIS_AmdCtx* S, MLCtx* C, int attempt)
+{
+	if (!mlctx_handoff_ops(C) && !attempt) return 1;
+	if (mlsd_stream_sync(S->stream)) return -1;
+	if (mlctx_handoff_check(C) == 0) return 1;
+	if (attempt) return -1;
+	mlctx_handoffs_off(C);
+	S->n_handoff_retries++;
+	return 0;
+}
+
 MLB_API int mlis_amd_decode(MLIS_AmdCtx* S)
 {
-	if (S->vae_tile > 0 && !S->c.use_tae && mlis_amd_decoder_tile_prepare(S)) return decode_tiled(S);
-	if (mlctx_compute(S->dec_ctx) < 0) return -1;
+	if (S->vae_tile > 0 && !S->c.use_tae && mlis_amd_decoder_tile_prepare(S)) {
+		for (int attempt=0; attempt<2; ++attempt) {
+			if (decode_tiled(S) < 0) return -1;
+			const int ok = handoffs_clean(S, S->dect_ctx, attempt);
+			if (ok) return ok;
+		}
+		return -1;
+	}
+	for (int attempt=0; ; ++attempt) {
+		if (mlctx_compute(S->dec_ctx) < 0) return -1;
+		const int ok = handoffs_clean(S, S->dec_ctx, attempt);
+		if (ok < 0) return -1;
+		if (ok) break;
+	}
 	int64_t ld = 0;
 	MLTensor *r = mlctx_result(S->dec_ctx);
 	const float *y = mlctx_tensor_device_f32(S->dec_ctx, r, &ld);
@@ -649,13 +706,19 @@ MLB_API int mlis_amd_encode(MLIS_AmdCtx* S, const float* images, int sample)
 	if (mlsd_memcpy(S->d_img_in, images, img_elems*4, 0, st)) return -1;
 	if (mlsd_memset(S->d_nan, 0, 4, st)) return -1;
 	const float *y; int64_t ld = 0;
-	if (tiled) {
-		if (encode_tiled(S) < 0) return -1;
-		y = NULL;
-	} else {
-		if (mlctx_compute(S->enc_ctx) < 0) return -1;
-		y = mlctx_tensor_device_f32(S->enc_ctx, mlctx_result(S->enc_ctx), &ld);
-		if (mlsd_count_nonfinite(y, (size_t)B*S->hw*ld, S->d_nan, st)) return -1;
+	for (int attempt=0; ; ++attempt) {            /* (second pass only after a timed-out in-launch hand-off: the plan is hand-off-free then) */
+		if (attempt && mlsd_memset(S->d_nan, 0, 4, st)) return -1;
+		if (tiled) {
+			if (encode_tiled(S) < 0) return -1;
+			y = NULL;
+		} else {
+			if (mlctx_compute(S->enc_ctx) < 0) return -1;
+			y = mlctx_tensor_device_f32(S->enc_ctx, mlctx_result(S->enc_ctx), &ld);
+			if (mlsd_count_nonfinite(y, (size_t)B*S->hw*ld, S->d_nan, st)) return -1;
+		}
+		const int ok = handoffs_clean(S, tiled ? S->enct_ctx : S->enc_ctx, attempt);
+		if (ok < 0) return -1;
+		if (ok) break;
 	}
 	if (S->c.use_tae) {
 		if (mlsd_nhwc_to_nchw_f32(y, ld, B, 4, S->hw, S->d_x, 1.0f, 0.0f, st)) return -1;
@@ -684,9 +747,10 @@ MLB_API int mlis_amd_generate(MLIS_AmdCtx* S, const uint64_t* seeds, float* late
 	if (mlis_amd_decode(S) < 0) return -1;
 	if (images_out && mlsd_memcpy(images_out, S->d_img, (size_t)S->B*3*S->c.width*S->c.height*4, 1, S->stream)) return -1;
 	if (mlsd_stream_sync(S->stream)) return -1;
-	if (mlctx_handoff_check(S->dec_ctx) < 0) return -1;
 	return 1;
 }
+
+MLB_API int mlis_amd_handoff_retries(const MLIS_AmdCtx* S) { return S->n_handoff_retries; }   /* denoise / decode / encode passes re-run on the hand-off-free plan */
 
 MLB_API int mlis_amd_sync(MLIS_AmdCtx* S) { return mlsd_stream_sync(S->stream) ? -1 : 1; }
 MLB_API void* mlis_amd_latent_device(MLIS_AmdCtx* S) { return S->d_x; }

@@ -19,6 +19,12 @@
 #define BIG_BYTES     ((size_t)8 << 20)
 #define ALIGN_UP(x,a) (((x) + (a) - 1) / (a) * (a))
 
+#define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile (256 x 256) */
+#define VARIANT_STREAMK2 29     /* the same on the 128 x 320 tile (round 4) */
+#define IS_STREAMK(v) ((v) == VARIANT_STREAMK || (v) == VARIANT_STREAMK2)
+#define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile; word 4095: sticky give-up */
+#define LN_CNT_WORDS 8192       /* LayerNorm fold: arrival / departure counters per (row block, wave row); word 8191: sticky give-up */
+
 #define VEC_PUSH(C, arr, n, cap, T) \
 	(((n) == (cap) ? ((cap) = (cap) ? (cap)*2 : 64, (arr) = (T*)realloc((arr), sizeof(T)*(cap))) : 0), &(arr)[(n)++])
 
@@ -47,6 +53,7 @@ MLB_API MLCtx* mlctx_new(void* stream)
 }
 
 static void ctx_reset_(MLCtx* C);
+static void wstream_free(MLCtx* C);
 static void ctx_reset(MLCtx* C)
 {	/* memory handed out by the dry runtime is host memory: release it the same way even if the mode changed since */
 	const int was = mlsd_runtime_is_dry();
@@ -71,9 +78,11 @@ static void ctx_reset_(MLCtx* C)
 	if (C->sk_flags) { mlsd_free(C->sk_flags); C->sk_flags = NULL; }
 	if (C->ln_cnt) { mlsd_free(C->ln_cnt); C->ln_cnt = NULL; }
 	if (C->ln_ws) { mlsd_free(C->ln_ws); C->ln_ws = NULL; C->ln_ws_bytes = 0; }
+	wstream_free(C);
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
+	C->n_ln_fused = 0; C->n_ln_alias = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->epb, 0, sizeof(C->epb));
 	memset(&C->info, 0, sizeof(C->info));
@@ -105,11 +114,18 @@ MLB_API void mlctx_set_wtype(MLCtx* C, int t) { C->wtype = t; }
 MLB_API MLTensor* mlctx_result(MLCtx* C) { return C->result; }
 MLB_API int mlctx_sync(MLCtx* C) { return mlsd_stream_sync(C->stream) ? -1 : 1; }
 
-MLB_API int mlctx_ln_fused(const MLCtx* C) { return C ? C->n_ln_fused : 0; }   /* LayerNorms of the plan that run at the end of their producers' launches */
+MLB_API int mlctx_ln_fused(const MLCtx* C) { return C ? C->n_ln_fused : 0; }
+MLB_API int mlctx_ln_alias_refused(const MLCtx* C) { return C ? C->n_ln_alias : 0; }   /* LayerNorm folds refused because the fp16 rows would have overwritten an operand of their producer */
+/* CUs the plan's stream may use (a CU-masked stream, a partitioned device); 0 = the whole device.  Below 256 the plan is built without in-launch hand-offs
+ * (stream-K, LayerNorm fold): their blocks wait for partners that a masked stream may never make resident.  Call before mlctx_prep. */
+MLB_API void mlctx_set_cus(MLCtx* C, int n) { if (C) C->cu_budget = n; }   /* LayerNorms of the plan that run at the end of their producers' launches */
 
-/* Stream-K launches hand partial tiles over inside the launch; an owner block that gives up waiting (bounded spin: a contributor never became resident,
- * e.g. the CUs are shared with another process) raises a sticky word beside the flags.  Called by the drivers where they read their results back:
- * 0 = clean, < 0 = at least one hand-off of this plan timed out since the last check (the word is cleared). */
+/* Stream-K launches hand partial tiles over inside the launch, LayerNorm-ending launches exchange row statistics; a block that gives up waiting (bounded spin: a
+ * partner never became resident, e.g. the CUs are shared with another process or the stream is CU-masked) raises a sticky word beside the flags.  Called by the drivers
+ * where they read their results back: 0 = clean, < 0 = at least one hand-off of this plan timed out since the last check.
+ * After a give-up the per-block flags / arrival and departure counters are whatever the timed-out launch left (a late contributor sets a flag its owner no longer
+ * clears; a late tile leaves (arrivals, departures) = (1, 1)): the NEXT launch would consume a stale slab or stale statistics without raising the word again.
+ * So on a give-up the stream is drained and BOTH blocks are zeroed entirely before the error is returned. */
 MLB_API int mlctx_handoff_check(MLCtx* C)
 {
 	if (!C) return 0;
@@ -117,10 +133,77 @@ MLB_API int mlctx_handoff_check(MLCtx* C)
 	if (C->sk_flags && (mlsd_memcpy(&w, C->sk_flags + 4095, 4, 1, C->stream) || mlsd_stream_sync(C->stream))) return -1;
 	if (C->ln_cnt && (mlsd_memcpy(&w2, C->ln_cnt + 8191, 4, 1, C->stream) || mlsd_stream_sync(C->stream))) return -1;
 	if (!w && !w2) return 0;
-	if (w) mlsd_memset(C->sk_flags + 4095, 0, 4, C->stream);
-	if (w2) mlsd_memset(C->ln_cnt + 8191, 0, 4, C->stream);
+	mlsd_stream_sync(C->stream);
+	if (C->sk_flags) mlsd_memset(C->sk_flags, 0, SK_FLAG_WORDS * 4, C->stream);
+	if (C->ln_cnt) mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream);
+	mlsd_stream_sync(C->stream);
 	return mlsd_set_error(-8, "an in-launch hand-off (%s) timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid",
 	                      w ? "stream-K" : "LayerNorm statistics");
+}
+
+/* number of ops of the plan that hand data over inside a launch (stream-K tiles, LayerNorms ended in their producers): 0 = nothing to check */
+MLB_API int mlctx_handoff_ops(const MLCtx* C)
+{
+	int n = 0;
+	if (!C || !C->prepared) return 0;
+	for (int i=0;i<C->n_ops;++i) {
+		const MLOp *o = &C->ops[i];
+		if (o->kind != OP_GEMM) continue;
+		if (o->u.gemm.ln_y16 || (IS_STREAMK(o->u.gemm.tile_variant) && o->u.gemm.sk_flags)) ++n;
+	}
+	return n;
+}
+
+/* The plan without its in-launch hand-offs: stream-K launches lose their flag words, so the launcher runs them on the plain tile of the same shape
+ * (mlsd_gemm: sk_eligible fails); LayerNorms that were ended in their producers get their own launch back (the op and its output buffer were kept).  A captured
+ * hipGraph is dropped (the next compute captures the new launches).  Results change in the last bits (other fp32 summation order in the former stream-K tiles).
+ * Returns the number of ops changed.  One-way: a context that timed out once stays on the hand-off-free plan. */
+static int g_handoff_retries = 0;
+MLB_API int mlctx_handoff_retries(void) { return g_handoff_retries; }
+
+MLB_API int mlctx_handoffs_off(MLCtx* C)
+{
+	int n = 0;
+	if (!C || !C->prepared) return 0;
+	mlsd_stream_sync(C->stream);
+	for (int i=0;i<C->n_ops;++i) {
+		MLOp *o = &C->ops[i];
+		if (o->kind != OP_GEMM) continue;
+		mlsd_gemm_args *g = &o->u.gemm;
+		if (g->ln_y16) {
+			g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL;
+			if (i + 1 < C->n_ops && C->ops[i+1].kind == OP_LN && C->ops[i+1].fused) { C->ops[i+1].fused = 0; C->n_ln_fused--; }
+			++n;
+		}
+		if (IS_STREAMK(g->tile_variant) && g->sk_flags) { g->sk_flags = NULL; ++n; }
+	}
+	if (n && C->graph_exec) { mlsd_graph_destroy(C->graph_exec); C->graph_exec = NULL; }
+	return n;
+}
+
+/* mlctx_compute for callers that read the result back right away (the builder-level run functions): compute, and if the plan has in-launch hand-offs, drain the
+ * stream and check them; after a give-up the evaluation is run AGAIN in the same process on the hand-off-free plan (counted: mlctx_handoff_retries), and only a
+ * failure of that second run is an error. */
+MLB_API int mlctx_compute_checked(MLCtx* C)
+{
+	if (mlctx_compute(C) < 0) return -1;
+	if (!mlctx_handoff_ops(C)) return 1;
+	if (mlsd_stream_sync(C->stream)) return -1;
+	if (mlctx_handoff_check(C) == 0) return 1;
+	mlctx_handoffs_off(C);
+	g_handoff_retries++;
+	C->static_valid = 0;                                     /* (the step-invariant ops may have been hit too) */
+	if (mlctx_compute(C) < 0 || mlsd_stream_sync(C->stream)) return -1;
+	return mlctx_handoff_check(C) == 0 ? 1 : -1;
+}
+
+/* test hook: raise the sticky give-up word as a timed-out launch would (what = 0: stream-K flags, 1: LayerNorm counters) */
+MLB_API int mlctx_debug_raise_giveup(MLCtx* C, int what)
+{
+	const unsigned v = 0xDEADu;
+	if (what == 0 && C->sk_flags) return mlsd_memcpy(C->sk_flags + 4095, &v, 4, 0, C->stream) || mlsd_stream_sync(C->stream) ? -1 : 1;
+	if (what == 1 && C->ln_cnt) return mlsd_memcpy(C->ln_cnt + 8191, &v, 4, 0, C->stream) || mlsd_stream_sync(C->stream) ? -1 : 1;
+	return 0;
 }
 
 /* ------------------------------------------------------------------ device memory */
@@ -159,6 +242,18 @@ static void* dalloc_ex(MLCtx* C, size_t nbytes, int is_param, int writer_op)
 }
 
 void* mlctx_dalloc(MLCtx* C, size_t nbytes, int is_param) { return dalloc_ex(C, nbytes, is_param, 0x7fffffff); }
+
+static int is_virtual(const MLCtx* C, const void* p) { return C->pstream && (const char*)p >= MLW_VBASE && (const char*)p < MLW_VBASE + C->pv_size; }
+
+void* mlctx_walloc(MLCtx* C, size_t nbytes)
+{
+	if (!C->pstream || C->pstream_hold) return dalloc_ex(C, nbytes, 1, 0x7fffffff);
+	nbytes = ALIGN_UP(nbytes ? nbytes : 256, 256);
+	MLWAlloc *a = VEC_PUSH(C, C->pv_allocs, C->n_pv, C->cap_pv, MLWAlloc);
+	a->voff = C->pv_size; a->bytes = nbytes;
+	C->pv_size += nbytes;
+	return MLW_VBASE + a->voff;
+}
 
 void mlctx_drelease(MLCtx* C, void* p, size_t nbytes)
 {
@@ -350,8 +445,8 @@ MLParam* mlctx_param_new_at(MLCtx* C, const char* name, int type, int64_t n0, in
 	}
 	p->dev_elems = elems;
 	const size_t esz = type == MLT_F16 ? 2 : 4;
-	p->dev = dev ? dev : mlctx_dalloc(C, elems * esz, 1);
-	if (p->dev && layout == 1 && p->lp[4] != n2) mlsd_memset(p->dev, 0, elems * esz, C->stream);
+	p->dev = dev ? dev : mlctx_walloc(C, elems * esz);
+	if (p->dev && layout == 1 && p->lp[4] != n2 && !is_virtual(C, p->dev)) mlsd_memset(p->dev, 0, elems * esz, C->stream);   /* (the host master copy of streamed weights starts zeroed) */
 	MLNameRec *r = VEC_PUSH(C, C->names, C->n_names, C->cap_names, MLNameRec);
 	r->kind = 2; r->name = strdup(name); r->param = C->n_params - 1;
 	return &C->params[C->n_params - 1];
@@ -654,10 +749,6 @@ static int splitk_ws_get(MLCtx* C, mlsd_gemm_args* g)
 	return 0;
 }
 
-#define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile (256 x 256) */
-#define VARIANT_STREAMK2 29     /* the same on the 128 x 320 tile (round 4) */
-#define IS_STREAMK(v) ((v) == VARIANT_STREAMK || (v) == VARIANT_STREAMK2)
-#define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile */
 static int streamk_get(MLCtx* C, mlsd_gemm_args* g)
 {	/* slabs in the split-K workspace (ops run one at a time on the plan's stream) + the plan's flag words (zero between launches:
 	 * the kernels that use them clear them again) */
@@ -677,6 +768,8 @@ static int select_gemm(MLCtx* C, MLOp* op)
 	const TuneKey k = tune_key(g);
 	int best = 0, ks = 1;
 	if (tune_lookup(&k, &best, &ks)) {
+		/* a plan on a CU-masked stream (mlctx_set_cus): no in-launch hand-offs -- a stream-K entry runs as the plain tile of its shape */
+		if (IS_STREAMK(best) && C->cu_budget > 0 && C->cu_budget < 256) best = best == VARIANT_STREAMK ? 18 : 19;
 		g->tile_variant = best; g->ksplit = ks;
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
 		if (g->ksplit > 1 && streamk_get(C, g)) return -1;
@@ -974,6 +1067,7 @@ static void wire_ln_fold(MLCtx* C)
 {
 	const char *e = getenv("MLSD_NO_LN_FOLD");
 	if (e && *e && *e != '0') return;
+	if (C->cu_budget > 0 && C->cu_budget < 256) return;      /* the tiles of a row block must be resident together: not on a CU-masked stream */
 	/* pass 0 sizes the scratch block (largest user), pass 1 hands the LayerNorms over */
 	for (int pass=0; pass<2; ++pass) {
 		size_t need_max = 0;
@@ -990,6 +1084,21 @@ static void wire_ln_fold(MLCtx* C)
 			const size_t need = (size_t)(g->M / 128) * (g->N / 320) * 128 * 8;
 			if (!pass) { if (need > need_max) need_max = need; continue; }
 			if (need > C->ln_ws_bytes) continue;
+			{	/* the fp16 rows are written one op EARLIER now, by a launch that is still reading its operands: they must not land in a block the arena lent to one of
+				 * them (the attention output `a`, A operand of out_proj, is released right after out_proj is recorded and has exactly the size of the next LayerNorm's
+				 * output: ADVICE r3) */
+				const char *y0 = (const char*)l->u.ln.y16, *y1 = y0 + (size_t)g->M * g->N * 2;
+				const struct { const void* p; size_t n; } rd[4] = {
+					{ g->A, (size_t)g->M * (size_t)g->lda * 2 }, { g->resid, g->resid ? (size_t)g->M * (size_t)g->ldr * 4 : 0 },
+					{ g->W_, (size_t)g->N * (size_t)g->ldb * 2 }, { g->bias, g->bias ? (size_t)g->N * 4 : 0 } };
+				int clash = 0;
+				for (int q=0;q<4;++q) if (rd[q].p && rd[q].n && (const char*)rd[q].p < y1 && y0 < (const char*)rd[q].p + rd[q].n) clash = 1;
+				/* ONE overlap is sound and common (135 of the 199 folds of the SDXL b4 plan): the rows land EXACTLY on the A operand, row for row (same base, K == N,
+				 * same stride).  A tile writes fp16 rows [m0, m0 + 128) only after every tile of that row block has published its statistics, i.e. finished its K
+				 * loop, and those tiles are the only readers of A rows [m0, m0 + 128).  Any other overlap is refused. */
+				if (clash && !(y0 == (const char*)g->A && g->K == g->N && g->lda == g->N && g->resid != (const float*)g->A &&
+				               !((const char*)g->W_ < y1 && y0 < (const char*)g->W_ + rd[2].n))) { C->n_ln_alias++; continue; }
+			}
 			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
 			if (mlsd_gemm_ln_fused(g) == 1) { l->fused = 1; C->n_ln_fused++; }
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
@@ -997,8 +1106,8 @@ static void wire_ln_fold(MLCtx* C)
 		if (!pass) {
 			if (!need_max) return;
 			if (!C->ln_cnt) {
-				if (mlsd_malloc((void**)&C->ln_cnt, 8192 * 4)) return;
-				if (mlsd_memset(C->ln_cnt, 0, 8192 * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
+				if (mlsd_malloc((void**)&C->ln_cnt, LN_CNT_WORDS * 4)) return;
+				if (mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
 			}
 			if (C->ln_ws_bytes < need_max) {
 				if (C->ln_ws) { mlsd_free(C->ln_ws); C->mem_compute -= C->ln_ws_bytes; }
@@ -1008,6 +1117,190 @@ static void wire_ln_fold(MLCtx* C)
 			}
 		}
 	}
+}
+
+static int hoist_on(void);
+/* ------------------------------------------------------------------ weight streaming (BASELINE configs[4]; the reference's --unet-split, src/unet.c:390-458)
+ * The reference halves the UNet graph and uploads each half's weights before computing it, every evaluation, so that only half the model is resident.  Here
+ * (mlctx_set_weight_streaming before the graph is built): weight storage comes from a virtual address range (mlctx_walloc), the master copy sits in pinned host
+ * memory in the engine's layout, and at prep the recorded plan is cut into SEGMENTS of consecutive ops whose weights fit one of TWO device slabs; every weight
+ * pointer of an op is replaced by its address inside the slab of its segment.  An evaluation then runs  upload(0), upload(1) | compute(0) | upload(2) into slab 0 ||
+ * compute(1) | upload(3) into slab 1 || compute(2) ...: hipMemcpyAsync on a copy stream, ordered against the compute stream by events, so the next segment's weights
+ * arrive under the current segment's launches.  Same launches, same operands: results are bit-identical to the resident plan.  Resident instead of streamed: the
+ * K/V projection weights of the cross attentions (their launch is step-invariant and hoisted out of the evaluation) and everything that is not a weight. */
+static const void** op_weight_slots(MLOp* o, int* n)
+{
+	static _Thread_local const void** slots[8];
+	int k = 0;
+	switch (o->kind) {
+	case OP_GEMM: slots[k++] = &o->u.gemm.W_; slots[k++] = (const void**)&o->u.gemm.bias; slots[k++] = (const void**)&o->u.gemm.bias_m;
+	              slots[k++] = (const void**)&o->u.gemm.ln_gamma; slots[k++] = (const void**)&o->u.gemm.ln_beta; break;
+	case OP_GN:   slots[k++] = (const void**)&o->u.gn.gamma; slots[k++] = (const void**)&o->u.gn.beta; break;
+	case OP_LN:   slots[k++] = (const void**)&o->u.ln.g; slots[k++] = (const void**)&o->u.ln.b; break;
+	case OP_CLIP_EMBED: slots[k++] = &o->u.cemb.tw; slots[k++] = (const void**)&o->u.cemb.pw; break;
+	default: break;
+	}
+	*n = k;
+	return (const void**)slots;
+}
+
+static int pv_find(const MLCtx* C, size_t voff)
+{	/* allocation that holds virtual offset voff (allocations are handed out in increasing order) */
+	int lo = 0, hi = C->n_pv - 1;
+	while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (C->pv_allocs[mid].voff <= voff) lo = mid; else hi = mid - 1; }
+	return lo;
+}
+
+static void wstream_free(MLCtx* C)
+{
+	for (int i=0;i<C->n_segs;++i) {
+		free(C->segs[i].r);
+		if (C->ev_up && C->ev_up[i]) mlsd_event_destroy(C->ev_up[i]);
+		if (C->ev_done && C->ev_done[i]) mlsd_event_destroy(C->ev_done[i]);
+	}
+	free(C->segs); C->segs = NULL; C->n_segs = 0;
+	free(C->ev_up); free(C->ev_done); C->ev_up = C->ev_done = NULL;
+	if (C->copy_stream) { mlsd_stream_destroy(C->copy_stream); C->copy_stream = NULL; }
+	if (C->pmaster) { mlsd_host_free(C->pmaster); C->pmaster = NULL; }
+	for (int i=0;i<2;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
+	if (C->pscratch) { mlsd_free(C->pscratch); C->pscratch = NULL; C->pscratch_bytes = 0; }
+	free(C->pv_allocs); C->pv_allocs = NULL; C->n_pv = C->cap_pv = 0; C->pv_size = 0;
+	C->stream_bytes_per_eval = 0; C->pstream_hold = 0;      /* (pstream / slab_bytes are settings of the context, like its flags: they survive mlctx_begin) */
+}
+
+/* slab_bytes: size of each of the two device slabs (0 = default 512 MiB); call before the graph is built */
+MLB_API int mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes)
+{
+	if (!C || C->n_ops || C->n_params) return mlctx_fail(C, "mlctx_set_weight_streaming: the graph is already being built");
+	C->pstream = 1;
+	C->slab_bytes = slab_bytes ? ALIGN_UP(slab_bytes, 256) : ((size_t)512 << 20);
+	return 1;
+}
+MLB_API int mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes)
+{
+	if (!C || !C->pstream) return 0;
+	if (n_segments) *n_segments = C->n_segs;
+	if (streamed_bytes_per_eval) *streamed_bytes_per_eval = C->stream_bytes_per_eval;
+	if (slab_bytes) *slab_bytes = C->slab_bytes;
+	if (host_bytes) *host_bytes = C->pv_size;
+	return 1;
+}
+
+/* at the end of mlctx_prep: segments, slabs, master copy, pointer patch */
+static int wstream_setup(MLCtx* C)
+{
+	if (!C->pstream || !C->pv_size) return 1;
+	if (C->flags & MLB_F_HIPGRAPH) return mlctx_fail(C, "weight streaming and hipGraph replay exclude each other");
+	/* the largest set of weights one op touches must fit a slab */
+	int *seg_of = (int*)malloc(sizeof(int) * (size_t)C->n_ops);
+	int *used = (int*)calloc((size_t)C->n_pv, sizeof(int));        /* allocation -> 1 + index in the current segment */
+	if (!seg_of || !used) { free(seg_of); free(used); return mlctx_fail(C, "out of memory"); }
+	int cap = 16, R = 1;
+	C->segs = (MLWSeg*)calloc((size_t)cap, sizeof(MLWSeg)); C->n_segs = 0;
+	MLWSeg *cur = NULL;
+	for (int i=0;i<C->n_ops && R>0;++i) {
+		int ns; const void ***sl = (const void***)op_weight_slots(&C->ops[i], &ns);
+		int al[8], na = 0; size_t add = 0;
+		for (int q=0;q<ns;++q) {
+			const void *pp = *sl[q];
+			if (!pp || !is_virtual(C, pp)) continue;
+			const int a = pv_find(C, (size_t)((const char*)pp - MLW_VBASE));
+			int dup = 0; for (int z=0;z<na;++z) if (al[z] == a) dup = 1;
+			if (!dup) { al[na++] = a; if (!cur || !used[a]) add += C->pv_allocs[a].bytes; }
+		}
+		if (!cur || (na && cur->bytes + add > C->slab_bytes)) {     /* open a new segment at this op */
+			if (cur) { cur->op1 = i; for (int z=0;z<cur->n;++z) used[pv_find(C, cur->r[z].voff)] = 0; }
+			if (C->n_segs == cap) { cap *= 2; C->segs = (MLWSeg*)realloc(C->segs, sizeof(MLWSeg) * (size_t)cap); memset(C->segs + C->n_segs, 0, sizeof(MLWSeg) * (size_t)(cap - C->n_segs)); }
+			cur = &C->segs[C->n_segs++]; cur->op0 = i; cur->n = 0; cur->r = NULL; cur->bytes = 0;
+		}
+		for (int z=0;z<na;++z) {
+			const int a = al[z];
+			if (used[a]) continue;
+			cur->r = realloc(cur->r, sizeof(*cur->r) * (size_t)(cur->n + 1));
+			cur->r[cur->n].voff = C->pv_allocs[a].voff; cur->r[cur->n].bytes = C->pv_allocs[a].bytes; cur->r[cur->n].soff = cur->bytes;
+			cur->bytes += C->pv_allocs[a].bytes; used[a] = ++cur->n;
+			if (cur->bytes > C->slab_bytes) R = mlctx_fail(C, "weight streaming: op %d needs %zu bytes of weights at once, the slab holds %zu", i, cur->bytes, C->slab_bytes);
+		}
+		seg_of[i] = C->n_segs - 1;
+	}
+	if (cur) cur->op1 = C->n_ops;
+	if (R > 0) {
+		if (mlsd_host_alloc((void**)&C->pmaster, C->pv_size)) R = mlctx_fail(C, "weight streaming: %zu bytes of pinned host memory not available", C->pv_size);
+		else memset(C->pmaster, 0, C->pv_size);
+	}
+	for (int k=0;k<2 && R>0;++k) {
+		if (mlsd_malloc((void**)&C->slab[k], C->slab_bytes)) R = mlctx_fail(C, "weight streaming: slab allocation failed");
+		else C->mem_params += C->slab_bytes;
+	}
+	/* pointer patch: virtual -> slab of the op's segment */
+	C->stream_bytes_per_eval = 0;
+	for (int g=0; g<C->n_segs && R>0; ++g) {
+		MLWSeg *sg = &C->segs[g];
+		C->stream_bytes_per_eval += sg->bytes;
+		for (int i=sg->op0; i<sg->op1; ++i) {
+			int ns; const void ***sl = (const void***)op_weight_slots(&C->ops[i], &ns);
+			for (int q=0;q<ns;++q) {
+				const void *pp = *sl[q];
+				if (!pp || !is_virtual(C, pp)) continue;
+				const size_t vo = (size_t)((const char*)pp - MLW_VBASE);
+				int z = 0;
+				for (; z<sg->n; ++z) if (vo >= sg->r[z].voff && vo < sg->r[z].voff + sg->r[z].bytes) break;
+				if (z == sg->n) { R = mlctx_fail(C, "weight streaming: internal (op %d references weights outside its segment)", i); break; }
+				*sl[q] = C->slab[g & 1] + sg->r[z].soff + (vo - sg->r[z].voff);
+			}
+		}
+	}
+	if (R > 0) {
+		C->ev_up = (void**)calloc((size_t)C->n_segs, sizeof(void*)); C->ev_done = (void**)calloc((size_t)C->n_segs, sizeof(void*));
+	}
+	free(seg_of); free(used);
+	return R;
+}
+
+/* host address of a streamed parameter's master copy (NULL: the parameter is resident) */
+static char* param_master(const MLCtx* C, const MLParam* p)
+{
+	return is_virtual(C, p->dev) ? C->pmaster + ((const char*)p->dev - MLW_VBASE) : NULL;
+}
+
+static int compute_streamed(MLCtx* C)
+{
+	const int ns = C->n_segs;
+	if (!C->copy_stream) {
+		if (mlsd_stream_create(&C->copy_stream)) return -1;
+		for (int g=0; g<ns; ++g) if (mlsd_event_create(&C->ev_up[g]) || mlsd_event_create(&C->ev_done[g])) return -1;
+	}
+	const int hoist = C->n_once > 0 && hoist_on();
+#define UPLOAD(g) do { const MLWSeg *sg_ = &C->segs[g]; \
+		for (int z=0; z<sg_->n; ) { int z1 = z + 1; size_t nb = sg_->r[z].bytes;      /* coalesce ranges contiguous on both sides */ \
+			while (z1 < sg_->n && sg_->r[z1].voff == sg_->r[z1-1].voff + sg_->r[z1-1].bytes && sg_->r[z1].soff == sg_->r[z1-1].soff + sg_->r[z1-1].bytes) { nb += sg_->r[z1].bytes; ++z1; } \
+			if (mlsd_memcpy(C->slab[(g) & 1] + sg_->r[z].soff, C->pmaster + sg_->r[z].voff, nb, 0, C->copy_stream)) return -1; \
+			z = z1; } \
+		if (mlsd_event_record(C->ev_up[g], C->copy_stream)) return -1; } while (0)
+	/* the slabs may still be read by the previous evaluation's last two segments */
+	for (int k=0;k<2 && k<ns;++k) {
+		const int last = ns - 1 - ((ns - 1 - k) & 1);          /* last segment that used slab k */
+		if (C->info.n_compute > 0 && last >= 0 && mlsd_stream_wait_event(C->copy_stream, C->ev_done[last])) return -1;
+	}
+	for (int g=0; g<2 && g<ns; ++g) UPLOAD(g);
+	for (int g=0; g<ns; ++g) {
+		if (mlsd_stream_wait_event(C->stream, C->ev_up[g])) return -1;
+		for (int i=C->segs[g].op0; i<C->segs[g].op1; ++i) {
+			if (hoist && C->static_valid && C->ops[i].once) continue;
+			if (run_op(C, &C->ops[i])) {
+				char why[300]; snprintf(why, sizeof(why), "%s", mlsd_last_error());
+				mlsd_set_error(-1, "%s: op %d (%s) failed: %s", C->name, i, C->ops[i].label, why);
+				return -1;
+			}
+		}
+		if (mlsd_event_record(C->ev_done[g], C->stream)) return -1;
+		if (g + 2 < ns) {
+			if (mlsd_stream_wait_event(C->copy_stream, C->ev_done[g])) return -1;
+			UPLOAD(g + 2);
+		}
+	}
+#undef UPLOAD
+	return 1;
 }
 
 MLB_API int mlctx_prep(MLCtx* C)
@@ -1035,6 +1328,8 @@ MLB_API int mlctx_prep(MLCtx* C)
 	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;
 	C->info.mem_params = C->mem_params; C->info.mem_compute = C->mem_compute; C->info.mem_total = C->mem_params + C->mem_compute;
 	if (C->err) return C->err;
+	if (wstream_setup(C) < 0) return -1;
+	C->info.mem_params = C->mem_params; C->info.mem_total = C->mem_params + C->mem_compute;
 	C->prepared = 1;
 	return 1;
 }
@@ -1067,6 +1362,13 @@ MLB_API int mlctx_compute(MLCtx* C)
 			}
 		}
 		C->tuned = 1;
+		C->info.n_compute++;
+		return 1;
+	}
+	if (C->pstream && C->n_segs) {
+		if (compute_streamed(C) < 0) return -1;
+		C->static_valid = 1;
+		C->info.t_compute = now_s() - t0;
 		C->info.n_compute++;
 		return 1;
 	}
@@ -1182,7 +1484,15 @@ MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
 	if (!C->prepared) return mlctx_fail(C, "mlctx_profile_ops before mlctx_prep");
 	void *e0 = NULL, *e1 = NULL;
 	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
+	int seg = 0;
 	for (int i=0;i<C->n_ops;++i) {
+		if (C->pstream && seg < C->n_segs && C->segs[seg].op0 == i) {     /* streamed weights: this segment's weights into its slab first (blocking: not part of the op's time) */
+			const MLWSeg *sg = &C->segs[seg];
+			for (int z=0; z<sg->n; ++z)
+				if (mlsd_memcpy(C->slab[seg & 1] + sg->r[z].soff, C->pmaster + sg->r[z].voff, sg->r[z].bytes, 0, C->stream)) return -1;
+			if (mlsd_stream_sync(C->stream)) return -1;
+			++seg;
+		}
 		mlsd_event_record(e0, C->stream);
 		if (run_op(C, &C->ops[i])) return -1;
 		mlsd_event_record(e1, C->stream);
@@ -1287,8 +1597,15 @@ MLB_API int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void*
 		const int64_t o = param_dst_index(p, i);
 		if (p->type == MLT_F16) ((uint16_t*)buf)[o] = f32_to_f16_rne(v); else ((float*)buf)[o] = v;
 	}
-	int rc = mlsd_memcpy(p->dev, buf, p->dev_elems * esz, 0, C->stream);
-	if (!rc) rc = mlsd_stream_sync(C->stream);
+	int rc = 0;
+	char *pm = param_master(C, p);
+	if (pm) {       /* streamed weight: the master copy is host memory; an evaluation in flight may be uploading from it */
+		if (C->copy_stream) { mlsd_stream_sync(C->stream); mlsd_stream_sync(C->copy_stream); }
+		memcpy(pm, buf, p->dev_elems * esz);
+	} else {
+		rc = mlsd_memcpy(p->dev, buf, p->dev_elems * esz, 0, C->stream);
+		if (!rc) rc = mlsd_stream_sync(C->stream);
+	}
 	free(buf);
 	if (rc) return -1;
 	p->loaded = 1;
@@ -1324,8 +1641,23 @@ MLB_API int mlctx_params_synth(MLCtx* C, uint64_t seed)
 		const uint64_t key = mix64(h ^ (seed * 0x9E3779B97F4A7C15ULL));
 		const float kf = (float)((double)scale * 1.7320508075688772 / 65536.0);
 		const int64_t n = p->ne[0]*p->ne[1]*p->ne[2]*p->ne[3];
-		if (mlsd_synth_fill(p->dev, p->type == MLT_F16 ? 1 : 0, n, key, offset, kf, p->layout,
+		void *dst = p->dev;
+		char *pm = param_master(C, p);
+		const size_t pbytes = p->dev_elems * (p->type == MLT_F16 ? 2 : 4);
+		if (pm) {       /* streamed weight: fill a device scratch, copy it into the host master (same stream: in order) */
+			if (C->pscratch_bytes < pbytes) {
+				if (mlsd_stream_sync(C->stream)) return -1;
+				if (C->pscratch) mlsd_free(C->pscratch);
+				C->pscratch = NULL; C->pscratch_bytes = 0;
+				if (mlsd_malloc(&C->pscratch, ALIGN_UP(pbytes, (size_t)1 << 20))) return -1;
+				C->pscratch_bytes = ALIGN_UP(pbytes, (size_t)1 << 20);
+			}
+			dst = C->pscratch;
+			if (p->layout == 1 && p->lp[4] != p->lp[2] && mlsd_memset(dst, 0, pbytes, C->stream)) return -1;
+		}
+		if (mlsd_synth_fill(dst, p->type == MLT_F16 ? 1 : 0, n, key, offset, kf, p->layout,
 				p->lp[0], p->lp[1], p->lp[2], p->lp[3], p->lp[4], C->stream)) return -1;
+		if (pm && mlsd_memcpy(pm, dst, pbytes, 1, C->stream)) return -1;
 		p->loaded = 1;
 	}
 	if (mlsd_stream_sync(C->stream)) return -1;

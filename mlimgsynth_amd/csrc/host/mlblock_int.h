@@ -106,8 +106,25 @@ struct MLCtx {
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums / stream-K slabs (one buffer: ops run in order on one stream) */
 	unsigned* sk_flags;                        /* stream-K: one flag per persistent block, zeroed once (consumers clear them) */
 	unsigned* ln_cnt; float* ln_ws; size_t ln_ws_bytes; int n_ln_fused;   /* LayerNorms ended in their producers (wire_ln_fold): counters, scratch, count */
+	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
+	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy
+	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of two device slabs, and segment i+2 is uploaded (copy stream) while i+1 computes */
+	int pstream, pstream_hold;              /* on (mlctx_set_weight_streaming before the graph is built); hold > 0: allocations stay resident (weights of step-invariant ops) */
+	size_t pv_size;                         /* bytes of virtual weight space handed out */
+	struct MLWAlloc* pv_allocs; int n_pv, cap_pv;
+	char* pmaster;                          /* pinned host master copy [pv_size] (engine layout) */
+	size_t slab_bytes; char* slab[2];
+	struct MLWSeg* segs; int n_segs;
+	void* copy_stream; void **ev_up, **ev_done;   /* per segment */
+	void* pscratch; size_t pscratch_bytes;  /* device scratch for the synthetic fill */
+	size_t stream_bytes_per_eval;
 	MLCtxInfo info;
 };
+
+#define MLW_VBASE ((char*)0x600000000000ULL)      /* virtual weight addresses: never dereferenced, replaced by slab addresses at prep */
+typedef struct MLWAlloc { size_t voff, bytes; } MLWAlloc;
+typedef struct MLWSeg { int op0, op1; int n; struct { size_t voff, bytes, soff; } *r; size_t bytes; } MLWSeg;
+void* mlctx_walloc(MLCtx* C, size_t nbytes);      /* weight storage: device memory, or a virtual address when the plan streams its weights */
 
 /* internal helpers shared by mlblock_nn.c and the model builders */
 MLTensor* mlt_new(MLCtx* C, int n, int h, int w, int c);

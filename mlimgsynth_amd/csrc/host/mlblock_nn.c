@@ -226,8 +226,8 @@ int mlb_emb_proj_batch(MLCtx* C, MLTensor* emb, int n_total)
 	const int n_in = emb->c;
 	const int64_t rows = rows_of(emb);
 	C->epb.emb = emb; C->epb.n_in = n_in; C->epb.n_total = n_total; C->epb.n_used = 0;
-	C->epb.wbase = (char*)mlctx_dalloc(C, (size_t)n_total * n_in * 2, 1);
-	C->epb.bbase = (float*)mlctx_dalloc(C, (size_t)n_total * 4, 1);
+	C->epb.wbase = (char*)mlctx_walloc(C, (size_t)n_total * n_in * 2);
+	C->epb.bbase = (float*)mlctx_walloc(C, (size_t)n_total * 4);
 	C->epb.out32 = (float*)mlctx_dalloc(C, (size_t)rows * n_total * 4, 0);
 	MLOp *op = mlctx_op_new(C, OP_GEMM, "");
 	mlsd_gemm_args *g = &op->u.gemm;
@@ -336,8 +336,8 @@ static MLTensor* fused_proj(MLCtx* C, MLTensor* x, int d_embed, bool bias, const
 	const void *xd = mlt_need16(C, x);
 	if (!xd) return NULL;
 	if (n_in % 8) { mlctx_fail(C, "attention: n_in=%d must be a multiple of 8", n_in); return NULL; }
-	char *wbase = (char*)mlctx_dalloc(C, (size_t)n_proj * d_embed * n_in * 2, 1);
-	float *bbase = bias ? (float*)mlctx_dalloc(C, (size_t)n_proj * d_embed * 4, 1) : NULL;
+	char *wbase = (char*)mlctx_walloc(C, (size_t)n_proj * d_embed * n_in * 2);
+	float *bbase = bias ? (float*)mlctx_walloc(C, (size_t)n_proj * d_embed * 4) : NULL;
 	for (int i=0;i<n_proj;++i) {
 		mlctx_block_begin(C);   /* the mlb_nn_linear scope of the reference */
 		mlctx_param_new_at(C, "weight", MLT_F16, n_in, d_embed, 1, 1, 0, wbase + (size_t)i * d_embed * n_in * 2);

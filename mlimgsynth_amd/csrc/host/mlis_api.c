@@ -441,7 +441,7 @@ static int option_apply(MLIS_Ctx* S, int id, ArgSrc* A)
 		} else S->seed = va_arg(*A->ap, uint64_t);
 		break;
 	case MLIS_OPT_VAE_TILE: if (!arg_int(A, 0, 65535, 0, &i)) BAD_VALUE; S->vae_tile = i; break;
-	case MLIS_OPT_UNET_SPLIT: if (!arg_bool(A, &i)) BAD_VALUE; if (i) S->flags |= CF_UNET_SPLIT; else S->flags &= ~CF_UNET_SPLIT; break;   /* residency replaces streaming */
+	case MLIS_OPT_UNET_SPLIT: if (!arg_bool(A, &i)) BAD_VALUE; if (i) S->flags |= CF_UNET_SPLIT; else S->flags &= ~CF_UNET_SPLIT; break;   /* weight streaming through two device slabs (engine_get) */
 	case MLIS_OPT_WEIGHT_TYPE:
 		if (A->is_str) {
 			next_str_arg(A);
@@ -645,7 +645,7 @@ static int engine_get(MLIS_Ctx* S, int lw, int lh)
 {
 	const int f = 8, B = S->n_batch > 0 ? S->n_batch : 1, tae = !!(S->flags & CF_USE_TAE);
 	char key[96];
-	snprintf(key, sizeof(key), "%s/%dx%d/b%d/g%d/t%d/w%d", S->mname, lw, lh, B, S->cfg_scale > 1, tae, S->wtype);
+	snprintf(key, sizeof(key), "%s/%dx%d/b%d/g%d/t%d/w%d/s%d", S->mname, lw, lh, B, S->cfg_scale > 1, tae, S->wtype, !!(S->flags & CF_UNET_SPLIT));
 	int n_step, method, sched;
 	sampler_defaults(S, &n_step, &method, &sched);
 	if (!S->eng || strcmp(key, S->eng_key)) {
@@ -654,6 +654,7 @@ static int engine_get(MLIS_Ctx* S, int lw, int lh)
 		c.model = S->mname; c.width = lw * f; c.height = lh * f; c.n_batch = B; c.n_step = n_step; c.cfg_scale = S->cfg_scale;
 		c.s_ancestral = S->s_ancestral; c.sched = sched; c.use_tae = tae; c.weight_seed = S->synth_seed; c.method = method;
 		c.s_noise = S->s_noise; c.f_t_ini = S->f_t_ini; c.f_t_end = S->f_t_end; c.defer_weights = 1;
+		c.unet_split = (S->flags & CF_UNET_SPLIT) ? 1 : 0;      /* MLIS_OPT_UNET_SPLIT (src/mlimgsynth.c:1629 unet_split): the UNet's weights are streamed, not resident */
 		S->eng = mlis_amd_create(&c, NULL);
 		if (!S->eng) return api_error_lib(S, MLIS_E_UNKNOWN);
 		mlctx_set_wtype(mlis_amd_unet_ctx(S->eng), S->wtype);

@@ -321,7 +321,7 @@ MLB_API int unet_denoise_run_n(UnetState* S, const float* x, const float* cond, 
 	if (R > 0 && mlctx_input_set(C, S->t_t, ts, N*4) < 0) R = -1;
 	if (R > 0 && mlctx_input_set(C, S->t_c, cond, (size_t)N*77*P->n_ctx*4) < 0) R = -1;
 	if (R > 0 && S->t_l && mlctx_input_set(C, S->t_l, label, (size_t)N*P->ch_adm_in*4) < 0) R = -1;
-	if (R > 0 && mlctx_compute(C) < 0) R = -1;
+	if (R > 0 && mlctx_compute_checked(C) < 0) R = -1;            /* (re-runs on the hand-off-free plan after a timed-out in-launch hand-off) */
 	if (R > 0 && mlctx_output_get(C, S->t_out, dx, nx*4) < 0) R = -1;
 	S->nfe++;
 	if (R > 0) {

@@ -149,7 +149,7 @@ MLB_API int sdvae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float*
 	for (size_t i=0;i<n_in;++i) tmp[i] = img[i]*2 - 1;                      /* sdvae_encoder_pre */
 	int R = mlctx_input_set(C, t_img, tmp, t_img->in_bytes);
 	free(tmp);
-	if (R < 0 || mlctx_compute(C) < 0) return -1;
+	if (R < 0 || mlctx_compute_checked(C) < 0) return -1;
 	MLTensor *r = mlctx_result(C);
 	const size_t n = (size_t)r->n * r->h * r->w * r->c;
 	if (mlctx_output_get(C, r, moments, n*4) < 0) return -1;
@@ -218,7 +218,7 @@ MLB_API int sdvae_decode_build(MLCtx* C, const VaeParams* P, MLTensor* t_latent)
 static int decode_run(MLCtx* C, MLTensor* t_latent, const float* latent, float* img, float mul, float add)
 {
 	if (mlctx_input_set(C, t_latent, latent, t_latent->in_bytes) < 0) return -1;
-	if (mlctx_compute(C) < 0) return -1;
+	if (mlctx_compute_checked(C) < 0) return -1;
 	MLTensor *r = mlctx_result(C);
 	const size_t n = (size_t)r->n * r->h * r->w * r->c;
 	if (mlctx_output_get(C, r, img, n*4) < 0) return -1;
@@ -343,7 +343,7 @@ MLB_API int sdtae_encode_build(MLCtx* C, MLTensor* t_img)
 /* img NCHW [n][3][h][w] (used as given: the reference's sdtae_encode applies no pre-scaling) -> latent [n][4][h/8][w/8] */
 MLB_API int sdtae_encode_run(MLCtx* C, MLTensor* t_img, const float* img, float* latent)
 {
-	if (mlctx_input_set(C, t_img, img, t_img->in_bytes) < 0 || mlctx_compute(C) < 0) return -1;
+	if (mlctx_input_set(C, t_img, img, t_img->in_bytes) < 0 || mlctx_compute_checked(C) < 0) return -1;
 	MLTensor *r = mlctx_result(C);
 	return mlctx_output_get(C, r, latent, (size_t)r->n * r->h * r->w * r->c * 4);
 }

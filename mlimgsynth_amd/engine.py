@@ -46,7 +46,7 @@ class AmdConfig(ctypes.Structure):
     _fields_ = [("model", ctypes.c_char_p), ("width", c_int), ("height", c_int), ("n_batch", c_int), ("n_step", c_int),
                 ("cfg_scale", c_f), ("s_ancestral", c_f), ("sched", c_int), ("use_tae", c_int), ("use_hipgraph", c_int),
                 ("weight_seed", c_u64), ("method", c_int), ("s_noise", c_f), ("f_t_ini", c_f), ("f_t_end", c_f),
-                ("defer_weights", c_int)]
+                ("defer_weights", c_int), ("unet_split", c_int)]
 
 
 _proto_done = False
@@ -139,6 +139,15 @@ class MLCtx:
         check1(L().mlctx_profile_ops(self.h, fptr(ms), n), "mlctx_profile_ops")
         return ms
 
+    def streaming_info(self):
+        """(segments, streamed bytes per evaluation, slab bytes, host bytes) of a weight-streaming plan, or None"""
+        f = L().mlctx_weight_streaming_info
+        f.argtypes = [vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        n, a, b, c = c_int(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        if not f(self.h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)):
+            return None
+        return n.value, a.value, b.value, c.value
+
     def tune_misses(self):
         """GEMM shapes of this plan that the compiled-in tile table does not list (they run on the static rule)."""
         f = L().mlctx_plan_tune_misses
@@ -172,9 +181,13 @@ def unet_params(model):
 class Unet:
     """unet_denoise_init_n / unet_denoise_run_n (src/unet.c:336-498) with a batch dimension."""
 
-    def __init__(self, model, lw, lh, n_batch, stream=None, flags=0, seed=1234, synth=True):
+    def __init__(self, model, lw, lh, n_batch, stream=None, flags=0, seed=1234, synth=True, stream_weights_mib=0):
         self.P = unet_params(model)
         self.ctx = MLCtx(stream, flags)
+        if stream_weights_mib:          # the reference's --unet-split: weights in pinned host memory, two device slabs of this size
+            f = L().mlctx_set_weight_streaming
+            f.argtypes = [vp, ctypes.c_size_t]
+            check1(f(self.ctx.h, int(stream_weights_mib) << 20), "mlctx_set_weight_streaming")
         self.S = UnetState()
         check1(L().unet_denoise_init_n(ctypes.byref(self.S), self.ctx.h, ctypes.byref(self.P), lw, lh, n_batch), "unet_denoise_init_n")
         check1(L().unet_denoise_build(ctypes.byref(self.S)), "unet_denoise_build")
@@ -314,11 +327,11 @@ class Generator:
 
     def __init__(self, model, width, height, n_batch, n_step=20, cfg_scale=7.0, s_ancestral=1.0, sched=1, use_tae=False,
                  use_hipgraph=False, weight_seed=1234, stream=None, method="euler", s_noise=0.0, f_t_ini=1.0, f_t_end=0.0,
-                 defer_weights=False):
+                 defer_weights=False, unet_split=0):
         l = _proto2()
         self.cfg = AmdConfig(model.encode(), width, height, n_batch, n_step, cfg_scale, s_ancestral, sched, int(use_tae),
                              int(use_hipgraph), weight_seed, self.METHODS.get(method, method), s_noise, f_t_ini, f_t_end,
-                             int(defer_weights))
+                             int(defer_weights), int(unet_split))
         self.h = l.mlis_amd_create(ctypes.byref(self.cfg), vp(stream))
         if not self.h:
             from ._lib import MlsdError, last_error

@@ -189,19 +189,48 @@ void orc_silu(OT* x)
 	for (int64_t i=0;i<n;++i) x->d[i] = x->d[i] / (1.0f + expf(-x->d[i]));
 }
 
-void orc_gelu(OT* x)
-{	/* ggml_gelu: tanh approximation (ggml's F16 lookup table is not emulated) */
-	int64_t n = ot_nel(x);
+/* ggml's CPU backend evaluates GELU and quick-GELU on F32 tensors through 65536-entry F16 lookup tables (ggml-cpu vec.h, GGML_GELU_FP16 / GGML_GELU_QUICK_FP16
+ * are defined by default): y = f16_to_f32(table[f32_to_f16(x)]) with table[i] = f32_to_f16(formula(f16_to_f32(i))) -- i.e. the INPUT and the OUTPUT of the activation
+ * are rounded to binary16 (GELU only for -10 < x < 10: outside that range ggml returns 0 / x exactly).  ggml is absent here, so this is restated from its published
+ * source, not pinned.  orc_set_ggml_f16_tables(1) switches the oracle to that behaviour (call sites: /root/reference/src/mlblock_nn.c:168 GEGLU gate,
+ * /root/reference/src/clip.c:354-356 CLIP MLP); the default (0) keeps the exact fp32 formulas.  tests/test_oracle_ops.py holds the two modes against each other and
+ * profiles/r4_parity_f16_tables.txt reports the HIP path against both. */
+static int g_f16_tables = 0;
+void orc_set_ggml_f16_tables(int on) { g_f16_tables = on != 0; }
+int orc_get_ggml_f16_tables(void) { return g_f16_tables; }
+
+static inline float gelu_f(float v)
+{
 	const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
+	return 0.5f*v*(1.0f + tanhf(c*v*(1.0f + a*v*v)));
+}
+
+void orc_gelu(OT* x)
+{	/* ggml_gelu: tanh approximation */
+	int64_t n = ot_nel(x);
+	const int tab = g_f16_tables;
 	#pragma omp parallel for schedule(static) if (n > 65536)
-	for (int64_t i=0;i<n;++i) { float v=x->d[i]; x->d[i] = 0.5f*v*(1.0f + tanhf(c*v*(1.0f + a*v*v))); }
+	for (int64_t i=0;i<n;++i) {
+		float v = x->d[i];
+		if (!tab) { x->d[i] = gelu_f(v); continue; }
+		if (v <= -10.0f) x->d[i] = 0.0f;
+		else if (v >= 10.0f) x->d[i] = v;
+		else { orc_round_f16(&v, 1); v = gelu_f(v); orc_round_f16(&v, 1); x->d[i] = v; }
+	}
 }
 
 void orc_gelu_quick(OT* x)
 {	/* ggml_gelu_quick: x*sigmoid(1.702x) */
 	int64_t n = ot_nel(x);
+	const int tab = g_f16_tables;
 	#pragma omp parallel for schedule(static) if (n > 65536)
-	for (int64_t i=0;i<n;++i) { float v=x->d[i]; x->d[i] = v / (1.0f + expf(-1.702f*v)); }
+	for (int64_t i=0;i<n;++i) {
+		float v = x->d[i];
+		if (tab) orc_round_f16(&v, 1);
+		v = v / (1.0f + expf(-1.702f*v));
+		if (tab) orc_round_f16(&v, 1);
+		x->d[i] = v;
+	}
 }
 
 void orc_relu(OT* x)

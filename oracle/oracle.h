@@ -95,6 +95,10 @@ ORACLE_API OT* orc_layer_norm(const OT* x, float eps, const OParam* w, const OPa
 /* q [d_head*n_head... see o_ops.c */
 ORACLE_API OT* orc_attention(const OT* q, const OT* k, const OT* v, int n_head, int causal);
 ORACLE_API void orc_silu(OT* x);
+/* 1: GELU / quick-GELU through ggml-CPU's F16 lookup tables (input and output rounded to binary16; restated from ggml's published source, ggml is absent: unpinned);
+ * 0 (default): the exact fp32 formulas */
+ORACLE_API void orc_set_ggml_f16_tables(int on);
+ORACLE_API int  orc_get_ggml_f16_tables(void);
 ORACLE_API void orc_gelu(OT* x);
 ORACLE_API void orc_gelu_quick(OT* x);
 ORACLE_API void orc_relu(OT* x);

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import tolerances as T
 import pytest
 
 import loader_cases as LC
@@ -153,7 +154,7 @@ def test_checkpoint_gguf_container_equals_safetensors(lib, tmp_path):
         m.close()
     assert np.array_equal(lat["plain.gguf"], lat["tinyxl.safetensors"])
     r = rel(lat["q8.gguf"], lat["tinyxl.safetensors"])
-    assert 0 < r < 5e-2, r
+    assert 0 < r < 5e-2, r          # Q8_0 quantisation noise of the attention projections (measured 1.4e-2), not a parity bound
 
 
 def test_checkpoint_sdxl_style_with_fused_open_clip_attention(lib, tmp_path):
@@ -209,9 +210,9 @@ def test_img2img_and_inpaint_through_image_option(lib):
     ref, nfe = oracle_sample("tiny", 8, cond, ncond, None, None, "euler", 1.0, 1, 0.0, 10, 42, f_t_ini=0.5, init=init, lmask=lmask, rng_offset=1)
     e = rel(lat, ref)
     print("API inpaint vs oracle rel-L2", e)
-    assert nfe == 10 and e < 5e-2
+    assert nfe == 10 and e < T.LATENT
     keep = np.broadcast_to(lmask == 1, lat.shape)
-    assert rel(lat[keep], init[keep]) < 4e-3                                      # kept region == the encoded source
+    assert rel(lat[keep], init[keep]) < T.EVAL                                      # kept region == the encoded source
     m.close()
 
 
@@ -253,7 +254,7 @@ def test_image_encode_decode_entry_points(lib):
     dec = F.tensor_np(out)
     OP, V = O.Params(1234), O.vae_params("tiny")
     ref = O.from_ot(O.L().orc_vae_decode(OP.h, b"vae", V, O.to_ot(F.tensor_np(lat))))
-    assert dec.shape == (1, 3, 64, 64) and rel(dec - 0.5, ref - 0.5) < 4e-3
+    assert dec.shape == (1, 3, 64, 64) and rel(dec - 0.5, ref - 0.5) < T.EVAL
     m.close()
 
 

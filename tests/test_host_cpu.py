@@ -281,3 +281,27 @@ def test_block_graph_dump_reproduces_the_parameter_names(dry, tmp_path):
     assert L.mlctx_build_alloc(C.h, y) == 1
     assert [k for k, _, _ in C.param_list()] == ["fc.bias", "fc.weight"] or sorted(k for k, _, _ in C.param_list()) == ["fc.bias", "fc.weight"]
     C.destroy()
+
+
+def test_weight_streaming_plan_in_the_dry_runtime(dry):
+    """BASELINE configs[4] / the reference's --unet-split (src/unet.c:390-458): with mlctx_set_weight_streaming the plan's weights are cut into segments of consecutive
+    ops that fit one of two slabs.  Host logic only (no GPU): every weight of the plan is streamed exactly once per evaluation except the step-invariant cross-attention
+    K/V projections (resident), the segment count follows the slab size, a slab smaller than the largest single launch's weights is refused, and streaming + hipGraph
+    replay is refused."""
+    un = dry.Unet("tinyxl", 8, 8, 2, synth=False)
+    assert un.ctx.streaming_info() is None
+    total = sum(int(np.prod(ne)) * (2 if typ == 1 else 4) for _, typ, ne in un.ctx.param_list())
+    infos = {}
+    for mib in (1, 4):
+        s = dry.Unet("tinyxl", 8, 8, 2, synth=False, stream_weights_mib=mib)
+        nseg, per_eval, slab, host = s.ctx.streaming_info()
+        infos[mib] = nseg
+        assert slab == mib << 20 and nseg >= 2
+        assert per_eval == host                                    # every streamed byte moves once per evaluation
+        kv = sum(int(np.prod(ne)) * 2 for k, typ, ne in s.ctx.param_list() if ".attn2.k_proj." in k or ".attn2.v_proj." in k or "attn2.k_proj" in k or "attn2.v_proj" in k)
+        assert 0.9 * (total - kv) <= host <= 1.1 * (total - kv) + 256 * len(s.ctx.param_list())      # (256-byte alignment per allocation)
+        assert per_eval <= nseg * slab
+        s.ctx.destroy()
+    assert infos[1] > infos[4]
+    with pytest.raises(Exception):
+        dry.Unet("tinyxl", 8, 8, 2, synth=False, stream_weights_mib=1, flags=8)       # MLB_F_HIPGRAPH

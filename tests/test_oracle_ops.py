@@ -143,6 +143,40 @@ def test_activations_and_small_ops():
     assert np.abs(out - ref).max() < 2e-4
 
 
+def test_ggml_f16_table_mode_of_the_activations():
+    """orc_set_ggml_f16_tables(1): GELU / quick-GELU as ggml's CPU backend evaluates them -- through F16 lookup tables, i.e. fp16(x) -> formula -> fp16
+    (GELU passes x <= -10 / x >= 10 through exactly).  Held against a numpy restatement of the table construction; the default mode stays exact."""
+    L = O.L()
+    x = np.concatenate([np.linspace(-12, 12, 4001), [1e-4, -1e-4, 3.14159, 65504.0, -70000.0]]).astype(np.float32).reshape(1, 1, 1, -1)
+    xs = x.ravel()
+    xh = xs.astype(np.float16).astype(np.float32)
+    gelu = lambda v: (0.5 * v * (1.0 + np.tanh(np.float32(0.7978845608028654) * v * (1.0 + np.float32(0.044715) * v * v)))).astype(np.float32)
+    quick = lambda v: (v / (1.0 + np.exp(np.float32(-1.702) * v))).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want_g = np.where(xs <= -10, 0.0, np.where(xs >= 10, xs, gelu(xh).astype(np.float16).astype(np.float32))).astype(np.float32)
+        want_q = quick(xh).astype(np.float16).astype(np.float32)
+    try:
+        L.orc_set_ggml_f16_tables(1)
+        assert L.orc_get_ggml_f16_tables() == 1
+        for fn, want in (("orc_gelu", want_g), ("orc_gelu_quick", want_q)):
+            t = O.to_ot(x)
+            getattr(L, fn)(t)
+            got = O.from_ot(t).ravel()
+            fin = np.isfinite(want)
+            # (tanhf / expf of libm against numpy: the same value before the final fp16 rounding up to 1 ulp, so at most one fp16 step apart, on a few points)
+            assert np.array_equal(np.isfinite(got), fin), fn
+            step = np.spacing(np.abs(want[fin]).astype(np.float16)).astype(np.float32)
+            # (around x = -5.4 the fp32 formula cancels, 1 + tanh(..) ~ 2e-8, and libm's tanhf and numpy's differ there by a few fp16 subnormal steps of the result)
+            assert (np.abs(got[fin] - want[fin]) <= np.maximum(step, 2.5e-7)).all(), fn
+            assert (got[fin] == want[fin]).mean() > 0.95, fn
+            assert np.array_equal(got[fin], got[fin].astype(np.float16).astype(np.float32)) or fn == "orc_gelu", fn   # table outputs are fp16 values
+    finally:
+        L.orc_set_ggml_f16_tables(0)
+    t = O.to_ot(x[..., :4001])
+    L.orc_gelu(t)
+    assert rel(O.from_ot(t), F.gelu(torch.from_numpy(x[..., :4001]).double(), approximate="tanh").numpy()) < 1e-6     # default: exact formula
+
+
 def test_unet_tiny_runs_and_names_follow_reference():
     U = O.unet_params("tiny")
     P = O.Params(1234)

@@ -2,6 +2,7 @@
 import ctypes
 
 import numpy as np
+import tolerances as T
 import pytest
 
 import oracle_lib as O
@@ -26,7 +27,7 @@ def test_vae_decode_parity(model, lat, n):
     assert got.shape == ref.shape == (n, 3, lat * 8, lat * 8)
     err = rel(got - 0.5, ref - 0.5)
     print("vae", model, lat, "rel-L2", err)
-    assert err < 4e-3                       # tolerance as for the UNet (fp16 attention operands, fp32 order)
+    assert err < T.EVAL                       # tolerance as for the UNet (fp16 attention operands, fp32 order)
     mine = {k for k, _, _ in dec.ctx.param_list()}
     assert mine == {k for k, _, _ in P.names()}
 
@@ -44,16 +45,18 @@ def test_vae_decode_sd_real_config():
     ref = O.from_ot(O.L().orc_vae_decode(P.h, b"vae", V, O.to_ot(z)))
     err = rel(got - 0.5, ref - 0.5)
     print("vae sd1 rel-L2", err)
-    assert err < 4e-3
+    assert err < T.EVAL
 
 
 def test_vae_decode_512_parity():
-    """configs[1]'s decode at full size: the real SD1.5 KL decoder, 64x64 latent -> 512x512 image (2.5 TFLOP), vs the oracle."""
+    """The real SD1.5 KL decoder (configs[1]'s decode) against the oracle at a 32x32 latent -> 256x256 image (the CPU side is the cost of this test: 0.63 TFLOP in fp32;
+    the full 512x512 and SDXL 1024x1024 decodes are held against the independent torch vectors by tests/test_golden_gpu.py::*full_resolution*, and against the oracle
+    by tools/full_size_latent_parity.py)."""
     import os
     from mlimgsynth_amd import engine
     O.L().orc_set_threads(min(os.cpu_count() or 8, 128))
     rng = np.random.default_rng(5)
-    lat = 64
+    lat = 32
     z = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 0.5
     dec = engine.Decoder("sd1", lat, lat, 1)
     dec.run(z)
@@ -61,8 +64,8 @@ def test_vae_decode_512_parity():
     V, P = O.vae_params("sd1"), O.Params(1234)
     ref = O.from_ot(O.L().orc_vae_decode(P.h, b"vae", V, O.to_ot(z)))
     err = rel(got - 0.5, ref - 0.5)
-    print("vae sd1 512x512 rel-L2", err)
-    assert np.isfinite(got).all() and err < 4e-3
+    print("vae sd1 256x256 rel-L2", err)
+    assert np.isfinite(got).all() and err < T.EVAL
 
 
 def test_tae_decode_parity():
@@ -100,12 +103,12 @@ def test_clip_text_encode_parity(model, prefix, skip, norm, feat):
             # feat forces all layers + final norm; embed then is that same tensor (src/clip.c:446)
             e_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, -1, 1, 0, 0)).reshape(K.n_token, K.d_embed)
             f_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, -1, 1, 1, n_tok + 1)).reshape(K.d_embed)
-            assert rel(ft[p], f_ref) < 4e-3
+            assert rel(ft[p], f_ref) < T.EVAL
         else:
             e_ref = O.from_ot(O.L().orc_clip_text_encode(P.h, prefix.encode(), K, ptr, skip, int(norm), 0, 0)).reshape(K.n_token, K.d_embed)
         err = rel(emb[p], e_ref)
         print("clip", model, "prompt", p, "rel-L2", err)
-        assert err < 4e-3
+        assert err < T.EVAL
 
 
 @pytest.mark.parametrize("model", ["tiny", "tinyxl"])
@@ -130,18 +133,18 @@ def test_text_cond_assembly_vs_oracle(model):
         return r.reshape(K.d_embed) if feat else r.reshape(K.n_token, K.d_embed)
     if model == "tiny":
         assert cond.shape == (77, 64) and label is None and nlabel is None
-        assert rel(cond, oracle("clip", toks, 1, True, False)) < 4e-3
-        assert rel(ncond, oracle("clip", toks[:0], 1, True, False)) < 4e-3     # SD1: the empty prompt is encoded, not zeroed
+        assert rel(cond, oracle("clip", toks, 1, True, False)) < T.EVAL
+        assert rel(ncond, oracle("clip", toks[:0], 1, True, False)) < T.EVAL     # SD1: the empty prompt is encoded, not zeroed
     else:
         assert cond.shape == (77, 128) and label.shape == (96,)
-        assert rel(cond[:, :64], oracle("clip", toks, 2, False, False)) < 4e-3
-        assert rel(cond[:, 64:], oracle("clip2", toks, 2, False, False)) < 4e-3
-        assert rel(label[:64], oracle("clip2", toks, -1, True, True)) < 4e-3
+        assert rel(cond[:, :64], oracle("clip", toks, 2, False, False)) < T.EVAL
+        assert rel(cond[:, 64:], oracle("clip2", toks, 2, False, False)) < T.EVAL
+        assert rel(label[:64], oracle("clip2", toks, -1, True, True)) < T.EVAL
         assert not label[64:].any()
         assert not ncond.any()                                                 # uncond_empty_zero
-        assert rel(nlabel[:64], oracle("clip2", toks[:0], -1, True, True)) < 4e-3
+        assert rel(nlabel[:64], oracle("clip2", toks[:0], -1, True, True)) < T.EVAL
         c2, l2, nc2, nl2 = tc.encode_pair(toks, toks[:3])                      # a non-empty negative prompt is encoded
-        assert nc2.any() and rel(nc2[:, :64], oracle("clip", toks[:3], 2, False, False)) < 4e-3
+        assert nc2.any() and rel(nc2[:, :64], oracle("clip", toks[:3], 2, False, False)) < T.EVAL
         assert np.array_equal(c2, cond)
     tc.destroy()
 
@@ -156,7 +159,7 @@ def test_clip_prompt_too_long_is_an_error():
 def test_generate_latent_parity_vs_oracle(model, steps):
     """Whole denoising loop (schedule, Philox noise, CFG, Euler-a) on the tiny configs: HIP engine vs the
     oracle's restatement of mlis_generate.  The ancestral loop is chaotic, so the stated tolerance on the FINAL
-    latent is loose (rel-L2 <= 5e-2) while every single evaluation is held to 4e-3 by test_unet_gpu."""
+    latent is looser (rel-L2 <= 1e-2, tests/tolerances.py) while every single evaluation is held to 2e-3 by test_unet_gpu."""
     from mlimgsynth_amd import engine
     lat, B = 8, 2
     U = O.unet_params(model)
@@ -182,7 +185,7 @@ def test_generate_latent_parity_vs_oracle(model, steps):
         assert nfe == 2 * steps
         err = rel(lat_got[b], out)
         print(model, "image", b, "final latent rel-L2", err)
-        assert err < 5e-2
+        assert err < T.LATENT
     # the two images used different seeds: different latents
     assert rel(lat_got[0], lat_got[1]) > 0.1
     # determinism: a second run with the same seeds is bit-identical

@@ -4,6 +4,7 @@ kernels against numpy restatements of the reference's loops (bit-exact: same fp3
 import ctypes
 
 import numpy as np
+import tolerances as T
 import pytest
 
 import oracle_lib as O
@@ -175,12 +176,13 @@ def test_solvers_and_schedulers_vs_oracle(method, s_anc, sched, s_noise, steps):
     g.set_cond(cond, label, uncond, unlabel)
     seeds = [11, 12]
     got, _ = g.generate(seeds, want_images=False)
-    for b in range(B):
+    # (the CPU oracle is most of this test's time: both images of the batch for the Euler cases, image 1 -- the slot that is not first -- for the other solvers)
+    for b in (range(B) if method == "euler" else (1,)):
         ref, nfe = oracle_sample(model, lat, cond, uncond, label, unlabel, method, s_anc, sched, s_noise, steps, seeds[b])
         assert g.last_nfe() == nfe
         e = rel(got[b], ref)
         print(method, s_anc, sched, s_noise, "image", b, "rel-L2", e, "nfe", nfe)
-        assert np.isfinite(got[b]).all() and e < 5e-2
+        assert np.isfinite(got[b]).all() and e < T.LATENT
     g.destroy()
 
 
@@ -197,7 +199,7 @@ def test_vparam_generation_vs_oracle():
         ref, nfe = oracle_sample(model, lat, cond, uncond, None, None, method, 1.0, 1, 0.0, 8, 21, cfg=5.0)
         e = rel(got[0], ref)
         print("vparam", method, e)
-        assert g.last_nfe() == nfe and e < 5e-2
+        assert g.last_nfe() == nfe and e < T.LATENT
         # and it is NOT what an eps-model driver would return
         g.destroy()
 
@@ -209,7 +211,7 @@ def test_cfg_off_single_evaluation_per_step():
     g.set_cond(cond, None, None, None)
     got, _ = g.generate([3], want_images=False)
     ref, nfe = oracle_sample("tiny", 8, cond, uncond, None, None, "euler", 0.0, 1, 0.0, 5, 3, cfg=1.0)
-    assert g.last_nfe() == nfe == 5 and rel(got[0], ref) < 5e-2
+    assert g.last_nfe() == nfe == 5 and rel(got[0], ref) < T.LATENT
 
 
 def test_img2img_and_inpaint_vs_oracle():
@@ -232,7 +234,7 @@ def test_img2img_and_inpaint_vs_oracle():
         assert g.last_n_step() == 6 and g.last_nfe() == nfe == 12
         e = rel(got[0], ref)
         print("img2img", "mask" if mask is not None else "nomask", e)
-        assert e < 5e-2
+        assert e < T.LATENT
         if mask is not None:    # fully kept pixels equal the original latent exactly
             keep = np.broadcast_to(lmask == 1, got[0].shape)
             assert np.array_equal(got[0][keep], init[0][keep])
@@ -283,7 +285,7 @@ def test_vae_encoder_vs_oracle_and_golden(model, side):
     ref = O.from_ot(O.L().orc_vae_encode_moments(OP.h, b"vae", O.vae_params(model), O.to_ot(img)))
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_golden.npz"))[key]
     print(key, "vs oracle", rel(mom, ref), "vs independent golden", rel(mom, gold))
-    assert rel(mom, ref) < 4e-3 and rel(mom, gold) < 4e-3
+    assert rel(mom, ref) < T.EVAL and rel(mom, gold) < T.EVAL
     assert {k for k, _, _ in ctx.param_list()} == {k for k, _, _ in OP.names()}
 
 
@@ -304,10 +306,10 @@ def test_engine_encode_sample_and_img2img_roundtrip():
     rnd = O.randn(77, 0, 4 * lat * lat)
     ref = O.from_ot(O.L().orc_latent_sample(mom, V, O.fptr(rnd)))
     print("encode+sample rel-L2", rel(latent, ref))
-    assert rel(latent, ref) < 4e-3
+    assert rel(latent, ref) < T.EVAL
     got, _ = g.generate(None, want_images=False)            # seeds None: continue the Philox streams (offset 1)
     out, nfe = oracle_sample(model, lat, cond, uncond, None, None, "euler", 1.0, 1, 0.0, 10, 77, f_t_ini=0.5, init=ref[0], rng_offset=1)
-    assert g.last_n_step() == 5 and rel(got[0], out) < 5e-2
+    assert g.last_n_step() == 5 and rel(got[0], out) < T.LATENT
     g.destroy()
 
 
@@ -320,7 +322,7 @@ def test_tae_encoder_vs_oracle():
     OP = O.Params(1234)
     ref = O.from_ot(O.L().orc_tae_encode(OP.h, b"tae", O.to_ot(img)))
     print("tae encode rel-L2", rel(latent, ref))
-    assert rel(latent, ref) < 4e-3
+    assert rel(latent, ref) < T.EVAL
     g.destroy()
 
 
@@ -343,7 +345,7 @@ def test_vae_tiling_decode_and_encode_vs_oracle():
     ref_full = O.from_ot(O.L().orc_vae_decode(OP.h, b"vae", V, O.to_ot(z)))
     e_t, e_full = rel(img - 0.5, ref_t - 0.5), rel(img - 0.5, ref_full - 0.5)
     print("tiled decode vs oracle tiled", e_t, "vs oracle untiled", e_full)
-    assert e_t < 4e-3 and e_full > 2 * e_t            # it really is the tiled result (tile borders differ from the full decode)
+    assert e_t < T.EVAL and e_full > 2 * e_t            # it really is the tiled result (tile borders differ from the full decode)
     # encode: image tiles 192x192 (64 + 2*64 margin) over the 256x256 image -> 2x2 tiles
     src = rng.random((1, 3, H, W)).astype(F)
     g.seed([5])
@@ -352,7 +354,7 @@ def test_vae_tiling_decode_and_encode_vs_oracle():
     ref = O.from_ot(O.L().orc_latent_sample(mom, V, O.fptr(O.randn(5, 0, 4 * (H // 8) * (W // 8)))))
     e = rel(lat, ref)
     print("tiled encode+sample vs oracle", e)
-    assert e < 4e-3
+    assert e < T.EVAL
     g.destroy()
 
 

@@ -1,19 +1,20 @@
 """UNet evaluation parity: HIP engine (through the C host API) vs the oracle's restatement of
 src/unet.c on identical synthetic weights (both sides derive them from (seed, name, shape)).
 
-Tolerance (stated): per-evaluation relative L2 error of the predicted noise <= 4e-3.  Sources of
+Tolerance (stated): per-evaluation relative L2 error of the predicted noise <= 2e-3 (tests/tolerances.py; 4e-3 until round 4).  Sources of
 difference: fp16 Q/K/V/P in the fused attention (the reference's attention is fp32), fp32
 summation order on MFMA, fp16 storage of normalised activations that the reference rounds at the
 same point (ggml's F16 im2col / mul_mat operand conversion).
 """
 import numpy as np
+import tolerances as T
 import pytest
 
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = 4e-3
+TOL = T.EVAL
 
 
 def rel(a, b):
@@ -204,7 +205,7 @@ def test_groupnorm_statistics_from_producers_equal_two_pass(monkeypatch):
     MLSD_GN_TWO_PASS=1 the same plan runs the two-pass GroupNorm.  The statistics differ in the last fp32 bits (unshifted
     per-64-row partial sums against shifted per-chunk sums), which flips fp16 roundings of normalised activations here and there:
     the two evaluations agree at the same ~1e-3 level as any two equivalent fp16-operand implementations (tests/test_golden_cpu.py),
-    well inside the 4e-3 parity bound both hold against the oracle and the torch vectors."""
+    well inside the parity bound both hold against the oracle and the torch vectors."""
     from mlimgsynth_amd import engine
     import golden_cases as G
     # the headline plan (batch 4 => 8 UNet inputs at the 128x128 latent): its producers run on the ping-pong tiles
@@ -220,3 +221,134 @@ def test_groupnorm_statistics_from_producers_equal_two_pass(monkeypatch):
     un2.ctx.destroy()
     assert np.isfinite(a).all() and rel(a, b) < 3e-3, rel(a, b)
     assert n_fused >= 30, n_fused                          # most of the 46 GroupNorms of the SDXL UNet take the fused form
+
+
+def test_unet_parity_in_the_ggml_f16_table_mode():
+    """north_star names "the reference ggml CPU path": ggml's CPU backend evaluates GELU (the GEGLU gate of every transformer block, src/mlblock_nn.c:168) through an
+    F16 lookup table, i.e. with the input and the output of the activation rounded to binary16.  The oracle emulates that with orc_set_ggml_f16_tables(1) (restated from
+    ggml's published source: ggml is absent, unpinned).  The HIP path (exact fp32 GELU on the fp32 accumulator, product rounded to fp16 once) is held to the SAME bound
+    against both modes; profiles/r4_parity_f16_tables.txt lists the numbers (tools/parity_f16_tables.py)."""
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(43)
+    model, lat, n = "tinyxl", 8, 2
+    un = engine.Unet(model, lat, lat, n)
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 5
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.array([14.6, 0.7], np.float32)
+    got = un.run(x, cond, label, sigma)
+    ref0, _ = oracle_eval(model, x, cond, label, sigma)
+    try:
+        O.L().orc_set_ggml_f16_tables(1)
+        ref1, _ = oracle_eval(model, x, cond, label, sigma)
+    finally:
+        O.L().orc_set_ggml_f16_tables(0)
+    e0 = max(rel(got[i], ref0[i]) for i in range(n))
+    e1 = max(rel(got[i], ref1[i]) for i in range(n))
+    d = max(rel(ref1[i], ref0[i]) for i in range(n))
+    print(f"{model}: HIP vs oracle exact-GELU {e0:.3e}, vs ggml-F16-table mode {e1:.3e}; the two oracle modes differ by {d:.3e}")
+    assert d > 0, "the table mode changed nothing: is the switch wired?"
+    assert e0 < TOL and e1 < TOL
+
+
+def test_a_timed_out_handoff_is_retried_on_the_handoff_free_plan():
+    """VERDICT r3 item 7.  The headline plan (SDXL 128x128, batch 8) has ~200 launches that exchange data inside the launch (LayerNorm statistics; stream-K slabs).  When
+    one of them gives up waiting -- simulated by raising the sticky word exactly as a timed-out launch does (mlctx_debug_raise_giveup; the real give-up on a CU-masked
+    stream is test_kernels_gpu.py::test_stream_k_gives_up_on_a_cu_masked_stream) -- the evaluation is NOT failed: the flag / counter blocks are zeroed, the plan is
+    switched to plain tiles + separate LayerNorm launches, the evaluation runs again in the same process and the retry is counted."""
+    import ctypes
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    for f in ("mlctx_handoff_ops", "mlctx_handoff_check", "mlctx_ln_fused"): getattr(L, f).argtypes = [_lib.vp]
+    L.mlctx_debug_raise_giveup.argtypes = [_lib.vp, ctypes.c_int]
+    rng = np.random.default_rng(12)
+    n, lat = 8, 128
+    un = engine.Unet("sdxl", lat, lat, n)
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.linspace(9.0, 0.3, n).astype(np.float32)
+    n_ops = L.mlctx_handoff_ops(un.ctx.h)
+    assert n_ops >= 100 and L.mlctx_ln_fused(un.ctx.h) >= 100
+    ref = un.run(x, cond, label, sigma)
+    r0 = L.mlctx_handoff_retries()
+    assert L.mlctx_debug_raise_giveup(un.ctx.h, 1) == 1
+    got = un.run(x, cond, label, sigma)                       # succeeds: re-run on the hand-off-free plan
+    assert L.mlctx_handoff_retries() == r0 + 1
+    assert L.mlctx_handoff_ops(un.ctx.h) == 0 and L.mlctx_ln_fused(un.ctx.h) == 0
+    assert np.isfinite(got).all() and rel(got, ref) < 3e-3 and not np.array_equal(got, ref)      # other kernels: the last bits differ, the result does not
+    assert np.array_equal(un.run(x, cond, label, sigma).view(np.uint32), got.view(np.uint32))
+    assert L.mlctx_handoff_retries() == r0 + 1 and L.mlctx_handoff_check(un.ctx.h) == 0
+
+
+def test_generation_survives_a_timed_out_handoff():
+    """The same through the engine: a generation whose UNet plan reports a give-up at the end of the denoising loop is run again from its saved Philox states (and
+    initial latent) on the hand-off-free plan, inside the same mlis_amd_generate call; the caller sees a success and mlis_amd_handoff_retries() == 1."""
+    import ctypes
+    from mlimgsynth_amd import engine, _lib
+    L = engine._proto2()
+    L.mlis_amd_handoff_retries.argtypes = [_lib.vp]
+    L.mlctx_debug_raise_giveup.argtypes = [_lib.vp, ctypes.c_int]
+    L.mlctx_handoff_ops.argtypes = [_lib.vp]
+    g = engine.Generator("sdxl", 1024, 1024, 4, n_step=2, cfg_scale=7.0, s_ancestral=1.0)
+    P = g.P
+    rng = np.random.default_rng(3)
+    cond = rng.standard_normal((77, P.n_ctx)).astype(np.float32)
+    lab = rng.standard_normal(P.ch_adm_in).astype(np.float32)
+    g.set_cond(cond, lab, cond * 0, lab)
+    uc = g.unet_ctx()
+    assert L.mlctx_handoff_ops(uc.h) > 0
+    ref, _ = g.generate([5, 6, 7, 8], want_images=False)
+    assert L.mlis_amd_handoff_retries(g.h) == 0
+    assert L.mlctx_debug_raise_giveup(uc.h, 1) == 1
+    got, _ = g.generate([5, 6, 7, 8], want_images=False)
+    assert L.mlis_amd_handoff_retries(g.h) == 1 and L.mlctx_handoff_ops(uc.h) == 0
+    assert np.isfinite(got).all() and rel(got, ref) < T.LATENT
+    again, _ = g.generate([5, 6, 7, 8], want_images=False)
+    assert np.array_equal(again, got) and L.mlis_amd_handoff_retries(g.h) == 1
+
+
+@pytest.mark.parametrize("model,lat,n,mib", [("tinyxl", 8, 2, 1), ("sdxl", 32, 2, 256)])
+def test_weight_streaming_is_bit_identical_to_the_resident_plan(model, lat, n, mib):
+    """BASELINE configs[4], the reference's --unet-split (src/unet.c:390-458: two half-graphs, weights uploaded per half, every evaluation).  Here the UNet's weights
+    live in pinned host memory and pass through TWO device slabs segment by segment, uploaded on a copy stream under the previous segment's launches.  Same launches on
+    the same operands: several evaluations in a row (slab reuse across evaluations, changing inputs) are bit-identical to the resident plan's."""
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(21)
+    res = engine.Unet(model, lat, lat, n)
+    st = engine.Unet(model, lat, lat, n, stream_weights_mib=mib)
+    nseg, per_eval, slab, host = st.ctx.streaming_info()
+    print(f"{model}: {nseg} segments, {per_eval / 2**20:.1f} MiB streamed per evaluation through 2 x {slab / 2**20:.0f} MiB slabs; resident params of the streaming plan "
+          f"{st.ctx.info().mem_params / 2**20:.1f} MiB vs {res.ctx.info().mem_params / 2**20:.1f} MiB")
+    assert nseg >= 3 and st.ctx.info().mem_params < res.ctx.info().mem_params
+    P = res.P
+    for rep in range(3):
+        x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+        cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+        label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32) if P.ch_adm_in else None
+        sigma = rng.uniform(0.2, 12.0, n).astype(np.float32)
+        a = res.run(x, cond, label, sigma)
+        b = st.run(x, cond, label, sigma)
+        assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), rep
+
+
+def test_generation_with_unet_split_matches_the_resident_engine():
+    """The engine with MLIS_AmdConfig.unet_split (= MLIS_OPT_UNET_SPLIT of the public API): a whole 3-step generation, latent bit-identical to the resident engine's."""
+    from mlimgsynth_amd import engine
+    rng = np.random.default_rng(4)
+    outs = []
+    for split in (0, 2):       # 2 MiB slabs: the tinyxl UNet is cut into many segments
+        g = engine.Generator("tinyxl", 64, 64, 2, n_step=3, cfg_scale=7.0, s_ancestral=1.0, unet_split=split)
+        P = g.P
+        r = np.random.default_rng(4)
+        cond = r.standard_normal((77, P.n_ctx)).astype(np.float32)
+        lab = r.standard_normal(P.ch_adm_in).astype(np.float32)
+        g.set_cond(cond, lab, cond * 0.5, lab)
+        lat, _ = g.generate([11, 12], want_images=False)
+        outs.append(lat)
+        if split:
+            assert g.unet_ctx().streaming_info() is not None
+        g.destroy()
+    assert np.isfinite(outs[1]).all() and np.array_equal(outs[0], outs[1])
