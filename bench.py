@@ -65,7 +65,7 @@ def kernel_roofline(g, workload, B):
     ms = uc.profile_ops()
     agg = {}
     for (lab, fl), t, nb in zip(ops, ms, nbytes):
-        lab = re.sub(r",k/\d+>", ">", lab)       # split-K launches run the same kernel instantiation
+        lab = re.sub(r",k/\d+p?>", ">", lab)       # split-K launches run the same kernel instantiation
         e = agg.setdefault(lab, [0, 0.0, 0.0, 0.0])
         e[0] += 1; e[1] += float(t); e[2] += fl; e[3] += nb
     dom = max(agg.items(), key=lambda kv: kv[1][1])

@@ -167,6 +167,11 @@ void mlsd_gemm_set_debug(int d);
  * finishes a tile last sums the slabs in slice order and runs the epilogue: bit-identical to the two-launch form).  Default 0: the
  * two-launch form measured faster on MI355X (profiles/r3_gemm_splitk_inline.txt) */
 void mlsd_gemm_set_splitk_inline(int on);
+/* split-K launches (ksplit > 1, ticket counters in sk_flags) on the 64x128 / 128x128 tiles add their K slices INSIDE the launch, all blocks of a tile sharing the work
+ * (round 4; bit-identical to the two-launch form).  Measured SLOWER than the second launch (a dispatch boundary is the cheaper grid-wide barrier on MI355X): only in
+ * builds with EXPERIMENTS=1, and off unless switched on here / by MLSD_SPLITK_PAR=1. */
+void mlsd_gemm_set_splitk_parallel(int on);
+int mlsd_gemm_splitk_parallel(const mlsd_gemm_args* a);   /* 1 if this launch would do so (an in-launch hand-off: mlctx_handoff_check covers it) */
 size_t mlsd_gemm_streamk_ws_bytes(void);   /* workspace of a stream-K launch (slabs); the flags are 256 x 4 bytes, zeroed once */
 void mlsd_gemm_set_cus(int n);      /* CUs a persistent GEMM launch occupies (default 256; 128 for half-chip partitions) */
 void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */

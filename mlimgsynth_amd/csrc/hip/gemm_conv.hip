@@ -104,8 +104,16 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE, int DBG = 0, bool REG = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p)
+// PAR (round 4): a split-K launch that REDUCES ITS SLICES ITSELF, in parallel.  SD1.5 batch 1 is bound by its dispatch count (~4.5 us per dependent dispatch, 498 per
+// evaluation, 96 of them splitk_reduce).  Every block writes its raw partial tile to its slice of the workspace with write-through stores (as the two-launch form does),
+// takes a ticket on the TILE's arrival counter, and one thread waits (bounded) until all K slices of the tile have arrived -- the whole grid is resident: the launcher
+// checks tiles x slices against the occupancy of this kernel.  Then the blocks of the tile SHARE the reduction: block z adds, for its 1/nsl of the tile's 4-column
+// groups, the slices in order 0, 1, ... (agent-scope loads) and applies the epilogue -- the same operations in the same order as splitk_reduce: bit-identical to the
+// two-launch form.  (The round-3 variant let the LAST block reduce the whole tile alone at one CU's load bandwidth and lost to the second launch; profiles/NOTES.md.)
+// A departure counter clears both words for the next launch; a give-up raises the sticky word sk_flag[4095] (mlctx_handoff_check -> retry on the two-launch plan).
+// `pe` = the epilogue as requested (p carries the raw-partial form).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE, int DBG = 0, bool REG = false, bool PAR = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p, const GemmP pe)
 {
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -453,7 +461,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             default: break;
             }
             if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
-            if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + n) = v;
+            if constexpr (PAR) {      // raw partial sums, written through to the agent-coherent level (other XCDs' blocks read them in this launch)
+                const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)C32, 0, 0x7fffffff, 0x00020000);
+                const f32x4 w = {v.x, v.y, v.z, v.w};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), rsw, (int)(((long)m * p.ldc32 + n) * 4), 0, 16);   // aux 16 = sc1
+            } else if (C32) *reinterpret_cast<float4*>(C32 + (long)m * p.ldc32 + n) = v;
             if (p.C16) {
                 f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
@@ -535,6 +547,73 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if constexpr (PAR) {
+            // ---- the slices of this tile are added by the blocks that computed them
+            const int nsl = gridDim.y, z = blockIdx.y;
+            unsigned* const arr = p.sk_flag + blockIdx.x;             // arrivals of this tile (2047 tiles at most: the launcher checks)
+            unsigned* const dep = p.sk_flag + 2048 + blockIdx.x;      // departures
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's partial tile is at the coherent level
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(arr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsl && ++spins < (1u << 21)) __builtin_amdgcn_s_sleep(2);
+                if (spins >= (1u << 21)) __hip_atomic_store(p.sk_flag + 4095, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reported, not hung (mlctx_handoff_check)
+            }
+            __syncthreads();
+            const int rows = min(BM, p.M - m0), c4 = min(BN, p.N - n0) >> 2;      // (N % 4 == 0 on this path)
+            const int items = rows * c4, per = (items + nsl - 1) / nsl;
+            const int i1 = min(items, (z + 1) * per);
+            const auto rsl = __builtin_amdgcn_make_buffer_rsrc((void*)p.C32, 0, 0x7fffffff, 0x00020000);   // slice 0; slice zz at + zz * ws_stride floats
+            for (int it = z * per + tid; it < i1; it += THREADS) {
+                const int r = it / c4, m = m0 + r, n = n0 + ((it - r * c4) << 2);
+                const int off = (int)(((long)m * p.N + n) * 4);
+                float4 v = make_float4(0, 0, 0, 0);
+                for (int z0 = 0; z0 < nsl; z0 += 4) {                // 4 slices in flight, added in slice order (the order of splitk_reduce)
+                    f32x4 t[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        t[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsl, off, (int)((long)min(z0 + b, nsl - 1) * p.ws_stride * 4), 16));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (z0 + b < nsl) {
+                            if (z0 + b == 0) v = make_float4(t[b][0], t[b][1], t[b][2], t[b][3]);
+                            else { v.x += t[b][0]; v.y += t[b][1]; v.z += t[b][2]; v.w += t[b][3]; }
+                        }
+                }
+                // the requested epilogue: the operations of splitk_reduce, in its order
+                if (pe.bias) { const float4 b = *reinterpret_cast<const float4*>(pe.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (pe.biasm) { const float b = pe.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                if (pe.rowbias) {
+                    const float4 rb = *reinterpret_cast<const float4*>(pe.rowbias + (long)(m / pe.rows_per_batch) * pe.ldrb + n);
+                    v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
+                }
+                float4 rs = make_float4(0, 0, 0, 0);
+                if (pe.resid) rs = *reinterpret_cast<const float4*>(pe.resid + (long)m * pe.ldr + n);
+                if (pe.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                switch (pe.act) {
+                case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
+                case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
+                case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
+                case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
+                default: break;
+                }
+                if (!pe.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                if (pe.C32) *reinterpret_cast<float4*>(pe.C32 + (long)m * pe.ldc32 + n) = v;
+                if (pe.C16) {
+                    f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    *reinterpret_cast<f16x4*>(pe.C16 + (long)m * pe.ldc16 + n) = h;
+                }
+            }
+            // departures: the last block to leave the tile clears both counters for the next launch (nobody can still be polling: every block has passed the wait)
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)(nsl - 1)) {
+                    __hip_atomic_store(arr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         return;
     }
     // scalar fallback (N or a stride not a multiple of 4: 3-channel image outputs, padded 4-channel latents)
@@ -587,6 +666,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 }
 
 #include "gemm_pp.hpp"
+#include "gemm_skinny.hpp"
 
 // ---- split-K second pass: sum the slices in fixed order (deterministic), then the same epilogue as above.
 // One thread per 4 consecutive columns; only launched when the wide-epilogue alignment conditions hold.
@@ -646,6 +726,28 @@ int g_gemm_epi = 0;    // 0: wide LDS-transposed epilogue when shapes allow (def
 // SD1.5-sized problem (profiles/r3_gemm_splitk_inline.txt: 512x1280x5120 k/6 25.2 -> 29.0 us, 128x1280x5120 k/8 16.9 -> 20.3 us): the block that
 // finishes a tile last reads all of the tile's slabs alone, at one CU's load bandwidth, where the second launch spreads the same bytes over the chip.
 int g_gemm_sk_inline = 0;
+// split-K whose slices are added IN the launch by all blocks of a tile together (gemm_kernel PAR, round 4): on by default where the whole grid is resident
+// EXPERIMENTS builds only, and off unless MLSD_SPLITK_PAR=1 / mlsd_gemm_set_splitk_parallel(1): measured slower than the two-launch form (profiles/NOTES.md)
+int g_gemm_sk_par = -1;
+bool sk_par_on()
+{
+    if (g_gemm_sk_par < 0) { const char* e = getenv("MLSD_SPLITK_PAR"); g_gemm_sk_par = (e && *e && *e != '0') ? 1 : 0; }
+    return g_gemm_sk_par != 0;
+}
+
+int device_cus();
+// may this split-K launch add its slices itself (gemm_kernel PAR)?  Every block waits for the other slices of its tile, so the WHOLE grid must be resident at once:
+// tiles x slices <= CUs x blocks per CU of the tile (64x128: 3, 128x128: 2; LDS-bound), on an unpartitioned device; counters: 2047 tiles at most
+bool splitk_par_ok(const mlsd_gemm_args* a, int BM, int nsplit, long tiles)
+{
+#ifndef MLSD_GEMM_EXPERIMENTS
+    return false;       // (the kernels are not in the product build)
+#endif
+    if (!sk_par_on() || !a->sk_flags || nsplit < 2 || tiles > 2047) return false;
+    const int cus = device_cus();
+    if (cus < g_gemm_ncu || g_gemm_ncu < 256) return false;
+    return tiles * nsplit <= (long)cus * (BM == 64 ? 3 : 2);
+}
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, bool REG = false>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
@@ -690,9 +792,21 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     constexpr size_t EPI = (size_t)WAVES_M * WAVES_N * 32 * 64 * 4;      // 8 KiB per wave
     constexpr size_t LDS = RING > EPI ? RING : EPI;
     const dim3 grid(p.nbm * p.nbn, nsplit), block(THREADS);
+    // ---- slices added in the launch by the blocks of the tile together (gemm_kernel PAR): the small tiles of the split-K launches, whole grid resident
+#ifdef MLSD_GEMM_EXPERIMENTS   /* measured SLOWER than the second launch (SD1.5 b1 evaluation 7.17 -> 7.76 ms, profiles/NOTES.md): a dispatch boundary is the cheaper grid barrier */
+    if constexpr ((BM == 64 || BM == 128) && BN == 128 && BK == 64 && NSTAGE == 2 && !REG) {
+        if (nsplit > 1 && !inl && splitk_par_ok(a, BM, nsplit, p.nbm * p.nbn)) {
+            p.sk_flag = a->sk_flags;
+            auto kfn = a->conv ? gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, false, true> : gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, false, true>;
+            if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            hipLaunchKernelGGL(kfn, grid, block, LDS, st, p, pe);
+            return mlsd_check_launch("gemm_kernel(split-K, reduced in the launch)");
+        }
+    }
+#endif
     auto go = [&](auto kfn) -> int {
         if (LDS > 65536) MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, p, pe);
         if (nsplit > 1 && !inl) {
             const long n = (long)a->M * (a->N >> 2);
             hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
@@ -872,6 +986,75 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, false, NPH, SCH>);
 }
 
+// ---- skinny-M weight-streaming kernel (gemm_skinny.hpp, tile variant 29): M <= 128, K in whole 64-wide steps, conv taps of whole steps; the K slices go to the
+// split-K workspace and splitk_reduce (declared above) adds them and applies the epilogue -- also for ONE slice
+bool skinny_eligible(const mlsd_gemm_args* a)
+{
+    if (a->M > 128 || a->act == MLSD_ACT_GEGLU || (a->K & 63) || a->K < 128 || (a->N & 3) || !a->ws || ((uintptr_t)a->ws & 15)) return false;
+    if (a->conv && (a->upsample || (a->Cin & 63) || a->KH * a->KW > 9)) return false;
+    return (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&
+           (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) && (!a->bias || !((uintptr_t)a->bias & 15)) &&
+           (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15)));
+}
+
+int skinny_slices(const mlsd_gemm_args* a, int* kt_per_out)
+{
+    const int nkt = a->K / 64;
+    int s = a->ksplit < 1 ? 1 : a->ksplit;
+    if (s > nkt / 2) s = nkt / 2 > 0 ? nkt / 2 : 1;          // >= 2 K steps per slice
+    const int maxper = SKINNY_MAXG * 4;                      // (the kernel is straight-line code for up to SKINNY_MAXG groups of PF + 1 = 4 K steps)
+    if ((nkt + s - 1) / s > maxper) s = (nkt + maxper - 1) / maxper;
+    const int per = (nkt + s - 1) / s;
+    if (kt_per_out) *kt_per_out = per;
+    return (nkt + per - 1) / per;
+}
+
+int launch_skinny(const mlsd_gemm_args* a, hipStream_t st)
+{
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_;
+    p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
+    p.stride = a->stride; p.pad = a->pad; p.ups = 0;
+    p.rows_per_batch = 1; p.vec = 1; p.gw = 0;
+    int kt_per;
+    const int nsplit = skinny_slices(a, &kt_per);
+    const size_t need = (size_t)nsplit * a->M * a->N * sizeof(float);
+    if (a->ws_bytes < need) return mlsd_set_error(-1, "mlsd_gemm: skinny-M workspace too small (%zu < %zu)", (size_t)a->ws_bytes, need);
+    p.kt_per = kt_per; p.C32 = (float*)a->ws; p.ldc32 = a->N; p.ws_stride = (long)a->M * a->N;
+    GemmP pe = p;                                  // the epilogue as requested: applied by splitk_reduce
+    pe.bias = a->bias; pe.biasm = a->bias_m; pe.act_post = a->act_after_resid; pe.rowbias = a->rowbias; pe.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+    pe.ldrb = a->ldrb; pe.resid = a->resid; pe.ldr = a->ldr; pe.act = a->act;
+    pe.C32 = a->C32; pe.ldc32 = a->ldc32; pe.C16 = (_Float16*)a->C16; pe.ldc16 = a->ldc16;
+    // K steps in flight per thread.  Measured (profiles/r4_gemm_skinny_ablation.txt, 128x1280x11520 conv, cold weights): PF = 7 (128 KB of LDS, one block per CU) 30.2 us,
+    // PF = 3 (64 KB, two blocks per CU: one block's barrier / LDS / MFMA chain overlaps the other's) 23.9 us; the weight stream alone 19.2 / 16.1 us
+    constexpr int PF = 3;
+    const dim3 grid((a->N + 63) / 64, nsplit), block(256);
+    auto go = [&](auto kfn, int rows, int pf = PF) -> int {
+        const size_t lds = (size_t)(pf + 1) * rows * 128;
+        static thread_local const void* attr_done[16]; static thread_local int n_done = 0;      // (one host call per kernel, not per launch)
+        bool seen = false;
+        for (int i = 0; i < n_done; ++i) seen |= attr_done[i] == (const void*)kfn;
+        if (!seen) {
+            MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (n_done < 16) attr_done[n_done++] = (const void*)kfn;
+        }
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+        const long n = (long)a->M * (a->N >> 2);
+        hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
+        return mlsd_check_launch("gemm_skinny_kernel");
+    };
+#ifdef MLSD_GEMM_EXPERIMENTS   /* timing-only builds (mlsd_gemm_set_debug): 16 = the weight stream alone with 7 K steps in flight (128 KB of LDS), 32 = that depth with the arithmetic, 48 = the stream alone at the product depth */
+    if (g_gemm_dbg == 16) return a->conv ? go(gemm_skinny_kernel<true, 8, 7, 1>, 128, 7) : go(gemm_skinny_kernel<false, 8, 7, 1>, 128, 7);
+    if (g_gemm_dbg == 32) return a->conv ? go(gemm_skinny_kernel<true, 8, 7>, 128, 7) : go(gemm_skinny_kernel<false, 8, 7>, 128, 7);
+    if (g_gemm_dbg == 48) return a->conv ? go(gemm_skinny_kernel<true, 8, 3, 1>, 128, 3) : go(gemm_skinny_kernel<false, 8, 3, 1>, 128, 3);
+#endif
+    if (a->M <= 16) return a->conv ? go(gemm_skinny_kernel<true, 1, PF>, 32) : go(gemm_skinny_kernel<false, 1, PF>, 32);
+    if (a->M <= 64) return a->conv ? go(gemm_skinny_kernel<true, 4, PF>, 64) : go(gemm_skinny_kernel<false, 4, PF>, 64);
+    return a->conv ? go(gemm_skinny_kernel<true, 8, PF>, 128) : go(gemm_skinny_kernel<false, 8, PF>, 128);
+}
+
 int g_gemm_variant = -1;   // >=0: forced tile variant (benchmarking)
 #ifdef MLSD_GEMM_EXPERIMENTS
 extern "C" int mlsd_gemm_w4_eligible(const mlsd_gemm_args* a, int tile);    // gemm_w4.hip (tile 0: 256 x 256, 1: 128 x 320)
@@ -913,6 +1096,7 @@ const Variant kVariants[] = {
     {"128x320x64w4", 128, 320, 256},    // 27: the same on the 128 x 320 tile (4 waves of 64 x 160)
     {"128x320x64ppsk", 128, 320, 256},  // 28: variant 18 as STREAM-K (round 4): N = 320 / 640 / 1280 outputs with FEW tiles and long K -- the 3x3 convolutions of SD1.5 batch 1
                                         //     (8192x320x2880: 64 tiles, 2048x640x5760: 32, 512x1280x11520: 16) -- dealt over all 256 CUs in K-tile units
+    {"skinny128x64", 128, 64, 512},     // 29: M <= 128 weight streaming (gemm_skinny.hpp): all rows in one block, weights global -> registers, 7 K steps in flight, K slices + fixed-order reduce
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -974,6 +1158,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 19:
         if (sk_eligible(a, 256, 256)) return launch_pp<256, 256, 2, 2, false, true>(a, st);
         return pp_eligible(a, 256, 256) ? launch_pp<256, 256, 2, 2, false>(a, st) : launch<256, 256, 64, 4, 4, 2>(a, st);
+    case 29:
+        if (skinny_eligible(a)) return launch_skinny(a, st);
+        return launch<64, 128, 64, 2, 2, 2>(a, st);
     case 28:
         if (sk_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, true>(a, st);
         [[fallthrough]];
@@ -1041,6 +1228,21 @@ MLSD_API int mlsd_has_experiments(void)
     return 0;
 #endif
 }
+MLSD_API void mlsd_gemm_set_splitk_parallel(int on) { g_gemm_sk_par = on ? 1 : 0; }
+/* 1 if this split-K launch would add its K slices inside the launch (all blocks of a tile wait for each other: an in-launch hand-off the plan has to check) */
+MLSD_API int mlsd_gemm_splitk_parallel(const mlsd_gemm_args* a)
+{
+    if (!a || a->ksplit < 2 || !a->sk_flags) return 0;
+    const int v = pick_variant(a);
+    if (v != 0 && v != 1) return 0;
+    const int BM = v == 1 ? 64 : 128;
+    const int nout = a->N;
+    const bool vec = !(nout & 3) && (!a->C32 || (!(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15))) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&
+                     (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) && (!a->bias || !((uintptr_t)a->bias & 15)) &&
+                     (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+    const int ns = vec ? splitk_slices(a, 64, nullptr) : 1;
+    return ns > 1 && splitk_par_ok(a, BM, ns, (long)((a->M + BM - 1) / BM) * ((a->N + 127) / 128)) ? 1 : 0;
+}
 MLSD_API void mlsd_gemm_set_cus(int n) { g_gemm_ncu = n > 0 && n <= 256 ? n : 256; }
 /* diagnostics: device buffer of 8 x uint64 per block (256 blocks) that the ping-pong kernels fill with s_memtime stamps:
  * [0] kernel entry, [1] prologue done, [2] first epilogue begins, [3] first epilogue issued, [4] last epilogue begins,
@@ -1091,6 +1293,11 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     int v = pick_variant(a);
     if (v == 19 && !sk_eligible(a, 256, 256)) v = 17;
     if (v == 28 && !sk_eligible(a, 128, 320)) v = 18;
+    if (v == 29 && !skinny_eligible(a)) v = 1;
+    if (v == 29) {
+        snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", skinny_slices(a, nullptr));
+        return buf;
+    }
     if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
@@ -1103,7 +1310,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 #endif
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
-    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", ns);
+    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
     else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

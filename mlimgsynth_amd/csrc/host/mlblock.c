@@ -22,6 +22,7 @@
 #define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile (256 x 256) */
 #define VARIANT_STREAMK2 29     /* the same on the 128 x 320 tile (round 4) */
 #define IS_STREAMK(v) ((v) == VARIANT_STREAMK || (v) == VARIANT_STREAMK2)
+#define VARIANT_SKINNY 30       /* the skinny-M weight-streaming kernel (gemm_skinny.hpp): always runs through the split-K workspace */
 #define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile; word 4095: sticky give-up */
 #define LN_CNT_WORDS 8192       /* LayerNorm fold: arrival / departure counters per (row block, wave row); word 8191: sticky give-up */
 
@@ -149,7 +150,7 @@ MLB_API int mlctx_handoff_ops(const MLCtx* C)
 	for (int i=0;i<C->n_ops;++i) {
 		const MLOp *o = &C->ops[i];
 		if (o->kind != OP_GEMM) continue;
-		if (o->u.gemm.ln_y16 || (IS_STREAMK(o->u.gemm.tile_variant) && o->u.gemm.sk_flags)) ++n;
+		if (o->u.gemm.ln_y16 || (IS_STREAMK(o->u.gemm.tile_variant) && o->u.gemm.sk_flags) || mlsd_gemm_splitk_parallel(&o->u.gemm)) ++n;
 	}
 	return n;
 }
@@ -175,7 +176,7 @@ MLB_API int mlctx_handoffs_off(MLCtx* C)
 			if (i + 1 < C->n_ops && C->ops[i+1].kind == OP_LN && C->ops[i+1].fused) { C->ops[i+1].fused = 0; C->n_ln_fused--; }
 			++n;
 		}
-		if (IS_STREAMK(g->tile_variant) && g->sk_flags) { g->sk_flags = NULL; ++n; }
+		if ((IS_STREAMK(g->tile_variant) || g->ksplit > 1) && g->sk_flags) { g->sk_flags = NULL; ++n; }     /* (split-K: back to the two-launch form) */
 	}
 	if (n && C->graph_exec) { mlsd_graph_destroy(C->graph_exec); C->graph_exec = NULL; }
 	return n;
@@ -773,7 +774,7 @@ static int select_gemm(MLCtx* C, MLOp* op)
 		g->tile_variant = best; g->ksplit = ks;
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
 		if (g->ksplit > 1 && streamk_get(C, g)) return -1;
-		if (IS_STREAMK(best) && streamk_get(C, g)) return -1;
+		if ((IS_STREAMK(best) || best == VARIANT_SKINNY) && streamk_get(C, g)) return -1;
 		return 1;
 	}
 	g->tile_variant = 0; g->ksplit = 1;
@@ -800,6 +801,19 @@ static int time_gemm(MLCtx* C, mlsd_gemm_args* g, void* e0, void* e1, float* ms_
 static int gemm_candidates(MLCtx* C, mlsd_gemm_args* g, int cv[32], int cs[32])
 {
 	int nc = 0;
+	/* skinny-M weight streaming (variant 29): K slices so that (N / 64) x slices is about one / two blocks per CU */
+	if (g->M <= 128 && !(g->K & 63) && g->K >= 256 && g->act != MLSD_ACT_GEGLU && !(g->N & 3) && (!g->conv || (!g->upsample && !(g->Cin & 63))) && !streamk_get(C, g)) {
+		const int nb = (g->N + 63) / 64, nkt = g->K / 64;
+		int last = 0;
+		for (int t = 256; t <= 1024 && nc < 6; t *= 2) {
+			int s = (t + nb / 2) / nb;
+			if (s < 1) s = 1;
+			if (s > nkt / 2) s = nkt / 2;
+			while (s > 1 && (size_t)s * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) --s;
+			if (s == last) continue;
+			cv[nc] = 29; cs[nc++] = s; last = s;
+		}
+	}
 	if (g->M <= 64) { cv[nc]=1; cs[nc++]=1; cv[nc]=0; cs[nc++]=1; }
 	else {
 		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
@@ -858,7 +872,7 @@ static int tune_gemm(MLCtx* C, MLOp* op)
 		if (tune_lookup(&k, &best, &ks)) {
 			g->tile_variant = best; g->ksplit = ks;
 			if (g->ksplit > 1 && streamk_get(C, g)) return -1;
-			if (IS_STREAMK(best) && streamk_get(C, g)) return -1;
+			if ((IS_STREAMK(best) || best == VARIANT_SKINNY) && streamk_get(C, g)) return -1;
 			return 1;
 		}
 	}
@@ -930,7 +944,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 			const int c = r < sh[j].nc ? r : 0;
 			mlsd_gemm_args *g = &C->ops[i].u.gemm;
 			g->tile_variant = sh[j].cv[c] + 1; g->ksplit = sh[j].cs[c];
-			if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant)) && streamk_get(C, g)) goto done;
+			if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant) || g->tile_variant == VARIANT_SKINNY) && streamk_get(C, g)) goto done;
 		}
 		for (int j=0;j<ns;++j) if (r < sh[j].nc) sh[j].t[r] = 1e30;
 		for (int rep=0; rep<reps+1; ++rep) {             /* (the first pass warms the instruction caches of this round's kernels) */
@@ -962,7 +976,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 		if (j < 0) continue;
 		mlsd_gemm_args *g = &C->ops[i].u.gemm;
 		g->tile_variant = sh[j].k.best; g->ksplit = sh[j].k.ksplit;
-		if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant)) && streamk_get(C, g)) { changed = -1; break; }
+		if ((g->ksplit > 1 || IS_STREAMK(g->tile_variant) || g->tile_variant == VARIANT_SKINNY) && streamk_get(C, g)) { changed = -1; break; }
 	}
 done:
 	free(sh); free(op_shape); free(ms);

@@ -365,6 +365,72 @@ def test_conv2d_stream_k(K):
     assert not fl.download((1024,), np.uint32).any()
 
 
+# ---- skinny-M weight streaming (round 4, tile variant 29, gemm_skinny.hpp)
+@pytest.mark.parametrize("M,N,Kd,ksplit,conv,mode", [
+    (128, 1280, 11520, 13, 1, "f32res"), (128, 1280, 11520, 26, 1, "f32"), (128, 1280, 23040, 13, 1, "f32"), (128, 1280, 2560, 13, 1, "f32"), (128, 1280, 1280, 10, 1, "f32res"),
+    (128, 1280, 1280, 10, 0, "f16"), (128, 1280, 5120, 12, 0, "f32res"), (128, 3840, 1280, 4, 0, "f16"), (2, 20160, 1280, 1, 0, "f32"), (2, 1280, 1280, 10, 0, "f32silu"),
+    (2, 1280, 320, 2, 0, "f16silu"), (64, 640, 5760, 9, 1, "f32"), (100, 264, 1088, 5, 0, "f32res"), (128, 1280, 11520, 2, 1, "f32")])
+def test_gemm_skinny_weight_streaming(K, M, N, Kd, ksplit, conv, mode):
+    """Tile variant 29: M <= 128, every weight byte read by exactly one block straight into registers (7 K steps in flight), activations through an LDS ring, K slices
+    added in fixed order by splitk_reduce.  Against the 64x128 split-K tile (the previous choice for these shapes: both round to fp32 sums of the same fp16 products in a
+    different order) and the exact product; conv 3x3 / 1x1 at the 8x8 level of SD1.5 batch 1, linear, the time-embedding sizes (M = 2), ragged N / M, slices longer than
+    the kernel's 32 steps (ksplit 2 on K = 11520 is raised to 6); bit-repeatable."""
+    kernels, _lib = K
+    rng = np.random.default_rng(M + N + Kd + ksplit)
+    if conv:
+        k = 3 if Kd % 9 == 0 and Kd > 2560 else 1
+        cin = Kd // (k * k)
+        hw = {128: (2, 8, 8), 64: (1, 8, 8)}[M]
+        x = f16r(rng.standard_normal((hw[0], hw[1], hw[2], cin)))
+        A = x.astype(np.float16)
+        Wt = f16r(rng.standard_normal((N, k, k, cin)) / np.sqrt(Kd))                       # [cout][kh][kw][cin]: the engine layout
+        W = Wt.reshape(N, Kd).astype(np.float16)
+        # exact product through an explicit im2col (zero padding)
+        xp = np.zeros((hw[0], hw[1] + 2 * (k // 2), hw[2] + 2 * (k // 2), cin), np.float32)
+        xp[:, k // 2:k // 2 + hw[1], k // 2:k // 2 + hw[2]] = x
+        cols = np.stack([xp[:, i:i + hw[1], j:j + hw[2]] for i in range(k) for j in range(k)], 3).reshape(M, Kd)
+        exact = cols @ W.astype(np.float32).T
+    else:
+        A = f16r(rng.standard_normal((M, Kd))).astype(np.float16)
+        W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+        exact = A.astype(np.float32) @ W.astype(np.float32).T
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dW, dB, dR = dev(_lib, A), dev(_lib, W), dev(_lib, bias), dev(_lib, R)
+    dC = _lib.DeviceBuffer(M * N * 4)
+    nws = max(kernels.gemm_splitk_ws_bytes(M, N, max(ksplit, 8)), 1 << 20)
+    ws = _lib.DeviceBuffer(nws)
+    def mk(v, ks):
+        a = kernels.GemmArgs(A=dA.ptr, lda=cin if conv else Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=v + 1, ksplit=ks, ws=ws.ptr, ws_bytes=nws)
+        if conv:
+            a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, hw[0], hw[1], hw[2], cin, hw[1], hw[2], k, k, 1, k // 2
+        if mode.startswith("f16"): a.C16, a.ldc16 = dC.ptr, N
+        else: a.C32, a.ldc32 = dC.ptr, N
+        if mode.endswith("res"): a.resid, a.ldr = dR.ptr, N
+        if mode.endswith("silu"): a.act = kernels.ACT_SILU
+        return a
+    want = exact + bias
+    if mode.endswith("silu"): want = want / (1 + np.exp(-want))
+    if mode.endswith("res"): want = want + R
+    dt = np.float16 if mode.startswith("f16") else np.float32
+    tol = 1e-3 if dt == np.float16 else 3e-5
+    kernels.gemm(mk(1, min(ksplit, 8)))
+    ref = dC.download((M, N), dt).astype(np.float32)
+    assert rel(ref, want) < tol
+    a = mk(29, ksplit)
+    assert "skinny" in kernels.gemm_variant(a), kernels.gemm_variant(a)
+    first = None
+    for rep in range(3):
+        _lib.check(_lib.lib().mlsd_memset(_lib.vp(dC.ptr), 0x7C, ctypes.c_size_t(M * N * 4), None))
+        kernels.gemm(a)
+        raw = dC.download((M, N), dt)
+        got = raw.astype(np.float32)
+        assert np.isfinite(got).all() and rel(got, want) < tol, (rep, rel(got, want))
+        assert np.abs(got - ref).max() < (2e-2 if dt == np.float16 else 1e-3) * max(1.0, np.abs(ref).max()), rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+
+
 # ---- stream-K on the 128 x 320 tile (round 4, tile variant 28): the few-tile, long-K launches of SD1.5 batch 1 (N = 320 / 640 / 1280)
 SK320_CASES = [(8192, 320, 2880, 0), (2048, 640, 5760, 1), (512, 1280, 11520, 1), (128, 1280, 11520, 0), (512, 1280, 1280, 2), (1024, 960, 4096, 3), (2048, 640, 2560, 1)]
 
@@ -683,6 +749,60 @@ def test_gemm_split_k_reduced_in_the_launch(K, M, N, Kd, ksplit, variant, conv):
         L.mlsd_gemm_set_splitk_inline(0)                 # (the default: two launches even with counters)
     kernels.gemm(a)
     assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32))
+
+
+@needs_experiments
+@pytest.mark.parametrize("M,N,Kd,ksplit,variant,conv", [
+    (512, 1280, 1280, 5, 2, 0), (128, 1280, 5120, 12, 2, 0), (128, 1280, 5120, 8, 1, 0), (100, 264, 1096, 5, 2, 0), (2048, 640, 2560, 3, 1, 0),
+    (512, 1280, 11520, 6, 2, 1), (128, 1280, 11520, 13, 2, 1), (128, 320, 2880, 12, 1, 1), (2, 1280, 1280, 10, 2, 0)])
+def test_gemm_split_k_reduced_in_the_launch_by_all_blocks_of_the_tile(K, M, N, Kd, ksplit, variant, conv):
+    """Round 4 (gemm_kernel PAR): a split-K launch that was given ticket counters adds its K slices itself -- every block writes its raw partial tile through, waits for
+    the other slices of its TILE, and reduces 1 / nslices of the tile's 4-column groups in slice order with the requested epilogue (bias, SiLU, residual, fp32 + fp16
+    outputs here).  Bit-identical to the two-launch form (same additions in the same order), bit-repeatable, counters back at zero; with the switch off, or when the grid
+    would not be resident at once, the same arguments run as two launches."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_splitk_parallel.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(M + N + Kd + ksplit)
+    if conv:
+        cin = Kd // 9
+        hw = {512: (2, 16, 16), 128: (2, 8, 8)}[M]
+        x = f16r(rng.standard_normal((hw[0], cin, hw[1], hw[2])))
+        A = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16)
+    else:
+        A = f16r(rng.standard_normal((M, Kd))).astype(np.float16)
+    W = f16r(rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    dB, dR = dev(_lib, rng.standard_normal(N).astype(np.float32)), dev(_lib, rng.standard_normal((M, N)).astype(np.float32))
+    dC32, dC16 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
+    ws = _lib.DeviceBuffer(nws)
+    flags = dev(_lib, np.zeros(4096, np.uint32))
+    a = kernels.GemmArgs(A=dA.ptr, lda=cin if conv else Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, resid=dR.ptr, ldr=N, act=kernels.ACT_SILU,
+                         C32=dC32.ptr, ldc32=N, C16=dC16.ptr, ldc16=N, tile_variant=variant, ksplit=ksplit, ws=ws.ptr, ws_bytes=nws)
+    if conv:
+        a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, hw[0], hw[1], hw[2], cin, hw[1], hw[2], 3, 3, 1, 1
+    assert L.mlsd_gemm_splitk_parallel(ctypes.byref(a)) == 0       # no counters: two launches
+    kernels.gemm(a)
+    ref32, ref16 = dC32.download((M, N), np.float32), dC16.download((M, N), np.float16)
+    assert np.isfinite(ref32).all()
+    a.sk_flags = flags.ptr
+    L.mlsd_gemm_set_splitk_parallel(1)
+    assert L.mlsd_gemm_splitk_parallel(ctypes.byref(a)) == 1 and "p>" in kernels.gemm_variant(a)
+    for rep in range(4):
+        L.mlsd_memset(_lib.vp(dC32.ptr), 0xff, ctypes.c_size_t(M * N * 4), None)
+        L.mlsd_memset(_lib.vp(dC16.ptr), 0xff, ctypes.c_size_t(M * N * 2), None)
+        kernels.gemm(a)
+        assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32)), rep
+        assert np.array_equal(dC16.download((M, N), np.float16).view(np.uint16), ref16.view(np.uint16)), rep
+        assert not flags.download((4096,), np.uint32).any(), rep          # arrivals, departures and the sticky word are zero again
+    L.mlsd_gemm_set_splitk_parallel(0)
+    try:
+        assert L.mlsd_gemm_splitk_parallel(ctypes.byref(a)) == 0
+        kernels.gemm(a)
+        assert np.array_equal(dC32.download((M, N), np.float32).view(np.uint32), ref32.view(np.uint32))
+    finally:
+        L.mlsd_gemm_set_splitk_parallel(0)      # (the default)
 
 
 @pytest.mark.parametrize("M,N,Kd,res", [(8192, 1280, 1280, 1), (8192, 1280, 5120, 1), (1024, 1280, 320, 0), (2048, 640, 640, 1), (4096, 320, 256, 0), (128, 1280, 192, 1),
