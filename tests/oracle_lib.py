@@ -58,6 +58,8 @@ def L():
             import subprocess
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         l = ctypes.CDLL(ORACLE_SO)
+        # (the GPU boxes show 256 CPUs shared between pods: OpenMP's default of one thread per CPU oversubscribes them; bench.py's cpu_baseline uses 64 too)
+        l.orc_set_threads(min(os.cpu_count() or 8, 64))
         OTP = ctypes.POINTER(OT)
         OPP = ctypes.POINTER(OParam)
         l.ot_new.restype = OTP
