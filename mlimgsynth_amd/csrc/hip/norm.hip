@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnP p, float* __restric
 // ONE-DISPATCH GroupNorm for small maps (round 4): SD1.5 batch 1 is bound by its dispatch count (~4.5 us per dependent dispatch, 498 per evaluation), and on
 // the 8x8 .. 32x32 levels an (image, group) slab is 10..80 KB.  One block per (image, group) holds its slab in registers (each element read ONCE), takes the mean
 // and the centred sum of squares with two block reductions (fixed order: deterministic, and better conditioned than single-pass sums), normalises and stores.
-// A slab row is cg*4 bytes of one pixel (160 B at C = 1280), so this form is for cg % 4 == 0 and slabs of <= GN1_MAXI float4 per thread; the two-kernel form
+// A slab row is cg*4 bytes of one pixel (160 B at C = 1280), so this form is for cg % 4 == 0 and slabs of <= GN1_MAXI float4 per thread (40 KB); the two-kernel form
 // keeps everything else (its 1024 blocks stream the big maps better than 64 blocks can: measured in round 2).
-constexpr int GN1_MAXI = 20;      // float4 per thread: slabs of up to 256 * 20 * 4 = 20480 elements
+constexpr int GN1_MAXI = 10;      // float4 per thread: slabs of up to 256 * 10 * 4 = 10240 elements (40 KB).  Measured per GroupNorm in the SD1.5 b1 plan (rocprofv3 dispatch times,
+// two kernels -> one): n2 hw64 c1280 11.2 -> 7.4 us, hw64 c2560 16.2 -> 8.5, hw256 c1280 13.8 -> 12.4; 80 KB slabs LOSE (hw1024 c640 13.5 -> 19.5 us: 64 blocks cannot pull 5 MB as fast as 1024 can)
 __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p)
 {
     __shared__ float red[8];
