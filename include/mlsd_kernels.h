@@ -150,7 +150,8 @@ typedef struct mlsd_gemm_args {
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
 /* rows per statistics block (64 or 128) if this launch would write a->colstats, 0 if its kernel cannot */
 int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
-/* 1 if this launch (ln_* fields set) ends with the LayerNorm of its output (see mlsd_gemm_args.ln_y16) */
+/* != 0 if this launch (ln_* fields set) ends with the LayerNorm of its output (see mlsd_gemm_args.ln_y16): 1 = inside the launch, the tiles of a row block exchanging their
+ * row statistics (128x320 ping-pong tile; an in-launch hand-off); 2 = in the reduce pass of a split-K launch (one block per finished row: no hand-off; ln_ws / ln_cnt unused) */
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);

@@ -705,6 +705,67 @@ __global__ __launch_bounds__(256) void splitk_reduce(const GemmP p, const float*
     }
 }
 
+// ---- split-K second pass that ENDS WITH THE LAYERNORM of the rows it finishes (round 4).  SD1.5 batch 1 is bound by its dispatch count; where the producer of a
+// LayerNorm's input is a split-K launch, its reduce pass already holds every finished row: one block per row (N / 4 threads, a thread owns 4 consecutive columns)
+// adds the slices in slice order and applies the epilogue exactly like splitk_reduce (bit-identical fp32 output), then takes the row's mean and centred sum of squares
+// with two block reductions (fixed order) and writes fp16((v - mean) rstd gamma + beta): the LayerNorm launch (ggml_norm + mul + add, src/mlblock_nn.c:65-71)
+// disappears.  No cross-block hand-off: nothing to time out.
+__global__ __launch_bounds__(1024) void splitk_reduce_ln(const GemmP p, const float* __restrict__ ws, int nsplit)
+{
+    __shared__ float red[2][16];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int n = tid * 4;
+    const bool in = n < p.N;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (in) {
+        v = *reinterpret_cast<const float4*>(ws + (long)m * p.N + n);
+        for (int z = 1; z < nsplit; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(ws + z * p.ws_stride + (long)m * p.N + n);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (p.rowbias) {
+            const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        float4 rs = make_float4(0, 0, 0, 0);
+        if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+        if (p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+        switch (p.act) {
+        case MLSD_ACT_SILU: v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); break;
+        case MLSD_ACT_GELU: v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); break;
+        case MLSD_ACT_GELU_QUICK: v.x = gelu_quick_f(v.x); v.y = gelu_quick_f(v.y); v.z = gelu_quick_f(v.z); v.w = gelu_quick_f(v.w); break;
+        case MLSD_ACT_RELU: v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); break;
+        default: break;
+        }
+        if (!p.act_post) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = v;
+    }
+    // LayerNorm of the finished row: mean, then the centred sum of squares (two passes over the registers: no cancellation), waves combined in wave order
+    float s = in ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < nw; ++w) tot += red[0][w];
+    const float mean = tot / (float)p.N;
+    float q = 0.f;
+    if (in) { const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; q = (a * a + b * b) + (c * c + d * d); }
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    float tq = 0.f;
+    for (int w = 0; w < nw; ++w) tq += red[1][w];
+    const float rstd = 1.0f / sqrtf(tq / (float)p.N + p.ln_eps);
+    if (in) {
+        const float4 g = *reinterpret_cast<const float4*>(p.ln_g + n), b = *reinterpret_cast<const float4*>(p.ln_b + n);
+        f16x4 h = {(_Float16)((v.x - mean) * rstd * g.x + b.x), (_Float16)((v.y - mean) * rstd * g.y + b.y),
+                   (_Float16)((v.z - mean) * rstd * g.z + b.z), (_Float16)((v.w - mean) * rstd * g.w + b.w)};
+        *reinterpret_cast<f16x4*>(p.ln_y + (long)m * p.ldln + n) = h;
+    }
+}
+
 // number of K slices mlsd_gemm will actually use for these args (1 = no split)
 int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
 {
@@ -809,6 +870,11 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p, pe);
         if (nsplit > 1 && !inl) {
             const long n = (long)a->M * (a->N >> 2);
+            if (a->ln_y16) {       // the reduce pass ends with the LayerNorm of its rows (mlsd_gemm_ln_fused == 2; mlsd_gemm checked that this launch qualifies)
+                GemmP pl = pe;
+                pl.ln_g = a->ln_gamma; pl.ln_b = a->ln_beta; pl.ln_eps = a->ln_eps; pl.ln_y = (_Float16*)a->ln_y16; pl.ldln = a->ldln;
+                hipLaunchKernelGGL(splitk_reduce_ln, dim3((unsigned)a->M), dim3((unsigned)(((a->N >> 2) + 63) / 64 * 64)), 0, st, pl, (const float*)a->ws, nsplit);
+            } else
             hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
         }
         return mlsd_check_launch("gemm_kernel");
@@ -1282,9 +1348,17 @@ MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
 {
     if (!a || !a->ln_y16) return 0;
     const int v = pick_variant(a);
+    // 2: a split-K launch on the general tiles whose REDUCE pass ends with the LayerNorm (splitk_reduce_ln: one block per row; no in-launch hand-off)
+    if ((v == 0 || v == 1) && a->ksplit > 1 && a->ws && a->C32 && !a->C16 && a->ln_gamma && a->ln_beta && !(a->N & 3) && a->N <= 4096 && !(a->ldln & 3) &&
+        !((uintptr_t)a->ln_y16 & 7) && !((uintptr_t)a->ln_gamma & 15) && !((uintptr_t)a->ln_beta & 15) && a->act != MLSD_ACT_GEGLU && !g_gemm_sk_inline) {
+        const bool vec = !(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
+                         (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+        if (vec && splitk_slices(a, 64, nullptr) > 1 && !splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)))
+            return 2;
+    }
     if (v != 18 || !ln_eligible(a)) return 0;
     const int e = pp_epilogue_kind(a, 320);
-    return e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN;
+    return (e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN) ? 1 : 0;
 }
 
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
@@ -1310,7 +1384,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 #endif
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
-    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
+    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : "", ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
     else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

@@ -150,7 +150,7 @@ MLB_API int mlctx_handoff_ops(const MLCtx* C)
 	for (int i=0;i<C->n_ops;++i) {
 		const MLOp *o = &C->ops[i];
 		if (o->kind != OP_GEMM) continue;
-		if (o->u.gemm.ln_y16 || (IS_STREAMK(o->u.gemm.tile_variant) && o->u.gemm.sk_flags) || mlsd_gemm_splitk_parallel(&o->u.gemm)) ++n;
+		if ((o->u.gemm.ln_y16 && mlsd_gemm_ln_fused(&o->u.gemm) == 1) || (IS_STREAMK(o->u.gemm.tile_variant) && o->u.gemm.sk_flags) || mlsd_gemm_splitk_parallel(&o->u.gemm)) ++n;
 	}
 	return n;
 }
@@ -171,7 +171,7 @@ MLB_API int mlctx_handoffs_off(MLCtx* C)
 		MLOp *o = &C->ops[i];
 		if (o->kind != OP_GEMM) continue;
 		mlsd_gemm_args *g = &o->u.gemm;
-		if (g->ln_y16) {
+		if (g->ln_y16 && mlsd_gemm_ln_fused(g) == 1) {      /* (a LayerNorm in a split-K reduce pass waits for nobody: it stays) */
 			g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL;
 			if (i + 1 < C->n_ops && C->ops[i+1].kind == OP_LN && C->ops[i+1].fused) { C->ops[i+1].fused = 0; C->n_ln_fused--; }
 			++n;
@@ -1085,6 +1085,7 @@ static void wire_ln_fold(MLCtx* C)
 	/* pass 0 sizes the scratch block (largest user), pass 1 hands the LayerNorms over */
 	for (int pass=0; pass<2; ++pass) {
 		size_t need_max = 0;
+		int any_splitk = 0;
 		for (int i=1;i<C->n_ops;++i) {
 			MLOp *l = &C->ops[i];
 			if (l->kind != OP_LN || !l->u.ln.y16 || l->u.ln.y32 || !l->u.ln.b) continue;
@@ -1094,10 +1095,13 @@ static void wire_ln_fold(MLCtx* C)
 			MLOp *o = &C->ops[j];
 			mlsd_gemm_args *g = &o->u.gemm;
 			if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
-			if ((g->M % 128) || (g->N % 320)) continue;
-			const size_t need = (size_t)(g->M / 128) * (g->N / 320) * 128 * 8;
-			if (!pass) { if (need > need_max) need_max = need; continue; }
+			/* two forms (mlsd_gemm_ln_fused): inside a single-round launch of the 128x320 ping-pong tile (needs scratch for the row statistics), or -- round 4 -- in the
+			 * reduce pass of a split-K launch (no scratch, no hand-off) */
+			const int pp_form = !(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1);
+			const size_t need = pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
+			if (!pass) { if (need > need_max) need_max = need; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }
 			if (need > C->ln_ws_bytes) continue;
+			if (!pp_form && !(g->ksplit > 1)) continue;
 			{	/* the fp16 rows are written one op EARLIER now, by a launch that is still reading its operands: they must not land in a block the arena lent to one of
 				 * them (the attention output `a`, A operand of out_proj, is released right after out_proj is recorded and has exactly the size of the next LayerNorm's
 				 * output: ADVICE r3) */
@@ -1114,11 +1118,12 @@ static void wire_ln_fold(MLCtx* C)
 				               !((const char*)g->W_ < y1 && y0 < (const char*)g->W_ + rd[2].n))) { C->n_ln_alias++; continue; }
 			}
 			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
-			if (mlsd_gemm_ln_fused(g) == 1) { l->fused = 1; C->n_ln_fused++; }
+			if (mlsd_gemm_ln_fused(g) >= 1) { l->fused = 1; C->n_ln_fused++; }
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
 		if (!pass) {
-			if (!need_max) return;
+			if (!need_max && !any_splitk) return;
+			if (!need_max) continue;
 			if (!C->ln_cnt) {
 				if (mlsd_malloc((void**)&C->ln_cnt, LN_CNT_WORDS * 4)) return;
 				if (mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream) || mlsd_stream_sync(C->stream)) return;

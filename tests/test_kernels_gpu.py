@@ -857,6 +857,58 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         kernels.gemm(a2)
 
 
+@pytest.mark.parametrize("M,N,Kd,ksplit,variant,res,conv", [(512, 1280, 1280, 3, 2, 1, 0), (512, 1280, 5120, 6, 2, 1, 0), (128, 1280, 1280, 10, 2, 1, 0), (2048, 640, 2560, 6, 1, 1, 0),
+                                                            (512, 1280, 1280, 3, 2, 0, 1), (154, 768, 3072, 4, 2, 1, 0), (100, 264, 1096, 5, 2, 0, 0)])
+def test_split_k_reduce_pass_that_ends_with_the_layernorm(K, M, N, Kd, ksplit, variant, res, conv):
+    """Round 4: where a LayerNorm's input comes from a split-K launch, the reduce pass ends with it (splitk_reduce_ln: one block per finished row, slices added in slice
+    order, epilogue, then mean / centred variance of the row by two block reductions): the LayerNorm dispatch disappears -- SD1.5 batch 1 is bound by its dispatch count.
+    Against the same launch followed by mlsd_layernorm: fp32 output bit-identical, fp16 rows equal up to the last fp16 digit (other reduction tree), bit-repeatable;
+    mlsd_gemm_ln_fused reports form 2 (no in-launch hand-off)."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_ln_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, (rng.standard_normal(N) * 2).astype(np.float32))
+    dR = dev(_lib, (rng.standard_normal((M, N)) * 3 + 1.5).astype(np.float32))
+    dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    dY0, dY1 = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
+    nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
+    ws = _lib.DeviceBuffer(nws)
+
+    def mk(dst, ln):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=variant, ksplit=ksplit, ws=ws.ptr, ws_bytes=nws)
+        if conv: a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, 2, 16, 16, Kd, 16, 16, 1, 1, 1, 0
+        if res: a.resid, a.ldr = dR.ptr, N
+        if ln: a.ln_y16, a.ldln, a.ln_gamma, a.ln_beta, a.ln_eps = dY1.ptr, N, dG.ptr, dBt.ptr, 1e-5
+        return a
+    a0, a1 = mk(dC0, False), mk(dC1, True)
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(a0)) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(a1)) == 2
+    assert "+layernorm" in kernels.gemm_variant(a1)
+    kernels.gemm(a0)
+    kernels.layernorm(dC0.ptr, N, M, N, 1e-5, dG.ptr, dBt.ptr, dY0.ptr)
+    c_ref, y_ref = dC0.download((M, N), np.uint32), dY0.download((M, N), np.float16).astype(np.float32)
+    first = None
+    for rep in range(3):
+        _lib.check(L.mlsd_memset(_lib.vp(dC1.ptr), 0xff, ctypes.c_size_t(M * N * 4), None))
+        _lib.check(L.mlsd_memset(_lib.vp(dY1.ptr), 0xff, ctypes.c_size_t(M * N * 2), None))
+        kernels.gemm(a1)
+        assert np.array_equal(dC1.download((M, N), np.uint32), c_ref), rep
+        raw = dY1.download((M, N), np.uint16)
+        y = raw.view(np.float16).astype(np.float32)
+        assert np.isfinite(y).all(), rep
+        assert np.abs(y - y_ref).max() <= 2.0 ** -9 * np.maximum(1.0, np.abs(y_ref)).max(), rep      # one fp16 digit
+        assert rel(y, y_ref) < 2e-4, rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+    # without the split (one K slice) the launch cannot honour the request and says so
+    a2 = mk(dC1, True); a2.ksplit = 1
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a2)
+
+
 def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     """A REAL give-up: the LayerNorm-ending launch 1024x1280x1280 is 32 tiles whose row-block partners wait for each other; on a stream masked to 8 of
     the 256 CUs the partners of the resident tiles never become resident while those wait, the bounded polling runs out, and the launch must (a) terminate, (b) raise the

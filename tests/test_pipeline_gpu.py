@@ -319,5 +319,13 @@ def test_bench_line_carries_the_whole_baseline_metric():
         assert abs(e["value"] - (4 if key == "sdxl_tae" else 1) * 1e3 / e["ms_per_step"]) / e["value"] < 0.02
         assert e["roofline"]["frac"] > 0 and 0 < e["unet_eval_mfma"]["frac_of_mfma_peak"] < 1
     assert d["sdxl_tae"]["config"].endswith("-tae") and d["sd15"]["config"].endswith("-vae")
+    # round 4: one rank's share of configs[3] (batch 8 per GPU) and configs[4] with the weights streamed (--unet-split)
+    b8, sp = d["sdxl_b8"], d["sdxl_tae_split"]
+    assert b8["config"] == "sdxl-1024x1024-euler_a-20-cfg7-b8-vae" and b8["value"] > 0 and b8["roofline"]["frac"] > 0 and b8["tile_table_misses"] == 0
+    assert abs(b8["value"] - 8e3 / b8["ms_per_step"]) / b8["value"] < 0.02
+    ws = sp["weight_streaming"]
+    assert sp["config"].endswith("-tae") and sp["value"] > 0 and ws["segments"] >= 2 and ws["streamed_mib_per_eval"] > 3000 and ws["h2d_gb_per_s_sustained"] > 1
+    assert ws["unet_params_on_device_mib"] < 2500 and sp["value"] < d["sdxl_tae"]["value"]          # PCIe-bound at batch 4: never faster than the resident plan
+    assert d["sd15"]["tile_table_misses"] == 0 and d["cpu_baseline"]["host_cpus"] >= d["cpu_baseline"]["cores"]
     c15 = d["cpu_baseline"]["sd15"]
     assert c15["kind"] == "port" and c15["value"] > 0 and c15["s_per_unet_eval"] > 0 and "SD1.5" in c15["sample"]

@@ -352,3 +352,29 @@ def test_generation_with_unet_split_matches_the_resident_engine():
             assert g.unet_ctx().streaming_info() is not None
         g.destroy()
     assert np.isfinite(outs[1]).all() and np.array_equal(outs[0], outs[1])
+
+
+def test_sd15_layernorms_in_the_split_k_reduce_pass_keep_the_result(monkeypatch):
+    """The SD1.5 batch-1 plan (cond + uncond: batch 2, 64x64 latent): LayerNorms whose input comes from a split-K launch run at the end of that launch's reduce pass
+    (no dispatch of their own, no hand-off: the plan still has nothing to time out on their account).  Against the plan with separate LayerNorm launches."""
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    L.mlctx_ln_fused.argtypes = [_lib.vp]; L.mlctx_handoff_ops.argtypes = [_lib.vp]
+    rng = np.random.default_rng(13)
+    n, lat = 2, 64
+    monkeypatch.setenv("MLSD_NO_LN_FOLD", "1")
+    ref = engine.Unet("sd1", lat, lat, n)
+    assert L.mlctx_ln_fused(ref.ctx.h) == 0
+    monkeypatch.delenv("MLSD_NO_LN_FOLD")
+    un = engine.Unet("sd1", lat, lat, n)
+    nf = L.mlctx_ln_fused(un.ctx.h)
+    print("LayerNorms of the SD1.5 b1 plan that end a split-K reduce pass:", nf, "of 48")
+    assert nf >= 15
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    sigma = np.array([9.0, 0.4], np.float32)
+    a = ref.run(x, cond, None, sigma)
+    b = un.run(x, cond, None, sigma)
+    assert np.isfinite(b).all() and rel(b, a) < 3e-3, rel(b, a)
+    assert np.array_equal(un.run(x, cond, None, sigma).view(np.uint32), b.view(np.uint32))
