@@ -57,6 +57,7 @@ int    mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes);
 int    mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes);   /* 0: the plan does not stream */
 void   mlctx_set_cus(MLCtx* C, int n);   /* CUs the plan's stream may use (CU-masked stream); < 256: the plan is built without in-launch hand-offs.  Before mlctx_prep */
 int    mlctx_ln_alias_refused(const MLCtx* C);
+int    mlctx_gn_fused(const MLCtx* C);   /* GroupNorms of the plan that run at the end of their producer's split-K reduce pass (MLSD_NO_GN_FOLD=1: none) */
 int    mlctx_handoff_ops(const MLCtx* C);   /* launches of the plan that hand data over inside the launch (0: nothing to check) */
 int    mlctx_handoffs_off(MLCtx* C);        /* the plan without in-launch hand-offs (plain tiles, separate LayerNorm launches); returns the ops changed; one-way */
 int    mlctx_compute_checked(MLCtx* C);     /* compute + (if the plan has hand-offs) drain, check, and ONE re-run on the hand-off-free plan after a give-up */

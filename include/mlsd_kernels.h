@@ -145,6 +145,15 @@ typedef struct mlsd_gemm_args {
 	float ln_eps;
 	float* ln_ws;
 	unsigned* ln_cnt;
+	/* GroupNorm at the END of a split-K launch's reduce pass (round 4; mlsd_gemm_gn_fused): when gn_y16 is set and the launch qualifies -- general tile, ksplit > 1, fp32
+	 * output, N % gn_groups == 0 with N / gn_groups a multiple of 4, an (image, group) slab of gn_hw * N / gn_groups <= 10240 values -- the reduce pass runs one block
+	 * per (image, group): slices added in slice order + the epilogue (C32 bit-identical to splitk_reduce), then
+	 * gn_y16[m][n] = fp16(silu?((C32 - mean) rstd gn_gamma[n] + gn_beta[n])), statistics over the gn_hw rows of the image and the group's columns
+	 * (ggml_group_norm + mul + add [+ silu], src/mlblock_nn.c:86-99,135-136).  M must be a multiple of gn_hw.  mlsd_gemm FAILS when gn_y16 is set and the launch cannot honour it. */
+	void* gn_y16; int64_t gn_ldy;
+	const float *gn_gamma, *gn_beta;
+	float gn_eps;
+	int gn_groups, gn_hw, gn_silu;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -154,6 +163,8 @@ int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
  * row statistics (128x320 ping-pong tile; an in-launch hand-off); 2 = in the reduce pass of a split-K launch (one block per finished row: no hand-off; ln_ws / ln_cnt unused) */
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
+/* 1 if this launch (gn_* fields set) ends its split-K reduce pass with the GroupNorm of its output (see mlsd_gemm_args.gn_y16) */
+int mlsd_gemm_gn_fused(const mlsd_gemm_args* a);
 const char* mlsd_gemm_variant(const mlsd_gemm_args* a);
 /* tile order inside an XCD's range: column panels `mode` tiles wide (default 8; 0 = row-major).  A/B timing knob. */
 void mlsd_gemm_set_panel(int width);

@@ -83,6 +83,7 @@ struct GemmP {
     long ldln;
     float* ln_ws;
     unsigned* ln_cnt;
+    int gn_G, gn_hw, gn_silu;   // splitk_reduce_gn: groups, rows per image, SiLU (gamma / beta / eps / output in the ln_* fields)
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -766,6 +767,99 @@ __global__ __launch_bounds__(1024) void splitk_reduce_ln(const GemmP p, const fl
     }
 }
 
+#ifdef MLSD_GEMM_EXPERIMENTS
+// ---- split-K second pass that ends with the GROUPNORM (+ SiLU) of what it finishes (round 4): one block per (image, group), the slab of HW rows x N / G columns in
+// registers (<= GNR_MAXI float4 per thread: the sizes for which the one-dispatch GroupNorm of norm.hip wins).  Slices added in slice order + epilogue as splitk_reduce
+// (bit-identical fp32 output), then mean / centred variance of the slab by two block reductions, normalise, affine, SiLU, fp16.  The GroupNorm launch that follows a
+// split-K convolution in every resnet of SD1.5's 8x8 / 16x16 levels (ggml_group_norm + mul + add + silu, src/mlblock_nn.c:86-99,135-136,146-147) disappears.
+constexpr int GNR_MAXI = 10;
+__global__ __launch_bounds__(256) void splitk_reduce_gn(const GemmP p, const float* __restrict__ ws, int nsplit)
+{
+    __shared__ float red[8];
+    const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = p.N / p.gn_G, Q4 = cg >> 2, items = p.gn_hw * Q4, c0 = g * cg;
+    const int NI = (items + 255) >> 8;
+    float4 v[GNR_MAXI];
+    long off[GNR_MAXI];
+#pragma unroll
+    for (int i = 0; i < GNR_MAXI; ++i) {
+        const int it = min(tid + i * 256, items - 1);
+        const int pix = it / Q4;
+        off[i] = ((long)img * p.gn_hw + pix) * p.N + c0 + 4 * (it - pix * Q4);      // element offset inside a slice ([M][N])
+        v[i] = make_float4(0, 0, 0, 0);
+    }
+    for (int z = 0; z < nsplit; ++z) {          // slice order; the (up to) GNR_MAXI loads of a slice are in flight together
+        float4 t[GNR_MAXI];
+#pragma unroll
+        for (int i = 0; i < GNR_MAXI; ++i) if (i < NI) t[i] = *reinterpret_cast<const float4*>(ws + z * p.ws_stride + off[i]);
+#pragma unroll
+        for (int i = 0; i < GNR_MAXI; ++i) if (i < NI) {
+            if (z == 0) v[i] = t[i];
+            else { v[i].x += t[i].x; v[i].y += t[i].y; v[i].z += t[i].z; v[i].w += t[i].w; }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNR_MAXI; ++i) {
+        const int it = tid + i * 256;
+        if (i < NI && it < items) {
+            const int pix = it / Q4, n = c0 + 4 * (it - pix * Q4), m = img * p.gn_hw + pix;
+            float4 x = v[i];
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w; }
+            if (p.biasm) { const float b = p.biasm[m]; x.x += b; x.y += b; x.z += b; x.w += b; }
+            if (p.rowbias) {
+                const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+                x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+            }
+            float4 rs = make_float4(0, 0, 0, 0);
+            if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+            if (p.act_post) { x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w; }
+            switch (p.act) {
+            case MLSD_ACT_SILU: x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); break;
+            case MLSD_ACT_GELU: x.x = gelu_tanh_f(x.x); x.y = gelu_tanh_f(x.y); x.z = gelu_tanh_f(x.z); x.w = gelu_tanh_f(x.w); break;
+            case MLSD_ACT_GELU_QUICK: x.x = gelu_quick_f(x.x); x.y = gelu_quick_f(x.y); x.z = gelu_quick_f(x.z); x.w = gelu_quick_f(x.w); break;
+            case MLSD_ACT_RELU: x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); break;
+            default: break;
+            }
+            if (!p.act_post) { x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w; }
+            if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = x;
+            v[i] = x;
+            s += (x.x + x.y) + (x.z + x.w);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float cnt = (float)cg * (float)p.gn_hw;
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNR_MAXI; ++i)
+        if (i < NI && tid + i * 256 < items) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / cnt + p.ln_eps);
+#pragma unroll
+    for (int i = 0; i < GNR_MAXI; ++i) {
+        const int it = tid + i * 256;
+        if (i < NI && it < items) {
+            const int pix = it / Q4, n = c0 + 4 * (it - pix * Q4);
+            const long m = (long)img * p.gn_hw + pix;
+            const float4 ga = *reinterpret_cast<const float4*>(p.ln_g + n), be = *reinterpret_cast<const float4*>(p.ln_b + n);
+            float y0 = (v[i].x - mean) * rstd * ga.x + be.x, y1 = (v[i].y - mean) * rstd * ga.y + be.y;
+            float y2 = (v[i].z - mean) * rstd * ga.z + be.z, y3 = (v[i].w - mean) * rstd * ga.w + be.w;
+            if (p.gn_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+            f16x4 h = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+            *reinterpret_cast<f16x4*>(p.ln_y + m * p.ldln + n) = h;
+        }
+    }
+}
+#endif  // MLSD_GEMM_EXPERIMENTS (GroupNorm in the reduce pass)
+
 // number of K slices mlsd_gemm will actually use for these args (1 = no split)
 int splitk_slices(const mlsd_gemm_args* a, int BK, int* kt_per_out)
 {
@@ -870,6 +964,14 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p, pe);
         if (nsplit > 1 && !inl) {
             const long n = (long)a->M * (a->N >> 2);
+#ifdef MLSD_GEMM_EXPERIMENTS
+            if (a->gn_y16) {       // the reduce pass ends with the GroupNorm of its (image, group) slabs (mlsd_gemm_gn_fused; mlsd_gemm checked that this launch qualifies)
+                GemmP pl = pe;
+                pl.ln_g = a->gn_gamma; pl.ln_b = a->gn_beta; pl.ln_eps = a->gn_eps; pl.ln_y = (_Float16*)a->gn_y16; pl.ldln = a->gn_ldy;
+                pl.gn_G = a->gn_groups; pl.gn_hw = a->gn_hw; pl.gn_silu = a->gn_silu;
+                hipLaunchKernelGGL(splitk_reduce_gn, dim3((unsigned)a->gn_groups, (unsigned)(a->M / a->gn_hw)), dim3(256), 0, st, pl, (const float*)a->ws, nsplit);
+            } else
+#endif
             if (a->ln_y16) {       // the reduce pass ends with the LayerNorm of its rows (mlsd_gemm_ln_fused == 2; mlsd_gemm checked that this launch qualifies)
                 GemmP pl = pe;
                 pl.ln_g = a->ln_gamma; pl.ln_b = a->ln_beta; pl.ln_eps = a->ln_eps; pl.ln_y = (_Float16*)a->ln_y16; pl.ldln = a->ldln;
@@ -1204,6 +1306,8 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     if (a->colstats && a->colstats_rows > 0 && mlsd_gemm_colstats_rows(a) != a->colstats_rows)
         return mlsd_set_error(-1, "mlsd_gemm: a GroupNorm was planned on this launch's column statistics (blocks of %d rows) but the launch "
                               "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
+    if (a->gn_y16 && !mlsd_gemm_gn_fused(a))
+        return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a GroupNorm for this launch's reduce pass but the launch would not run it (tile or K-split settings changed after planning)");
     if (a->ln_y16 && !mlsd_gemm_ln_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a LayerNorm for this launch's *_LN epilogue but the launch would not run it (tile or epilogue settings changed after planning)");
     hipStream_t st = (hipStream_t)stream;
@@ -1361,6 +1465,28 @@ MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
     return (e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN) ? 1 : 0;
 }
 
+/* 1 if this launch (gn_* fields set) ends its split-K reduce pass with the GroupNorm of its output: the plan builder then drops the GroupNorm launch */
+MLSD_API int mlsd_gemm_gn_fused(const mlsd_gemm_args* a)
+{
+#ifndef MLSD_GEMM_EXPERIMENTS
+    /* measured SLOWER than splitk_reduce + the one-dispatch GroupNorm on every map size of the SD1.5 b1 plan (evaluation 6.84 -> 6.88 / 6.90 ms, profiles/NOTES.md): the
+     * reduce then runs on 64 blocks (one per image and group) instead of 640.  Only in EXPERIMENTS builds. */
+    (void)a;
+    return 0;
+#else
+    if (!a || !a->gn_y16 || a->ln_y16 || a->colstats) return 0;
+    const int v = pick_variant(a);
+    if ((v != 0 && v != 1) || a->ksplit < 2 || !a->ws || !a->C32 || a->C16 || !a->gn_gamma || !a->gn_beta || a->act == MLSD_ACT_GEGLU || g_gemm_sk_inline) return 0;
+    if (a->gn_groups <= 0 || a->gn_hw <= 0 || (a->N % a->gn_groups) || (a->M % a->gn_hw)) return 0;
+    const int cg = a->N / a->gn_groups;
+    if ((cg & 3) || (long)a->gn_hw * (cg >> 2) > 256L * GNR_MAXI || (a->gn_ldy & 3) || ((uintptr_t)a->gn_y16 & 7) || ((uintptr_t)a->gn_gamma & 15) || ((uintptr_t)a->gn_beta & 15)) return 0;
+    const bool vec = !(a->N & 3) && !(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15) && (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) &&
+                     (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+    if (!vec || splitk_slices(a, 64, nullptr) < 2) return 0;
+    return splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)) ? 0 : 1;
+#endif
+}
+
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
@@ -1384,7 +1510,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 #endif
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
-    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : "", ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
+    if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : (mlsd_gemm_gn_fused(a) ? "+groupnorm" : ""), ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
     else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

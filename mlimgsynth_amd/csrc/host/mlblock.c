@@ -83,7 +83,7 @@ static void ctx_reset_(MLCtx* C)
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
-	C->n_ln_fused = 0; C->n_ln_alias = 0;
+	C->n_ln_fused = 0; C->n_ln_alias = 0; C->n_gn_fused = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->epb, 0, sizeof(C->epb));
 	memset(&C->info, 0, sizeof(C->info));
@@ -642,7 +642,8 @@ static int run_op(MLCtx* C, MLOp* op)
 	switch (op->kind) {
 	case OP_GEMM: return mlsd_gemm(&op->u.gemm, st);
 	case OP_ATTN: return mlsd_attention(&op->u.attn, st);
-	case OP_GN:   return mlsd_groupnorm(&op->u.gn, st);
+	case OP_GN:   if (op->fused) return 0;                    /* its producer's reduce pass ends with it (wire_gn_fold) */
+	              return mlsd_groupnorm(&op->u.gn, st);
 	case OP_LN:   if (op->fused) return 0;                    /* its producer ends with it (wire_ln_fold) */
 	              return mlsd_layernorm(op->u.ln.x, op->u.ln.ldx, op->u.ln.rows, op->u.ln.d, op->u.ln.eps, op->u.ln.g, op->u.ln.b,
 	                                   op->u.ln.y16, op->u.ln.y32, st);
@@ -919,7 +920,7 @@ MLB_API int mlctx_tune_inplan(MLCtx* C, int reps)
 	for (int i=0;i<C->n_ops;++i) {
 		op_shape[i] = -1;
 		MLOp *op = &C->ops[i];
-		if (op->kind != OP_GEMM || op->u.gemm.colstats || op->u.gemm.ln_y16) continue;     /* (tiles bound by a consumer's wiring stay) */
+		if (op->kind != OP_GEMM || op->u.gemm.colstats || op->u.gemm.ln_y16 || op->u.gemm.gn_y16) continue;     /* (tiles bound by a consumer's wiring stay) */
 		mlsd_gemm_args *g = &op->u.gemm;
 		const TuneKey k = tune_key(g);
 		int j = 0;
@@ -997,6 +998,7 @@ static int op_outputs(const MLOp* o, const void* out[3])
 		if (o->u.gemm.C32) out[n++] = o->u.gemm.C32;
 		if (o->u.gemm.C16) out[n++] = o->u.gemm.C16;
 		if (o->u.gemm.ln_y16 && n < 3) out[n++] = o->u.gemm.ln_y16;
+		if (o->u.gemm.gn_y16 && n < 3) out[n++] = o->u.gemm.gn_y16;
 		break;
 	case OP_ATTN: out[n++] = o->u.attn.out; break;
 	case OP_GN: out[n++] = o->u.gn.y16; if (o->u.gn.raw16) out[n++] = o->u.gn.raw16; break;
@@ -1322,6 +1324,42 @@ static int compute_streamed(MLCtx* C)
 	return 1;
 }
 
+/* GroupNorm at the end of its producer's split-K reduce pass (round 4; same idea as the LayerNorm form above, no hand-off).  A GroupNorm with ONE source, no raw copy, of
+ * a size the one-dispatch GroupNorm takes, whose input is the fp32 output of the op recorded right before it, a split-K launch on the general tiles: the launch gets gamma,
+ * beta, eps, groups, rows per image, the SiLU flag and the fp16 output buffer, the GroupNorm op is skipped.  MLSD_NO_GN_FOLD=1 keeps the separate launch (A/B, parity test).
+ * MEASURED SLOWER (SD1.5 b1 evaluation 6.84 -> 6.88..6.90 ms): mlsd_gemm_gn_fused answers 0 outside EXPERIMENTS builds, so nothing is folded in the product. */
+static void wire_gn_fold(MLCtx* C)
+{
+	const char *e = getenv("MLSD_NO_GN_FOLD");
+	if (e && *e && *e != '0') return;
+	const char *eh = getenv("MLSD_GN_FOLD_MAX_HW");       /* A/B knob: largest map (rows per image) whose GroupNorm is folded */
+	const int max_hw = eh && *eh ? atoi(eh) : 1024;
+	for (int i=1;i<C->n_ops;++i) {
+		MLOp *l = &C->ops[i];
+		if (l->kind != OP_GN || l->fused) continue;
+		mlsd_gn_args *n = &l->u.gn;
+		if (n->C2 || n->raw16 || n->cs1 || !n->y16 || l->gn_src[0] != i - 1) continue;
+		MLOp *o = &C->ops[i-1];
+		mlsd_gemm_args *g = &o->u.gemm;
+		if (o->kind != OP_GEMM || o->once || g->C32 != n->x1 || g->ldc32 != n->ld1 || g->N != n->C1 || g->M != n->n_img * n->HW || g->ln_y16 || g->gn_y16 || g->colstats || g->ksplit < 2) continue;
+		if (!mlsd_groupnorm_single_pass(n->n_img, n->HW, n->C1, n->n_grp)) continue;
+		if (n->HW > max_hw) continue;
+		{	/* the fp16 output is written one op earlier, by the reduce pass (the GEMM's own operands are done by then): it must not land on what that pass reads */
+			const char *y0 = (const char*)n->y16, *y1 = y0 + (size_t)g->M * g->N * 2;
+			const struct { const void* p; size_t nb; } rd[4] = {
+				{ g->resid, g->resid ? (size_t)g->M * (size_t)g->ldr * 4 : 0 }, { g->bias, g->bias ? (size_t)g->N * 4 : 0 },
+				{ g->rowbias, g->rowbias ? (size_t)(g->M / (g->rows_per_batch > 0 ? g->rows_per_batch : 1)) * (size_t)g->ldrb * 4 : 0 }, { g->ws, g->ws_bytes } };
+			int clash = 0;
+			for (int q=0;q<4;++q) if (rd[q].p && rd[q].nb && (const char*)rd[q].p < y1 && y0 < (const char*)rd[q].p + rd[q].nb) clash = 1;
+			if (clash) continue;
+		}
+		g->gn_y16 = n->y16; g->gn_ldy = n->C1; g->gn_gamma = n->gamma; g->gn_beta = n->beta; g->gn_eps = n->eps; g->gn_groups = n->n_grp; g->gn_hw = n->HW; g->gn_silu = n->silu;
+		if (mlsd_gemm_gn_fused(g) == 1) { l->fused = 1; C->n_gn_fused++; }
+		else { g->gn_y16 = NULL; g->gn_gamma = g->gn_beta = NULL; g->gn_groups = g->gn_hw = g->gn_silu = 0; }
+	}
+}
+MLB_API int mlctx_gn_fused(const MLCtx* C) { return C ? C->n_gn_fused : 0; }   /* GroupNorms of the plan that run at the end of their producers' split-K reduce pass */
+
 MLB_API int mlctx_prep(MLCtx* C)
 {
 	if (C->err) return C->err;
@@ -1343,7 +1381,7 @@ MLB_API int mlctx_prep(MLCtx* C)
 		char path[96]; snprintf(path, sizeof(path), "dump-graph-%s.txt", C->name[0] ? C->name : "ctx");
 		if (mlctx_block_graph_dump_path(C, path) < 0) return -1;
 	}
-	if (!autotune_on()) { wire_gn_stats(C); wire_ln_fold(C); }   /* (need the tiles: the offline tuning mode runs the two-pass / separate forms) */
+	if (!autotune_on()) { wire_gn_stats(C); wire_ln_fold(C); wire_gn_fold(C); }   /* (need the tiles: the offline tuning mode runs the two-pass / separate forms) */
 	C->info.flops = fl; C->info.n_conv = nconv; C->info.n_ops = C->n_ops;
 	C->info.mem_params = C->mem_params; C->info.mem_compute = C->mem_compute; C->info.mem_total = C->mem_params + C->mem_compute;
 	if (C->err) return C->err;
@@ -1486,6 +1524,7 @@ MLB_API double mlctx_op_bytes(const MLCtx* C, int i)
 	}
 	case OP_GN: {
 		const mlsd_gn_args *a = &op->u.gn;
+		if (op->fused) return 0.0;
 		const double n = (double)a->n_img * a->HW * (a->C1 + a->C2);
 		return n * (4.0 + 2.0 + (a->raw16 ? 2.0 : 0.0));
 	}

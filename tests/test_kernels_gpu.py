@@ -909,6 +909,62 @@ def test_split_k_reduce_pass_that_ends_with_the_layernorm(K, M, N, Kd, ksplit, v
         kernels.gemm(a2)
 
 
+@needs_experiments
+@pytest.mark.parametrize("n_img,hw,C,Kd,ksplit,variant,mode", [(2, 64, 1280, 11520, 13, 2, "rowbias_silu"), (2, 256, 1280, 11520, 6, 2, "res"), (2, 256, 640, 5760, 6, 2, "plain_silu"),
+                                                             (2, 64, 1280, 1280, 10, 2, "res_silu"), (1, 64, 2560, 2560, 8, 2, "rowbias_silu"), (3, 16, 640, 1152, 4, 2, "res")])
+def test_split_k_reduce_pass_that_ends_with_the_groupnorm(K, n_img, hw, C, Kd, ksplit, variant, mode):
+    """Round 4: where a GroupNorm's single input comes from a split-K launch and its (image, group) slab is small, the reduce pass ends with it (splitk_reduce_gn: one block
+    per (image, group), slices added in slice order, epilogue, statistics by two block reductions, affine, SiLU, fp16).  Against the same launch followed by
+    mlsd_groupnorm: fp32 output bit-identical, fp16 output within one fp16 digit (the statistics are summed in another order), bit-repeatable."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_gn_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    L.mlsd_groupnorm_ws_bytes.restype = ctypes.c_size_t
+    M, N = n_img * hw, C
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, (rng.standard_normal(N) * 2).astype(np.float32))
+    dR = dev(_lib, (rng.standard_normal((M, N)) * 3 + 1.5).astype(np.float32))
+    dRB = dev(_lib, rng.standard_normal((n_img, N)).astype(np.float32))
+    dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    dY0, dY1 = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
+    nws = kernels.gemm_splitk_ws_bytes(M, N, ksplit)
+    ws = _lib.DeviceBuffer(nws)
+    gws = _lib.DeviceBuffer(L.mlsd_groupnorm_ws_bytes(n_img, hw, 32))
+    silu = int(mode.endswith("silu"))
+
+    def mk(dst, gn):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=variant, ksplit=ksplit, ws=ws.ptr, ws_bytes=nws)
+        if mode.startswith("res"): a.resid, a.ldr = dR.ptr, N
+        if mode.startswith("rowbias"): a.rowbias, a.rows_per_batch, a.ldrb = dRB.ptr, hw, N
+        if gn: a.gn_y16, a.gn_ldy, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_groups, a.gn_hw, a.gn_silu = dY1.ptr, N, dG.ptr, dBt.ptr, 1e-6, 32, hw, silu
+        return a
+    a0, a1 = mk(dC0, False), mk(dC1, True)
+    assert L.mlsd_gemm_gn_fused(ctypes.byref(a0)) == 0 and L.mlsd_gemm_gn_fused(ctypes.byref(a1)) == 1
+    assert "+groupnorm" in kernels.gemm_variant(a1)
+    kernels.gemm(a0)
+    kernels.groupnorm(kernels.GnArgs(x1=dC0.ptr, ld1=N, C1=N, C2=0, n_img=n_img, HW=hw, n_grp=32, eps=1e-6, gamma=dG.ptr, beta=dBt.ptr, silu=silu, y16=dY0.ptr, ws=gws.ptr))
+    c_ref, y_ref = dC0.download((M, N), np.uint32), dY0.download((M, N), np.float16).astype(np.float32)
+    first = None
+    for rep in range(3):
+        _lib.check(L.mlsd_memset(_lib.vp(dC1.ptr), 0xff, ctypes.c_size_t(M * N * 4), None))
+        _lib.check(L.mlsd_memset(_lib.vp(dY1.ptr), 0xff, ctypes.c_size_t(M * N * 2), None))
+        kernels.gemm(a1)
+        assert np.array_equal(dC1.download((M, N), np.uint32), c_ref), rep
+        raw = dY1.download((M, N), np.uint16)
+        y = raw.view(np.float16).astype(np.float32)
+        assert np.isfinite(y).all(), rep
+        assert np.abs(y - y_ref).max() <= 2.0 ** -9 * np.maximum(1.0, np.abs(y_ref)).max(), rep
+        assert rel(y, y_ref) < 2e-4, rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+    a2 = mk(dC1, True); a2.ksplit = 1          # cannot honour the request without a reduce pass: says so
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(a2)
+
+
 def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     """A REAL give-up: the LayerNorm-ending launch 1024x1280x1280 is 32 tiles whose row-block partners wait for each other; on a stream masked to 8 of
     the 256 CUs the partners of the resident tiles never become resident while those wait, the bounded polling runs out, and the launch must (a) terminate, (b) raise the

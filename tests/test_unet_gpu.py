@@ -378,3 +378,31 @@ def test_sd15_layernorms_in_the_split_k_reduce_pass_keep_the_result(monkeypatch)
     b = un.run(x, cond, None, sigma)
     assert np.isfinite(b).all() and rel(b, a) < 3e-3, rel(b, a)
     assert np.array_equal(un.run(x, cond, None, sigma).view(np.uint32), b.view(np.uint32))
+
+
+def test_sd15_groupnorms_in_the_split_k_reduce_pass_keep_the_result(monkeypatch):
+    """(EXPERIMENTS builds only: measured slower than the separate one-dispatch GroupNorm, profiles/NOTES.md.)  The same for the GroupNorms of SD1.5's 8x8 / 16x16 levels that follow a split-K convolution (resnet norm2, the norm after a block's last convolution): the reduce
+    pass of the convolution ends with them.  Against the plan with separate GroupNorm launches (MLSD_NO_GN_FOLD=1)."""
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    if not L.mlsd_has_experiments():
+        pytest.skip("variant not in the product build (make EXPERIMENTS=1)")
+    L.mlctx_gn_fused.argtypes = [_lib.vp]; L.mlctx_handoff_ops.argtypes = [_lib.vp]
+    rng = np.random.default_rng(14)
+    n, lat = 2, 64
+    monkeypatch.setenv("MLSD_NO_GN_FOLD", "1")
+    ref = engine.Unet("sd1", lat, lat, n)
+    assert L.mlctx_gn_fused(ref.ctx.h) == 0
+    monkeypatch.delenv("MLSD_NO_GN_FOLD")
+    un = engine.Unet("sd1", lat, lat, n)
+    nf = L.mlctx_gn_fused(un.ctx.h)
+    print("GroupNorms of the SD1.5 b1 plan that end a split-K reduce pass:", nf, "of 61")
+    assert nf >= 10
+    P = un.P
+    x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    sigma = np.array([9.0, 0.4], np.float32)
+    a = ref.run(x, cond, None, sigma)
+    b = un.run(x, cond, None, sigma)
+    assert np.isfinite(b).all() and rel(b, a) < 3e-3, rel(b, a)
+    assert np.array_equal(un.run(x, cond, None, sigma).view(np.uint32), b.view(np.uint32))
