@@ -20,6 +20,9 @@ def t(ctx, k):
 out = []
 u = engine.Unet("sd1", 64, 64, 2, stream=st.value, flags=8); out.append(("sd15_b1_unet_eval_ms", t(u.ctx, 30))); u.ctx.destroy()
 u = engine.Unet("sdxl", 128, 128, 8, stream=st.value); out.append(("sdxl_b4_unet_eval_ms", t(u.ctx, 8))); u.ctx.destroy()
+u = engine.Unet("sdxl", 128, 128, 2, stream=st.value); out.append(("sdxl_b1_unet_eval_ms", t(u.ctx, 10))); u.ctx.destroy()
+u = engine.Unet("sdxl", 128, 128, 4, stream=st.value); out.append(("sdxl_b2_unet_eval_ms", t(u.ctx, 10))); u.ctx.destroy()
+u = engine.Unet("sd1", 64, 64, 4, stream=st.value, flags=8); out.append(("sd15_b2_unet_eval_ms", t(u.ctx, 20))); u.ctx.destroy()
 d = engine.Decoder("sdxl", 128, 128, 4, stream=st.value); out.append(("sdxl_b4_vae_decode_ms", t(d.ctx, 4))); d.ctx.destroy()
 d = engine.Decoder("sd1", 64, 64, 1, stream=st.value); out.append(("sd15_b1_vae_decode_ms", t(d.ctx, 8))); d.ctx.destroy()
 print("RESULT " + " ".join(f"{k}={v:.3f}" for k, v in out))

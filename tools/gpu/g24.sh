@@ -1,0 +1,3 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4s; mkdir -p $O
+cd $R; export PYTHONPATH=$R
+for d in 0 256; do for s in "8192 320 5760" "8192 320 2880" "2048 640 5760" "512 1280 11520" "8192 640 5760"; do timeout 120 python3 tools/gemm_trace_sk.py $s 28 $d 2>&1 | grep -v amdgpu; done; done | tee $O/r4_gemm_trace_sk3.txt
