@@ -65,6 +65,7 @@ def kernel_roofline(g, workload, B):
     ms = uc.profile_ops()
     agg = {}
     for (lab, fl), t, nb in zip(ops, ms, nbytes):
+        if t == 0.0: continue                      # a norm that runs inside its producer: no launch of its own (mlctx_profile_ops)
         lab = re.sub(r",k/\d+p?>", ">", lab)       # split-K launches run the same kernel instantiation
         e = agg.setdefault(lab, [0, 0.0, 0.0, 0.0])
         e[0] += 1; e[1] += float(t); e[2] += fl; e[3] += nb
@@ -154,10 +155,10 @@ def run_extra(engine, text, Lh, _lib, workload, tae, steps, cfg, denoise_steps, 
            "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
            "roofline": roof, "unet_eval_mfma": eval_mfma(agg), "tile_table_misses": g.unet_ctx().tune_misses()}
     si = g.unet_ctx().streaming_info()
-    if si:      # BASELINE configs[4]: the reference's --unet-split (weights streamed from pinned host memory through two device slabs, every evaluation)
+    if si:      # BASELINE configs[4]: the reference's --unet-split (weights streamed from pinned host memory through three device slabs, every evaluation)
         nseg, per_eval, slab, host = si
         evals_per_s = (steps * denoise_steps) / (um / 1e3) if um > 0 else 0.0
-        res["weight_streaming"] = {"segments": nseg, "slab_mib": slab >> 20, "host_master_mib": host >> 20, "streamed_mib_per_eval": per_eval >> 20,
+        res["weight_streaming"] = {"segments": nseg, "h2d_copies_per_eval": g.unet_ctx().streaming_copies(), "slab_mib": slab >> 20, "host_master_mib": host >> 20, "streamed_mib_per_eval": per_eval >> 20,
                                    "h2d_gb_per_s_sustained": round(per_eval * evals_per_s / 1e9, 1),
                                    "unet_params_on_device_mib": int(g.unet_ctx().info().mem_params) >> 20}
     aux = {"plist": g.unet_ctx().param_list(), "unet_flops_b1": info["unet_flops"] / (2 * B if cfg > 1 else B), "flop_per_img": flop_per_img}

@@ -54,6 +54,7 @@ int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream
  * slabs of slab_bytes each (0 = 512 MiB), uploaded segment by segment under the previous segment's launches.  Call before the graph is built; excludes MLB_F_HIPGRAPH.
  * Results are bit-identical to the resident plan. */
 int    mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes);
+int    mlctx_weight_streaming_copies(const MLCtx* C);   /* host -> device copies per evaluation (the host master is laid out in segment order: one per segment where no weight is needed twice) */
 int    mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes);   /* 0: the plan does not stream */
 void   mlctx_set_cus(MLCtx* C, int n);   /* CUs the plan's stream may use (CU-masked stream); < 256: the plan is built without in-launch hand-offs.  Before mlctx_prep */
 int    mlctx_ln_alias_refused(const MLCtx* C);

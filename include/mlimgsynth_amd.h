@@ -257,7 +257,7 @@ typedef struct {
 	float f_t_ini, f_t_end;  /* relative initial / final time: 0,0 -> 1,0 (txt2img); f_t_ini < 1 = img2img */
 	int defer_weights;       /* 1: do not synthesise weights: the caller loads them (mlctx_param_set on the *_ctx handles) */
 	int unet_split;          /* > 0: the UNet's weights are STREAMED (the reference's --unet-split / MLIS_OPT_UNET_SPLIT, src/unet.c:390-458): master copy in pinned host
-	                          * memory, two device slabs of `unet_split` MiB each (1 = the default 512 MiB) filled under the launches; excludes use_hipgraph */
+	                          * memory, three device slabs of `unet_split` MiB each (1 = the default 512 MiB) filled under the launches; excludes use_hipgraph */
 } MLIS_AmdConfig;
 
 /* progress callback (MLIS_Callback, include/mlimgsynth.h:405): called after every COMPLETED step (the stream is

@@ -158,7 +158,7 @@ MLB_API MLIS_AmdCtx* mlis_amd_create(const MLIS_AmdConfig* cfg, void* stream)
 
 	/* ---- UNet plan, x bound to the resident evaluation point (c_in scaling + cond/uncond duplication in the gather) */
 	S->unet_ctx = mlctx_new(stream);
-	if (S->c.unet_split > 0) {     /* --unet-split: the UNet's weights are streamed through two slabs (mlblock.c "weight streaming"); one evaluation = one pass over them */
+	if (S->c.unet_split > 0) {     /* --unet-split: the UNet's weights are streamed through three slabs (mlblock.c "weight streaming"); one evaluation = one pass over them */
 		if (mlctx_set_weight_streaming(S->unet_ctx, S->c.unet_split > 1 ? (size_t)S->c.unet_split << 20 : 0) < 0) goto err;
 	} else if (S->c.use_hipgraph) mlctx_set_flags(S->unet_ctx, MLB_F_HIPGRAPH);
 	if (unet_denoise_init_n(&S->unet, S->unet_ctx, &S->unet_p, S->lw, S->lh, N) < 0) goto err;

@@ -251,7 +251,7 @@ void* mlctx_walloc(MLCtx* C, size_t nbytes)
 	if (!C->pstream || C->pstream_hold) return dalloc_ex(C, nbytes, 1, 0x7fffffff);
 	nbytes = ALIGN_UP(nbytes ? nbytes : 256, 256);
 	MLWAlloc *a = VEC_PUSH(C, C->pv_allocs, C->n_pv, C->cap_pv, MLWAlloc);
-	a->voff = C->pv_size; a->bytes = nbytes;
+	a->voff = C->pv_size; a->bytes = nbytes; a->moff = a->voff;
 	C->pv_size += nbytes;
 	return MLW_VBASE + a->voff;
 }
@@ -1144,7 +1144,7 @@ static int hoist_on(void);
 /* ------------------------------------------------------------------ weight streaming (BASELINE configs[4]; the reference's --unet-split, src/unet.c:390-458)
  * The reference halves the UNet graph and uploads each half's weights before computing it, every evaluation, so that only half the model is resident.  Here
  * (mlctx_set_weight_streaming before the graph is built): weight storage comes from a virtual address range (mlctx_walloc), the master copy sits in pinned host
- * memory in the engine's layout, and at prep the recorded plan is cut into SEGMENTS of consecutive ops whose weights fit one of TWO device slabs; every weight
+ * memory in the engine's layout, and at prep the recorded plan is cut into SEGMENTS of consecutive ops whose weights fit one of MLW_NSLAB = 3 device slabs; every weight
  * pointer of an op is replaced by its address inside the slab of its segment.  An evaluation then runs  upload(0), upload(1) | compute(0) | upload(2) into slab 0 ||
  * compute(1) | upload(3) into slab 1 || compute(2) ...: hipMemcpyAsync on a copy stream, ordered against the compute stream by events, so the next segment's weights
  * arrive under the current segment's launches.  Same launches, same operands: results are bit-identical to the resident plan.  Resident instead of streamed: the
@@ -1183,13 +1183,14 @@ static void wstream_free(MLCtx* C)
 	free(C->ev_up); free(C->ev_done); C->ev_up = C->ev_done = NULL;
 	if (C->copy_stream) { mlsd_stream_destroy(C->copy_stream); C->copy_stream = NULL; }
 	if (C->pmaster) { mlsd_host_free(C->pmaster); C->pmaster = NULL; }
-	for (int i=0;i<2;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
+	for (int i=0;i<MLW_NSLAB;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
+	C->pf_valid = 0;
 	if (C->pscratch) { mlsd_free(C->pscratch); C->pscratch = NULL; C->pscratch_bytes = 0; }
 	free(C->pv_allocs); C->pv_allocs = NULL; C->n_pv = C->cap_pv = 0; C->pv_size = 0;
 	C->stream_bytes_per_eval = 0; C->pstream_hold = 0;      /* (pstream / slab_bytes are settings of the context, like its flags: they survive mlctx_begin) */
 }
 
-/* slab_bytes: size of each of the two device slabs (0 = default 512 MiB); call before the graph is built */
+/* slab_bytes: size of each of the device slabs (0 = default 512 MiB); call before the graph is built */
 MLB_API int mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes)
 {
 	if (!C || C->n_ops || C->n_params) return mlctx_fail(C, "mlctx_set_weight_streaming: the graph is already being built");
@@ -1197,6 +1198,7 @@ MLB_API int mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes)
 	C->slab_bytes = slab_bytes ? ALIGN_UP(slab_bytes, 256) : ((size_t)512 << 20);
 	return 1;
 }
+MLB_API int mlctx_weight_streaming_copies(const MLCtx* C) { return C && C->pstream ? C->stream_copies_per_eval : 0; }   /* host -> device copies per evaluation (one per segment at best) */
 MLB_API int mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes)
 {
 	if (!C || !C->pstream) return 0;
@@ -1245,11 +1247,30 @@ static int wstream_setup(MLCtx* C)
 		seg_of[i] = C->n_segs - 1;
 	}
 	if (cur) cur->op1 = C->n_ops;
+	/* The host master is laid out in SEGMENT order (an allocation sits where the first segment that needs it expects it), so that a segment's upload is one
+	 * contiguous copy -- or a few, where a later segment needs weights again that an earlier one placed: per-tensor copies of 1..50 MB ran at 42.6 GB/s of the
+	 * link's 57.6 (tools/h2d_probe.py: 8 MiB chunks 49.5 GB/s, whole-GiB copies 57.6). */
+	if (R > 0) {
+		size_t run = 0;
+		for (int a=0;a<C->n_pv;++a) used[a] = 0;
+		for (int g=0; g<C->n_segs; ++g)
+			for (int z=0; z<C->segs[g].n; ++z) {
+				const int a = pv_find(C, C->segs[g].r[z].voff);
+				if (!used[a]) { used[a] = 1; C->pv_allocs[a].moff = run; run += C->pv_allocs[a].bytes; }
+				C->segs[g].r[z].moff = C->pv_allocs[a].moff;
+			}
+		for (int a=0;a<C->n_pv;++a) if (!used[a]) { C->pv_allocs[a].moff = run; run += C->pv_allocs[a].bytes; }      /* (weights no op reads) */
+		C->stream_copies_per_eval = 0;
+		for (int g=0; g<C->n_segs; ++g)
+			for (int z=0; z<C->segs[g].n; ++z)
+				if (!z || C->segs[g].r[z].moff != C->segs[g].r[z-1].moff + C->segs[g].r[z-1].bytes || C->segs[g].r[z].soff != C->segs[g].r[z-1].soff + C->segs[g].r[z-1].bytes)
+					C->stream_copies_per_eval++;
+	}
 	if (R > 0) {
 		if (mlsd_host_alloc((void**)&C->pmaster, C->pv_size)) R = mlctx_fail(C, "weight streaming: %zu bytes of pinned host memory not available", C->pv_size);
 		else memset(C->pmaster, 0, C->pv_size);
 	}
-	for (int k=0;k<2 && R>0;++k) {
+	for (int k=0;k<MLW_NSLAB && R>0;++k) {
 		if (mlsd_malloc((void**)&C->slab[k], C->slab_bytes)) R = mlctx_fail(C, "weight streaming: slab allocation failed");
 		else C->mem_params += C->slab_bytes;
 	}
@@ -1267,7 +1288,7 @@ static int wstream_setup(MLCtx* C)
 				int z = 0;
 				for (; z<sg->n; ++z) if (vo >= sg->r[z].voff && vo < sg->r[z].voff + sg->r[z].bytes) break;
 				if (z == sg->n) { R = mlctx_fail(C, "weight streaming: internal (op %d references weights outside its segment)", i); break; }
-				*sl[q] = C->slab[g & 1] + sg->r[z].soff + (vo - sg->r[z].voff);
+				*sl[q] = C->slab[g % MLW_NSLAB] + sg->r[z].soff + (vo - sg->r[z].voff);
 			}
 		}
 	}
@@ -1281,7 +1302,10 @@ static int wstream_setup(MLCtx* C)
 /* host address of a streamed parameter's master copy (NULL: the parameter is resident) */
 static char* param_master(const MLCtx* C, const MLParam* p)
 {
-	return is_virtual(C, p->dev) ? C->pmaster + ((const char*)p->dev - MLW_VBASE) : NULL;
+	if (!is_virtual(C, p->dev)) return NULL;
+	const size_t vo = (size_t)((const char*)p->dev - MLW_VBASE);
+	const MLWAlloc *a = &C->pv_allocs[pv_find(C, vo)];
+	return C->pmaster + a->moff + (vo - a->voff);
 }
 
 static int compute_streamed(MLCtx* C)
@@ -1292,20 +1316,39 @@ static int compute_streamed(MLCtx* C)
 		for (int g=0; g<ns; ++g) if (mlsd_event_create(&C->ev_up[g]) || mlsd_event_create(&C->ev_done[g])) return -1;
 	}
 	const int hoist = C->n_once > 0 && hoist_on();
-#define UPLOAD(g) do { const MLWSeg *sg_ = &C->segs[g]; \
-		for (int z=0; z<sg_->n; ) { int z1 = z + 1; size_t nb = sg_->r[z].bytes;      /* coalesce ranges contiguous on both sides */ \
-			while (z1 < sg_->n && sg_->r[z1].voff == sg_->r[z1-1].voff + sg_->r[z1-1].bytes && sg_->r[z1].soff == sg_->r[z1-1].soff + sg_->r[z1-1].bytes) { nb += sg_->r[z1].bytes; ++z1; } \
-			if (mlsd_memcpy(C->slab[(g) & 1] + sg_->r[z].soff, C->pmaster + sg_->r[z].voff, nb, 0, C->copy_stream)) return -1; \
-			z = z1; } \
-		if (mlsd_event_record(C->ev_up[g], C->copy_stream)) return -1; } while (0)
-	/* the slabs may still be read by the previous evaluation's last two segments */
-	for (int k=0;k<2 && k<ns;++k) {
-		const int last = ns - 1 - ((ns - 1 - k) & 1);          /* last segment that used slab k */
-		if (C->info.n_compute > 0 && last >= 0 && mlsd_stream_wait_event(C->copy_stream, C->ev_done[last])) return -1;
+	/* diagnostics (MLSD_WSTREAM_TRACE=1, one plan per process): per segment, when its upload and its ops started and ended on the device, relative to the start of the
+	 * evaluation's first op.  Two sets of events, by evaluation parity: the uploads of the NEXT evaluation's first segments are issued (and stamped) in this call. */
+	static int trace = -1;
+	static void *T0[2][64], *T1[2][64], *TC[2][64];
+	if (trace < 0) {
+		const char *e = getenv("MLSD_WSTREAM_TRACE"); trace = e && *e && *e != '0';
+		if (trace) for (int q=0;q<2;++q) for (int g=0;g<64;++g) if (mlsd_event_create(&T0[q][g]) || mlsd_event_create(&T1[q][g]) || mlsd_event_create(&TC[q][g])) return -1;
 	}
-	for (int g=0; g<2 && g<ns; ++g) UPLOAD(g);
+	const int tr = trace && ns <= 64, par = C->info.n_compute & 1;
+#define UPLOAD(g, set) do { const MLWSeg *sg_ = &C->segs[g]; \
+		if (tr && mlsd_event_record(T0[set][g], C->copy_stream)) return -1; \
+		for (int z=0; z<sg_->n; ) { int z1 = z + 1; size_t nb = sg_->r[z].bytes;      /* coalesce ranges contiguous on both sides */ \
+			while (z1 < sg_->n && sg_->r[z1].moff == sg_->r[z1-1].moff + sg_->r[z1-1].bytes && sg_->r[z1].soff == sg_->r[z1-1].soff + sg_->r[z1-1].bytes) { nb += sg_->r[z1].bytes; ++z1; } \
+			if (mlsd_memcpy(C->slab[(g) % MLW_NSLAB] + sg_->r[z].soff, C->pmaster + sg_->r[z].moff, nb, 0, C->copy_stream)) return -1; \
+			z = z1; } \
+		if (tr && mlsd_event_record(T1[set][g], C->copy_stream)) return -1; \
+		if (mlsd_event_record(C->ev_up[g], C->copy_stream)) return -1; } while (0)
+	/* Segment g lives in slab g % MLW_NSLAB and is uploaded as soon as the previous user of that slab (segment g - MLW_NSLAB, or the last segment of that slab in the
+	 * previous evaluation) has finished.  The weights do not change between evaluations, so the first MLW_NSLAB segments of the NEXT evaluation are uploaded at the end
+	 * of this one, behind this evaluation's last users of their slabs: the copy stream never idles across the evaluation boundary (MLSD_WSTREAM_TRACE timeline of the
+	 * two-slab form, profiles/r4_wstream_trace.txt: 9 back-to-back uploads of 9.2 ms, then the last segment's 16 ms of ops and the next evaluation's first upload with
+	 * nothing beside them: 98 + 7 ms per evaluation for 81 ms of copies).  mlctx_param_set / mlctx_params_synth drop the prefetch (pf_valid). */
+#define LAST_USER(k) (ns - 1 - ((ns - 1 - (k)) % MLW_NSLAB))      /* last segment of this plan that lives in slab k (k < ns, k < MLW_NSLAB) */
+	const int lead = ns < MLW_NSLAB ? ns : MLW_NSLAB;
+	if (!C->pf_valid)
+		for (int g=0; g<lead; ++g) {
+			if (C->info.n_compute > 0 && mlsd_stream_wait_event(C->copy_stream, C->ev_done[LAST_USER(g)])) return -1;
+			UPLOAD(g, par);
+		}
+	C->pf_valid = 0;
 	for (int g=0; g<ns; ++g) {
 		if (mlsd_stream_wait_event(C->stream, C->ev_up[g])) return -1;
+		if (tr && mlsd_event_record(TC[par][g], C->stream)) return -1;
 		for (int i=C->segs[g].op0; i<C->segs[g].op1; ++i) {
 			if (hoist && C->static_valid && C->ops[i].once) continue;
 			if (run_op(C, &C->ops[i])) {
@@ -1315,12 +1358,28 @@ static int compute_streamed(MLCtx* C)
 			}
 		}
 		if (mlsd_event_record(C->ev_done[g], C->stream)) return -1;
-		if (g + 2 < ns) {
+		if (g + MLW_NSLAB < ns) {
 			if (mlsd_stream_wait_event(C->copy_stream, C->ev_done[g])) return -1;
-			UPLOAD(g + 2);
+			UPLOAD(g + MLW_NSLAB, par);
 		}
 	}
+	for (int g=0; g<lead; ++g) {                        /* the next evaluation's first segments */
+		if (mlsd_stream_wait_event(C->copy_stream, C->ev_done[LAST_USER(g)])) return -1;
+		UPLOAD(g, par ^ 1);
+	}
+	C->pf_valid = 1;
+#undef LAST_USER
 #undef UPLOAD
+	if (tr) {
+		mlsd_stream_sync(C->stream);
+		fprintf(stderr, "[wstream] evaluation %d, segment: upload start..end | ops start..end (ms from the start of the evaluation's first op; %zu MiB per evaluation)\n", C->info.n_compute, C->stream_bytes_per_eval >> 20);
+		for (int g=0; g<ns; ++g) {
+			float a = 0, b = 0, c = 0, d = 0;
+			mlsd_event_elapsed_ms(TC[par][0], T0[par][g], &a); mlsd_event_elapsed_ms(TC[par][0], T1[par][g], &b);
+			mlsd_event_elapsed_ms(TC[par][0], TC[par][g], &c); mlsd_event_elapsed_ms(TC[par][0], C->ev_done[g], &d);
+			fprintf(stderr, "[wstream] %2d (%4zu MiB, ops %d..%d): %7.2f .. %7.2f | %7.2f .. %7.2f\n", g, C->segs[g].bytes >> 20, C->segs[g].op0, C->segs[g].op1, a, b, c, d);
+		}
+	}
 	return 1;
 }
 
@@ -1547,9 +1606,13 @@ MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
 		if (C->pstream && seg < C->n_segs && C->segs[seg].op0 == i) {     /* streamed weights: this segment's weights into its slab first (blocking: not part of the op's time) */
 			const MLWSeg *sg = &C->segs[seg];
 			for (int z=0; z<sg->n; ++z)
-				if (mlsd_memcpy(C->slab[seg & 1] + sg->r[z].soff, C->pmaster + sg->r[z].voff, sg->r[z].bytes, 0, C->stream)) return -1;
+				if (mlsd_memcpy(C->slab[seg % MLW_NSLAB] + sg->r[z].soff, C->pmaster + sg->r[z].moff, sg->r[z].bytes, 0, C->stream)) return -1;
 			if (mlsd_stream_sync(C->stream)) return -1;
 			++seg;
+		}
+		if ((C->ops[i].kind == OP_LN || C->ops[i].kind == OP_GN) && C->ops[i].fused) {     /* runs inside its producer: no launch (an empty event pair would read ~4.8 us) */
+			if (i < n_out) ms_out[i] = 0;
+			continue;
 		}
 		mlsd_event_record(e0, C->stream);
 		if (run_op(C, &C->ops[i])) return -1;
@@ -1659,6 +1722,7 @@ MLB_API int mlctx_param_set(MLCtx* C, const char* key, int src_type, const void*
 	char *pm = param_master(C, p);
 	if (pm) {       /* streamed weight: the master copy is host memory; an evaluation in flight may be uploading from it */
 		if (C->copy_stream) { mlsd_stream_sync(C->stream); mlsd_stream_sync(C->copy_stream); }
+		C->pf_valid = 0;          /* the next evaluation's first segments were uploaded ahead with the old bytes: upload them again */
 		memcpy(pm, buf, p->dev_elems * esz);
 	} else {
 		rc = mlsd_memcpy(p->dev, buf, p->dev_elems * esz, 0, C->stream);
@@ -1703,6 +1767,7 @@ MLB_API int mlctx_params_synth(MLCtx* C, uint64_t seed)
 		char *pm = param_master(C, p);
 		const size_t pbytes = p->dev_elems * (p->type == MLT_F16 ? 2 : 4);
 		if (pm) {       /* streamed weight: fill a device scratch, copy it into the host master (same stream: in order) */
+			if (C->pf_valid) { if (C->copy_stream) mlsd_stream_sync(C->copy_stream); C->pf_valid = 0; }      /* (segments uploaded ahead hold the old bytes) */
 			if (C->pscratch_bytes < pbytes) {
 				if (mlsd_stream_sync(C->stream)) return -1;
 				if (C->pscratch) mlsd_free(C->pscratch);

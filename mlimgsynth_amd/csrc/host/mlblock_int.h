@@ -74,6 +74,7 @@ typedef struct { int kind; char* name; int param; int64_t ne[4]; } MLNameRec;  /
 
 typedef struct { void* ptr; size_t size; int rel_op; } MLFreeBlk;   /* rel_op: ops recorded at release time */
 
+#define MLW_NSLAB 3      /* device slabs of a weight-streaming plan: segment g lives in slab g % MLW_NSLAB */
 struct MLCtx {
 	void* stream;
 	char name[64];
@@ -109,22 +110,23 @@ struct MLCtx {
 	int n_gn_fused;            /* GroupNorms ended in their producers' split-K reduce pass (wire_gn_fold) */
 	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
 	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy
-	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of two device slabs, and segment i+2 is uploaded (copy stream) while i+1 computes */
+	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of MLW_NSLAB device slabs, and segment i+MLW_NSLAB is uploaded (copy stream) as soon as segment i is done */
 	int pstream, pstream_hold;              /* on (mlctx_set_weight_streaming before the graph is built); hold > 0: allocations stay resident (weights of step-invariant ops) */
 	size_t pv_size;                         /* bytes of virtual weight space handed out */
 	struct MLWAlloc* pv_allocs; int n_pv, cap_pv;
 	char* pmaster;                          /* pinned host master copy [pv_size] (engine layout) */
-	size_t slab_bytes; char* slab[2];
+	size_t slab_bytes; char* slab[MLW_NSLAB];
+	int pf_valid;                           /* the first segments of the NEXT evaluation are already uploaded / in flight (compute_streamed) */
 	struct MLWSeg* segs; int n_segs;
 	void* copy_stream; void **ev_up, **ev_done;   /* per segment */
 	void* pscratch; size_t pscratch_bytes;  /* device scratch for the synthetic fill */
-	size_t stream_bytes_per_eval;
+	size_t stream_bytes_per_eval; int stream_copies_per_eval;
 	MLCtxInfo info;
 };
 
 #define MLW_VBASE ((char*)0x600000000000ULL)      /* virtual weight addresses: never dereferenced, replaced by slab addresses at prep */
-typedef struct MLWAlloc { size_t voff, bytes; } MLWAlloc;
-typedef struct MLWSeg { int op0, op1; int n; struct { size_t voff, bytes, soff; } *r; size_t bytes; } MLWSeg;
+typedef struct MLWAlloc { size_t voff, bytes, moff; } MLWAlloc;     /* moff: offset in the host master (segment order, wstream_setup) */
+typedef struct MLWSeg { int op0, op1; int n; struct { size_t voff, bytes, soff, moff; } *r; size_t bytes; } MLWSeg;
 void* mlctx_walloc(MLCtx* C, size_t nbytes);      /* weight storage: device memory, or a virtual address when the plan streams its weights */
 
 /* internal helpers shared by mlblock_nn.c and the model builders */

@@ -441,7 +441,7 @@ static int option_apply(MLIS_Ctx* S, int id, ArgSrc* A)
 		} else S->seed = va_arg(*A->ap, uint64_t);
 		break;
 	case MLIS_OPT_VAE_TILE: if (!arg_int(A, 0, 65535, 0, &i)) BAD_VALUE; S->vae_tile = i; break;
-	case MLIS_OPT_UNET_SPLIT: if (!arg_bool(A, &i)) BAD_VALUE; if (i) S->flags |= CF_UNET_SPLIT; else S->flags &= ~CF_UNET_SPLIT; break;   /* weight streaming through two device slabs (engine_get) */
+	case MLIS_OPT_UNET_SPLIT: if (!arg_bool(A, &i)) BAD_VALUE; if (i) S->flags |= CF_UNET_SPLIT; else S->flags &= ~CF_UNET_SPLIT; break;   /* weight streaming through three device slabs (engine_get) */
 	case MLIS_OPT_WEIGHT_TYPE:
 		if (A->is_str) {
 			next_str_arg(A);

@@ -148,6 +148,12 @@ class MLCtx:
             return None
         return n.value, a.value, b.value, c.value
 
+    def streaming_copies(self):
+        """host -> device copies one evaluation of a weight-streaming plan issues (the host master is laid out in segment order: one per segment at best)"""
+        f = L().mlctx_weight_streaming_copies
+        f.argtypes = [vp]
+        return int(f(self.h))
+
     def tune_misses(self):
         """GEMM shapes of this plan that the compiled-in tile table does not list (they run on the static rule)."""
         f = L().mlctx_plan_tune_misses
@@ -184,7 +190,7 @@ class Unet:
     def __init__(self, model, lw, lh, n_batch, stream=None, flags=0, seed=1234, synth=True, stream_weights_mib=0):
         self.P = unet_params(model)
         self.ctx = MLCtx(stream, flags)
-        if stream_weights_mib:          # the reference's --unet-split: weights in pinned host memory, two device slabs of this size
+        if stream_weights_mib:          # the reference's --unet-split: weights in pinned host memory, three device slabs of this size
             f = L().mlctx_set_weight_streaming
             f.argtypes = [vp, ctypes.c_size_t]
             check1(f(self.ctx.h, int(stream_weights_mib) << 20), "mlctx_set_weight_streaming")

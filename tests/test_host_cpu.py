@@ -285,7 +285,7 @@ def test_block_graph_dump_reproduces_the_parameter_names(dry, tmp_path):
 
 def test_weight_streaming_plan_in_the_dry_runtime(dry):
     """BASELINE configs[4] / the reference's --unet-split (src/unet.c:390-458): with mlctx_set_weight_streaming the plan's weights are cut into segments of consecutive
-    ops that fit one of two slabs.  Host logic only (no GPU): every weight of the plan is streamed exactly once per evaluation except the step-invariant cross-attention
+    ops that fit one of three slabs.  Host logic only (no GPU): every weight of the plan is streamed exactly once per evaluation except the step-invariant cross-attention
     K/V projections (resident), the segment count follows the slab size, a slab smaller than the largest single launch's weights is refused, and streaming + hipGraph
     replay is refused."""
     un = dry.Unet("tinyxl", 8, 8, 2, synth=False)
@@ -301,6 +301,7 @@ def test_weight_streaming_plan_in_the_dry_runtime(dry):
         kv = sum(int(np.prod(ne)) * 2 for k, typ, ne in s.ctx.param_list() if ".attn2.k_proj." in k or ".attn2.v_proj." in k or "attn2.k_proj" in k or "attn2.v_proj" in k)
         assert 0.9 * (total - kv) <= host <= 1.1 * (total - kv) + 256 * len(s.ctx.param_list())      # (256-byte alignment per allocation)
         assert per_eval <= nseg * slab
+        assert nseg <= s.ctx.streaming_copies() <= nseg + 2        # the host master is laid out in segment order: a segment's upload is one contiguous copy
         s.ctx.destroy()
     assert infos[1] > infos[4]
     with pytest.raises(Exception):

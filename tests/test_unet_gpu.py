@@ -313,7 +313,7 @@ def test_generation_survives_a_timed_out_handoff():
 @pytest.mark.parametrize("model,lat,n,mib", [("tinyxl", 8, 2, 1), ("sdxl", 32, 2, 256)])
 def test_weight_streaming_is_bit_identical_to_the_resident_plan(model, lat, n, mib):
     """BASELINE configs[4], the reference's --unet-split (src/unet.c:390-458: two half-graphs, weights uploaded per half, every evaluation).  Here the UNet's weights
-    live in pinned host memory and pass through TWO device slabs segment by segment, uploaded on a copy stream under the previous segment's launches.  Same launches on
+    live in pinned host memory and pass through THREE device slabs segment by segment, uploaded on a copy stream under the previous segments' launches (the next evaluation's first segments under this one's last).  Same launches on
     the same operands: several evaluations in a row (slab reuse across evaluations, changing inputs) are bit-identical to the resident plan's."""
     from mlimgsynth_amd import engine
     rng = np.random.default_rng(21)
