@@ -1181,7 +1181,7 @@ static void wstream_free(MLCtx* C)
 	}
 	free(C->segs); C->segs = NULL; C->n_segs = 0;
 	free(C->ev_up); free(C->ev_done); C->ev_up = C->ev_done = NULL;
-	if (C->copy_stream) { mlsd_stream_destroy(C->copy_stream); C->copy_stream = NULL; }
+	if (C->copy_stream) { mlsd_stream_sync(C->copy_stream); mlsd_stream_destroy(C->copy_stream); C->copy_stream = NULL; }   /* (the next evaluation's first segments may be in flight: they read the master and write the slabs freed below) */
 	if (C->pmaster) { mlsd_host_free(C->pmaster); C->pmaster = NULL; }
 	for (int i=0;i<MLW_NSLAB;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
 	C->pf_valid = 0;
