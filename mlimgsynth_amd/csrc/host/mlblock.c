@@ -1601,6 +1601,8 @@ MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
 	if (!C->prepared) return mlctx_fail(C, "mlctx_profile_ops before mlctx_prep");
 	void *e0 = NULL, *e1 = NULL;
 	if (mlsd_event_create(&e0) || mlsd_event_create(&e1)) return -1;
+	if (C->pstream && C->copy_stream) { if (mlsd_stream_sync(C->copy_stream)) return -1; }      /* (segments uploaded ahead for the next evaluation: this pass refills the slabs itself) */
+	C->pf_valid = 0;
 	int seg = 0;
 	for (int i=0;i<C->n_ops;++i) {
 		if (C->pstream && seg < C->n_segs && C->segs[seg].op0 == i) {     /* streamed weights: this segment's weights into its slab first (blocking: not part of the op's time) */
