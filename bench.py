@@ -102,6 +102,26 @@ def kernel_roofline(g, workload, B):
     return roof, agg, ms
 
 
+def sustained_mfma_probe(_lib, iters=20000, launches=8):
+    """What this GPU's matrix pipes sustain with NOTHING else running (mlsd_probe_mfma_rate: 256 blocks x 8 waves of independent v_mfma_f32_16x16x32_f16 on random
+    register operands, no memory traffic): the part lowers its clock under matrix load, so this -- not the 2.5 PFLOP/s quoted at 2.4 GHz -- is the ceiling a GEMM loop on
+    this box can approach.  ~25 ms of GPU time, outside every timed region.  Reported beside `roofline.peak`, never instead of it."""
+    import numpy as np
+    L = _lib.lib(); vp = _lib.vp
+    src = _lib.from_numpy(np.random.default_rng(0).standard_normal(64 * 2048 * 8).astype(np.float16))
+    clk, sink = _lib.DeviceBuffer(256 * 8), _lib.DeviceBuffer(16)
+    ev = [vp(), vp()]
+    for e in ev: L.mlsd_event_create(ctypes.byref(e))
+    for _ in range(2): _lib.check(L.mlsd_probe_mfma_rate(vp(src.ptr), iters, 256, vp(clk.ptr), vp(sink.ptr), None), "probe")
+    L.mlsd_device_sync()
+    L.mlsd_event_record(ev[0], None)
+    for _ in range(launches): _lib.check(L.mlsd_probe_mfma_rate(vp(src.ptr), iters, 256, vp(clk.ptr), vp(sink.ptr), None), "probe")
+    L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
+    ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
+    for e in ev: L.mlsd_event_destroy(e)
+    return 256 * 8 * iters * 8 * 16384.0 * launches / (ms.value * 1e-3) / 1e12
+
+
 def eval_mfma(agg):
     """TIME-WEIGHTED matrix-pipe fraction of one whole UNet evaluation (sum of algorithmic FLOP of every launch / sum of launch
     durations / dense fp16 peak) and the same per kernel family, so that no bucket hides behind the best label."""
@@ -304,6 +324,13 @@ def main():
     }
 
     roof, agg, ms = kernel_roofline(g, a.workload, B)
+    if rank == 0 and roof.get("bound") == "mfma":
+        try:       # the power-limited ceiling of THIS box, measured: pure-MFMA loop on random operands (see sustained_mfma_probe)
+            sus = sustained_mfma_probe(_lib)
+            roof["sustained_mfma_tflops_measured"] = round(sus, 1)
+            roof["frac_of_sustained_measured"] = round(roof["achieved"] / sus, 4)
+        except Exception as e:
+            roof["sustained_mfma_tflops_measured"] = None; roof["sustained_probe_error"] = str(e)
     out["roofline"] = roof
     out["unet_eval_mfma"] = eval_mfma(agg)
     out["tile_table_misses"] = g.unet_ctx().tune_misses()     # GEMM shapes of this plan not in the compiled-in tile table (0 on the bench plans)

@@ -8,6 +8,7 @@
 // They are exercised by tests/test_hw_probe.py (-m gpu).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 // raw dump: every lane stores what it holds, python decodes.
@@ -132,7 +133,42 @@ __global__ __launch_bounds__(512) void probe_fill_kernel(const unsigned char* __
     if (MODE != 1 && smem[tid * 16] == 0x5a && smem[65536 + tid] == 0xa5) sink[1] = 1;
 }
 
+// Matrix-pipe RATE probe (round 4): what the part sustains when the matrix pipes are the only thing busy.  Every wave holds two A and two B fragments taken from `src`
+// (the caller decides the data: random values or zeros -- the power a v_mfma draws depends on the bits it multiplies) and issues `iters` rounds of 8 independent
+// v_mfma_f32_16x16x32_f16 on 8 accumulators: no memory traffic, no LDS, no barriers inside the loop.  clocks[block] = shader clocks of the loop; the caller times the launch.
+__global__ __launch_bounds__(512) void probe_mfma_rate(const _Float16* __restrict__ src, int iters, unsigned long long* __restrict__ clocks, float* __restrict__ sink)
+{
+    const int tid = threadIdx.x;
+    const f16x8* s8 = reinterpret_cast<const f16x8*>(src) + (size_t)(blockIdx.x & 63) * 2048 + tid * 4;
+    const f16x8 a0 = s8[0], a1 = s8[1], b0 = s8[2], b1 = s8[3];
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16((j & 1) ? a1 : a0, (j & 2) ? b1 : b0, acc[j], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) clocks[blockIdx.x] = t1 - t0;
+    f32x4 t = acc[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += acc[j];
+    if (t[0] + t[1] + t[2] + t[3] == 1.2345678e33f) sink[0] = t[0];       // (keeps the loop alive)
+}
+
 extern "C" {
+
+/* nblocks x 512 threads (8 waves: two per SIMD), `iters` x 8 MFMAs of 16x16x32 per wave; src: >= 64 x 2048 x 16 bytes of fp16 operands; clocks[nblocks].
+ * FLOP of a launch = nblocks * 8 * iters * 8 * 16384 */
+MLSD_API int mlsd_probe_mfma_rate(const void* src, int iters, int nblocks, void* clocks, void* sink, void* stream)
+{
+    if (!src || iters < 1 || nblocks < 1) return mlsd_set_error(-1, "mlsd_probe_mfma_rate: bad arguments");
+    static const bool one = [] { const char* e = getenv("MLSD_PROBE_ONE_WAVE"); return e && *e && *e != '0'; }();      /* diagnostics: ONE wave per SIMD (256 threads) */
+    hipLaunchKernelGGL(probe_mfma_rate, dim3(nblocks), dim3(one ? 256 : 512), 0, (hipStream_t)stream, (const _Float16*)src, iters, (unsigned long long*)clocks, (float*)sink);
+    return mlsd_check_launch("probe_mfma_rate");
+}
 
 MLSD_API int mlsd_probe_mfma_raw(const void* A, const void* B, void* Craw, void* stream)
 {
