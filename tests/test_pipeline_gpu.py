@@ -292,6 +292,8 @@ def test_bench_json_contract_on_tiny_workload():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] in (8000.0, 2500.0)
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "kernel" in r
+    if r["bound"] == "mfma":       # the matrix rate this box sustains with no memory traffic (mlsd_probe_mfma_rate), reported beside the contract's peak
+        assert 1000.0 < r["sustained_mfma_tflops_measured"] < 2600.0 and abs(r["frac_of_sustained_measured"] - r["achieved"] / r["sustained_mfma_tflops_measured"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] and c["value"] > 0 and c["unit"] == "images/s" and "oracle" in c["sample"]
     assert d["value"] > 50 * c["value"]                                          # a GPU against a CPU port, even on the tiny model
