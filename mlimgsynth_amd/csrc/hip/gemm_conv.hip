@@ -113,8 +113,12 @@ __device__ __forceinline__ void wait_vmcnt()
 // two-launch form.  (The round-3 variant let the LAST block reduce the whole tile alone at one CU's load bandwidth and lost to the second launch; profiles/NOTES.md.)
 // A departure counter clears both words for the next launch; a give-up raises the sticky word sk_flag[4095] (mlctx_handoff_check -> retry on the two-launch plan).
 // `pe` = the epilogue as requested (p carries the raw-partial form).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE, int DBG = 0, bool REG = false, bool PAR = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP p, const GemmP pe)
+// ST: the build whose wide epilogue also emits column statistics (GemmP::colstats).  A build of its own: the 8 + 8 running sums push the 512- / 1024-thread tiles over
+// 128 registers (120 -> 130: three waves per SIMD instead of four, the VAE's 256x128 convolutions +5 % -- measured with the sums in the common build); here the ST builds
+// of those tiles are held to four waves per SIMD and spill a few registers in the epilogue instead.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool CONV, int NSTAGE, int DBG = 0, bool REG = false, bool PAR = false, bool ST = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu((ST && WAVES_M * WAVES_N >= 8) ? 4 : 1, (ST && WAVES_M * WAVES_N >= 8) ? 4 : 10)))
+void gemm_kernel(const GemmP p, const GemmP pe)
 {
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         // instead of 64 scalar ones.
         float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
         // bias, row bias, residual, activation and both stores for 4 consecutive columns of row m
-        auto finish4 = [&](int m, int n, float4 v, const float4 bv, const float4 rs_pre, const bool have_pre) {
+        auto finish4 = [&](int m, int n, float4 v, const float4 bv, const float4 rs_pre, const bool have_pre) -> float4 {
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (p.biasm) { const float b = p.biasm[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
             if (p.rowbias) {
@@ -471,7 +475,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
             }
+            return v;
         };
+        // column statistics for a consuming GroupNorm (GemmP::colstats, round 4 on these tiles): per 64-column slab, the lane's 4 columns summed over the wave's WM rows
+        // (8 rows per 32-row block in the lane, then the 4 row groups of the wave by shuffles): one partial per (block of WM rows, column), fixed order
+        float4 st_s[ST ? (TN + 1) / 2 : 1], st_q[ST ? (TN + 1) / 2 : 1];
+        if constexpr (ST) {
+#pragma unroll
+            for (int q = 0; q < (TN + 1) / 2; ++q) { st_s[q] = make_float4(0, 0, 0, 0); st_q[q] = make_float4(0, 0, 0, 0); }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -498,7 +510,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         float4 rp = make_float4(0, 0, 0, 0);
                         if constexpr (PRE) rp = rpre[SLAB0 + it];
                         if (m >= p.M || n >= p.N) continue;
-                        finish4(m, n, v, bv, rp, PRE && pre);
+                        const float4 o = finish4(m, n, v, bv, rp, PRE && pre);
+                        if constexpr (ST) {
+                            st_s[jc / 2].x += o.x; st_s[jc / 2].y += o.y; st_s[jc / 2].z += o.z; st_s[jc / 2].w += o.w;
+                            st_q[jc / 2].x += o.x * o.x; st_q[jc / 2].y += o.y * o.y; st_q[jc / 2].z += o.z * o.z; st_q[jc / 2].w += o.w * o.w;
+                        }
                     }
                 } else if (!geglu) {
                     const int c4 = (lane & 7) * 4;
@@ -546,6 +562,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (ST) {     // (launcher: fp32 output, even TN, no GEGLU, single K slice: mlsd_gemm_colstats_rows)
+            const int rbk = (m0 + wm * WM) / WM;
+            if (m0 + wm * WM < p.M) {
+#pragma unroll
+                for (int q = 0; q < TN / 2; ++q) {
+                    float4 a = st_s[q], b = st_q[q];
+#pragma unroll
+                    for (int o = 16; o <= 32; o <<= 1) {
+                        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+                        b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+                    }
+                    const int n = n0 + wn * WN + q * 64 + (lane & 15) * 4;
+                    if (lane < 16 && n < p.N) {
+                        float* st = p.colstats + (long)rbk * 2 * p.N + n;
+                        *reinterpret_cast<float4*>(st) = a;
+                        *reinterpret_cast<float4*>(st + p.N) = b;
+                    }
+                }
             }
         }
         if constexpr (PAR) {
@@ -703,6 +739,80 @@ __global__ __launch_bounds__(256) void splitk_reduce(const GemmP p, const float*
     if (p.C16) {
         f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
+    }
+}
+
+// ---- split-K second pass that ALSO emits the column statistics of the rows it finishes (GemmP::colstats: [block of 32 rows][2][N] sums / sums of squares, for a
+// consuming GroupNorm: its first pass over the fp32 map disappears).  A block = 32 rows x 256 columns: thread (row lane rl = t / 64, column group t % 64) finishes
+// rows rl, rl + 4, ... with the operations of splitk_reduce in its order (bit-identical output, the slices' loads of the 8 rows in flight together), sums its 4
+// columns over its 8 rows, and the 4 row lanes are combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void splitk_reduce_stats(const GemmP p, const float* __restrict__ ws, int nsplit)
+{
+    __shared__ float4 sh_s[4][64], sh_q[4][64];
+    const int t = threadIdx.x, cgi = t & 63, rl = t >> 6;
+    const int n = (blockIdx.x * 64 + cgi) * 4, mb = blockIdx.y * 32;
+    const bool colok = n < p.N;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int m = mb + rl + 4 * k;
+        v[k] = (colok && m < p.M) ? *reinterpret_cast<const float4*>(ws + (long)m * p.N + n) : make_float4(0, 0, 0, 0);
+    }
+    for (int z = 1; z < nsplit; ++z) {
+        float4 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = mb + rl + 4 * k;
+            u[k] = (colok && m < p.M) ? *reinterpret_cast<const float4*>(ws + z * p.ws_stride + (long)m * p.N + n) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k].x += u[k].x; v[k].y += u[k].y; v[k].z += u[k].z; v[k].w += u[k].w; }
+    }
+    float4 cs = make_float4(0, 0, 0, 0), cq = cs;
+    float4 bv = make_float4(0, 0, 0, 0);
+    if (p.bias && colok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int m = mb + rl + 4 * k;
+        if (!colok || m >= p.M) continue;
+        float4 x = v[k];
+        if (p.bias) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
+        if (p.biasm) { const float b = p.biasm[m]; x.x += b; x.y += b; x.z += b; x.w += b; }
+        if (p.rowbias) {
+            const float4 r = *reinterpret_cast<const float4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n);
+            x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+        }
+        float4 rs = make_float4(0, 0, 0, 0);
+        if (p.resid) rs = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+        if (p.act_post) { x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w; }
+        switch (p.act) {
+        case MLSD_ACT_SILU: x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); break;
+        case MLSD_ACT_GELU: x.x = gelu_tanh_f(x.x); x.y = gelu_tanh_f(x.y); x.z = gelu_tanh_f(x.z); x.w = gelu_tanh_f(x.w); break;
+        case MLSD_ACT_GELU_QUICK: x.x = gelu_quick_f(x.x); x.y = gelu_quick_f(x.y); x.z = gelu_quick_f(x.z); x.w = gelu_quick_f(x.w); break;
+        case MLSD_ACT_RELU: x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); break;
+        default: break;
+        }
+        if (!p.act_post) { x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w; }
+        if (p.C32) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc32 + n) = x;
+        if (p.C16) {
+            f16x4 h = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+            *reinterpret_cast<f16x4*>(p.C16 + (long)m * p.ldc16 + n) = h;
+        }
+        cs.x += x.x; cs.y += x.y; cs.z += x.z; cs.w += x.w;
+        cq.x += x.x * x.x; cq.y += x.y * x.y; cq.z += x.z * x.z; cq.w += x.w * x.w;
+    }
+    sh_s[rl][cgi] = cs; sh_q[rl][cgi] = cq;
+    __syncthreads();
+    if (rl == 0 && colok) {
+        float4 a = sh_s[0][cgi], b = sh_q[0][cgi];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            const float4 a2 = sh_s[r][cgi], b2 = sh_q[r][cgi];
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        float* st = p.colstats + (long)blockIdx.y * 2 * p.N + n;
+        *reinterpret_cast<float4*>(st) = a;
+        *reinterpret_cast<float4*>(st + p.N) = b;
     }
 }
 
@@ -904,6 +1014,25 @@ bool splitk_par_ok(const mlsd_gemm_args* a, int BM, int nsplit, long tiles)
     return tiles * nsplit <= (long)cus * (BM == 64 ? 3 : 2);
 }
 
+// Rows per column-statistics block a launch of the GENERAL tiles would write for `a` (0: none).  Non-split: the wide epilogue of gemm_kernel sums per wave (WM rows);
+// split-K: splitk_reduce_stats (32 rows).  Needs the wide epilogue (alignment), an fp32 output, whole 64-column slabs per wave (even TN) and no fused norm.
+int general_stats_rows(const mlsd_gemm_args* a, int WM, int TN, int BK)
+{
+    if (!a->colstats || ((uintptr_t)a->colstats & 15) || !a->C32 || a->act == MLSD_ACT_GEGLU || a->ln_y16 || a->gn_y16 || (TN & 1) || (a->N & 3)) return 0;
+    const bool vec = !(a->ldc32 & 3) && !((uintptr_t)a->C32 & 15) && (!a->C16 || (!(a->ldc16 & 3) && !((uintptr_t)a->C16 & 7))) &&
+                     (!a->resid || (!(a->ldr & 3) && !((uintptr_t)a->resid & 15))) && (!a->bias || !((uintptr_t)a->bias & 15)) &&
+                     (!a->rowbias || (!(a->ldrb & 3) && !((uintptr_t)a->rowbias & 15))) && g_gemm_epi != 1;
+    if (!vec || g_gemm_sk_inline) return 0;
+    const int nsplit = splitk_slices(a, BK, nullptr);
+    if (nsplit > 1) {
+#ifdef MLSD_GEMM_EXPERIMENTS
+        if (sk_par_on()) return 0;          // (the slices may be added inside the launch: no reduce pass)
+#endif
+        return 32;
+    }
+    return WM;
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, bool REG = false>
 int launch(const mlsd_gemm_args* a, hipStream_t st)
 {
@@ -928,7 +1057,12 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     const int nsplit = p.vec ? splitk_slices(a, BK, &kt_per) : 1;
     p.kt_per = nsplit > 1 ? kt_per : (a->K + BK - 1) / BK;
     p.ws_stride = 0;
+    // column statistics for a consuming GroupNorm (general_stats_rows: the same conditions mlsd_gemm_colstats_rows promised the planner): one K slice -> this kernel's
+    // epilogue (blocks of WM rows); split-K -> the reduce pass (blocks of 32 rows)
+    const int st_rows = a->colstats ? general_stats_rows(a, BM / WAVES_M, (BN / WAVES_N) / 32, BK) : 0;
+    if (st_rows > 0 && nsplit == 1) p.colstats = a->colstats;
     GemmP pe = p;                                  // the epilogue as requested (second pass of a split-K launch)
+    if (st_rows > 0 && nsplit > 1) pe.colstats = a->colstats;
     // reduced inside the launch: one counter per output tile (a->sk_flags, 4096 words, zero between launches), one slab per (tile, slice)
     const bool inl = nsplit > 1 && g_gemm_sk_inline && a->sk_flags && (long)p.nbm * p.nbn <= 4095 &&        /* (word 4095 is the sticky give-up indicator of the stream-K hand-offs) */
                      !((uintptr_t)a->ws & 15) &&
@@ -976,7 +1110,9 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
                 GemmP pl = pe;
                 pl.ln_g = a->ln_gamma; pl.ln_b = a->ln_beta; pl.ln_eps = a->ln_eps; pl.ln_y = (_Float16*)a->ln_y16; pl.ldln = a->ldln;
                 hipLaunchKernelGGL(splitk_reduce_ln, dim3((unsigned)a->M), dim3((unsigned)(((a->N >> 2) + 63) / 64 * 64)), 0, st, pl, (const float*)a->ws, nsplit);
-            } else
+            } else if (pe.colstats)
+                hipLaunchKernelGGL(splitk_reduce_stats, dim3((unsigned)(((a->N >> 2) + 63) / 64), (unsigned)((a->M + 31) / 32)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
+            else
             hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pe, (const float*)a->ws, nsplit);
         }
         return mlsd_check_launch("gemm_kernel");
@@ -985,6 +1121,10 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     if (!a->conv && g_gemm_dbg == 1) return go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 1, REG>);
     if (!a->conv && g_gemm_dbg == 2) return go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 2, REG>);
 #endif
+    if constexpr (((BN / WAVES_N) / 32) % 2 == 0 && !REG) {       // the statistics builds (whole 64-column wave slabs)
+        if (p.colstats) return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, false, false, true>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, false, false, true>);
+    }
+    p.colstats = nullptr;
     return a->conv ? go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true, NSTAGE, 0, REG>) : go(gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false, NSTAGE, 0, REG>);
 }
 
@@ -1442,7 +1582,16 @@ MLSD_API int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a)
 #ifdef MLSD_GEMM_EXPERIMENTS
     else if (v == 25 && pp_eligible(a, 256, 128)) { bm = 256; bn = 128; }
 #endif
-    else return 0;
+    else {      // the general tiles that mlsd_gemm launches directly (round 4): {variant -> wave rows, BK}; every one of them has 64-column wave slabs
+        switch (v) {
+        case 0: return general_stats_rows(a, 64, 2, 64);       // 128x128x64, 2x2 waves
+        case 1: return general_stats_rows(a, 32, 2, 64);       // 64x128x64, 2x2
+        case 3: return general_stats_rows(a, 64, 2, 64);       // 256x128x64, 4x2
+        case 4: return general_stats_rows(a, 64, 2, 32);       // 256x128x32s3, 4x2
+        case 9: return general_stats_rows(a, 64, 2, 64);       // 256x256x64, 4x4
+        default: return 0;
+        }
+    }
     const int e = pp_epilogue_kind(a, bn);
     return (e == PP_EPI_F32_STATS || e == PP_EPI_F32_RES_STATS) ? bm / 2 : 0;
 }

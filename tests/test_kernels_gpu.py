@@ -1457,6 +1457,71 @@ def test_gemm_column_statistics_for_groupnorm(K, pp, conv, res):
     assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
 
 
+@pytest.mark.parametrize("v,conv,res,ksplit,act", [(0, False, True, 0, 0), (1, True, False, 0, 0), (3, False, False, 0, 1), (4, True, True, 0, 0), (9, False, True, 0, 0),
+                                                   (0, True, True, 4, 0), (1, False, True, 3, 1), (1, True, False, 6, 0), (0, False, False, 2, 0)])
+def test_gemm_column_statistics_from_the_general_tiles(K, v, conv, res, ksplit, act):
+    """Round 4: the general tiles emit the statistics too -- one K slice: in the wide epilogue, per wave (blocks of 32 / 64 rows); split-K: in the reduce pass
+    (splitk_reduce_stats, blocks of 32 rows), where the launch may also carry an activation.  Output bit-identical to the launch without statistics, statistics equal to the
+    sums of the stored output, bit-repeatable; ragged shapes (M, N not multiples of the tile) included."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    L.mlsd_gemm_colstats_rows.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(100 + v + 2 * conv + res + ksplit)
+    if conv:
+        n, h, w, cin, cout, k = 3, 24, 16, 64, 328, 3              # M = 1152, N = 328 (not a multiple of 64: the last slab is half empty)
+        M, N, Kd = n * h * w, cout, k * k * cin
+        A = rng.standard_normal((n, h, w, cin)).astype(np.float16)
+        W = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(Kd)).astype(np.float32)
+        dW = dev(_lib, repack_conv_w(W, cin).astype(np.float16))
+    else:
+        M, N, Kd = 1472, 712, 1152                                 # 1472 = 23 x 64: ragged against the 128 / 256-row tiles
+        A = rng.standard_normal((M, Kd)).astype(np.float16)
+        dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+    bias = rng.standard_normal(N).astype(np.float32) * 3
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dB, dR = dev(_lib, A), dev(_lib, bias), dev(_lib, R)
+    dC, dC0 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    ws = _lib.DeviceBuffer(max(ksplit, 1) * M * N * 4)
+
+    def args(dst, stats):
+        a = kernels.GemmArgs(A=dA.ptr, lda=cin if conv else Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=v + 1,
+                             ksplit=ksplit, ws=ws.ptr, ws_bytes=ws.nbytes)
+        if conv:
+            a.conv, a.n_img, a.H, a.W, a.Cin, a.OH, a.OW, a.KH, a.KW, a.stride, a.pad = 1, n, h, w, cin, h, w, k, k, 1, 1
+        if res:
+            a.resid, a.ldr = dR.ptr, N
+        if act:
+            a.act = kernels.ACT_SILU
+        if stats is not None:
+            a.colstats = stats.ptr
+        return a
+    a0 = args(dC0, None)
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a0)) == 0
+    kernels.gemm(a0)
+    plain = dC0.download((M, N), np.float32)
+    rows = 32 if ksplit > 1 else (32 if v == 1 else 64)
+    nb = (M + rows - 1) // rows
+    dS = _lib.DeviceBuffer(nb * 2 * N * 4)
+    a1 = args(dC, dS)
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a1)) == rows
+    assert ("k/" in kernels.gemm_variant(a1)) == (ksplit > 1)
+    outs = []
+    for rep in range(2):
+        _lib.check(L.mlsd_memset(vp(dS.ptr), 0xFF, ctypes.c_size_t(dS.nbytes), None))
+        kernels.gemm(a1)
+        outs.append(dS.download((nb, 2, N), np.float32))
+    got = dC.download((M, N), np.float32)
+    assert np.array_equal(got, plain)                                            # the output itself is untouched
+    assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all()       # fixed reduction order; every entry written
+    pad = np.zeros((nb * rows, N), np.float64); pad[:M] = got
+    blk = pad.reshape(nb, rows, N)
+    s, q = blk.sum(1), (blk * blk).sum(1)
+    assert np.abs(outs[0][:, 0] - s).max() < 2e-3 and np.abs(outs[0][:, 1] - q).max() / q.max() < 1e-5
+    # a fused LayerNorm, GEGLU or no fp32 output: no statistics
+    a2 = args(dC, dS); a2.C32 = None; a2.C16, a2.ldc16 = dC.ptr, N
+    assert L.mlsd_gemm_colstats_rows(ctypes.byref(a2)) == 0
+
+
 @needs_experiments
 @pytest.mark.parametrize("w4,kind,M,N,Kd", [
     (26, "f16", 4096, 5120, 320), (26, "geglu", 4096, 5120, 320), (26, "f32", 384, 640, 192), (26, "f32res", 4352, 4992, 192), (26, "f32res", 8192, 1280, 1280),

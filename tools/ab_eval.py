@@ -1,5 +1,5 @@
 """Same-box A/B of two library builds (alternating child processes, MLSD_LIB_PATH): UNet evaluation / decode times of the bench plans.
-usage: python3 tools/ab_eval.py <libA.so> <libB.so> [rounds]      (labels: A, B)"""
+usage: python3 tools/ab_eval.py <libA.so> <libB.so> [rounds]      (labels: A, B; AB_ENV_A / AB_ENV_B = comma-separated NAME=VALUE settings for each side)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -33,6 +33,8 @@ res = {"A": [], "B": []}
 for r in range(rounds):
     for lab in ("A", "B"):
         env = dict(os.environ, MLSD_LIB_PATH=os.path.abspath(libs[lab]))
+        for kv in os.environ.get("AB_ENV_" + lab, "").split(","):          # e.g. AB_ENV_A=MLSD_GN_TWO_PASS=1: the same library under two settings
+            if "=" in kv: env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
         p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
         if not line:
