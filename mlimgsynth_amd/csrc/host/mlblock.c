@@ -1155,7 +1155,8 @@ static const void** op_weight_slots(MLOp* o, int* n)
 	int k = 0;
 	switch (o->kind) {
 	case OP_GEMM: slots[k++] = &o->u.gemm.W_; slots[k++] = (const void**)&o->u.gemm.bias; slots[k++] = (const void**)&o->u.gemm.bias_m;
-	              slots[k++] = (const void**)&o->u.gemm.ln_gamma; slots[k++] = (const void**)&o->u.gemm.ln_beta; break;
+	              slots[k++] = (const void**)&o->u.gemm.ln_gamma; slots[k++] = (const void**)&o->u.gemm.ln_beta;
+	              slots[k++] = (const void**)&o->u.gemm.gn_gamma; slots[k++] = (const void**)&o->u.gemm.gn_beta; break;     /* (a GroupNorm folded into the reduce pass: EXPERIMENTS builds) */
 	case OP_GN:   slots[k++] = (const void**)&o->u.gn.gamma; slots[k++] = (const void**)&o->u.gn.beta; break;
 	case OP_LN:   slots[k++] = (const void**)&o->u.ln.g; slots[k++] = (const void**)&o->u.ln.b; break;
 	case OP_CLIP_EMBED: slots[k++] = &o->u.cemb.tw; slots[k++] = (const void**)&o->u.cemb.pw; break;
