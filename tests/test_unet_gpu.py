@@ -310,7 +310,7 @@ def test_generation_survives_a_timed_out_handoff():
     assert np.array_equal(again, got) and L.mlis_amd_handoff_retries(g.h) == 1
 
 
-@pytest.mark.parametrize("model,lat,n,mib", [("tinyxl", 8, 2, 1), ("sdxl", 32, 2, 256)])
+@pytest.mark.parametrize("model,lat,n,mib", [("tinyxl", 8, 2, 1), ("sdxl", 32, 2, 256), ("tinyxl", 8, 2, 8), ("tinyxl", 8, 2, 64)])     # 17, 20, 2 and 1 segment(s) through the 3 slabs
 def test_weight_streaming_is_bit_identical_to_the_resident_plan(model, lat, n, mib):
     """BASELINE configs[4], the reference's --unet-split (src/unet.c:390-458: two half-graphs, weights uploaded per half, every evaluation).  Here the UNet's weights
     live in pinned host memory and pass through THREE device slabs segment by segment, uploaded on a copy stream under the previous segments' launches (the next evaluation's first segments under this one's last).  Same launches on
@@ -322,7 +322,7 @@ def test_weight_streaming_is_bit_identical_to_the_resident_plan(model, lat, n, m
     nseg, per_eval, slab, host = st.ctx.streaming_info()
     print(f"{model}: {nseg} segments, {per_eval / 2**20:.1f} MiB streamed per evaluation through 3 x {slab / 2**20:.0f} MiB slabs; resident params of the streaming plan "
           f"{st.ctx.info().mem_params / 2**20:.1f} MiB vs {res.ctx.info().mem_params / 2**20:.1f} MiB")
-    assert nseg >= 3 and st.ctx.info().mem_params < res.ctx.info().mem_params
+    assert nseg >= (3 if mib < 8 or model == "sdxl" else 1) and (mib >= 8 or st.ctx.info().mem_params < res.ctx.info().mem_params)
     P = res.P
     for rep in range(3):
         x = rng.standard_normal((n, 4, lat, lat)).astype(np.float32) * 3
