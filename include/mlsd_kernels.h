@@ -245,6 +245,7 @@ int mlsd_groupnorm(const mlsd_gn_args* a, void* stream);
 /* 1 if these dimensions run as ONE dispatch (small maps: the (image, group) slab is held in registers; SD1.5 batch 1 is bound by its dispatch count) */
 int mlsd_groupnorm_single_pass(int n_img, int HW, int C, int n_grp);
 void mlsd_groupnorm_set_single(int on);     /* diagnostics / A-B timing: 0 = always the two-kernel form */
+void mlsd_groupnorm_set_finalize2(int on);  /* diagnostics / A-B timing: 0 = the one-level finalize of the producers' statistics also on large maps */
 
 /* LayerNorm over the last dim: ggml_norm + mul + add at src/mlblock_nn.c:65-71.  x fp32 [rows][ldx] ->
  * y fp16 [rows][d] (and/or y32 fp32 [rows][d]) */

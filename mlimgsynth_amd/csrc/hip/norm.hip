@@ -275,6 +275,49 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnP p, float* __restric
     }
 }
 
+// Two-level form of gn_finalize for LARGE maps (round 4; the VAE's 512^2 / 1024^2 levels: 4 096 .. 16 384 row blocks per image).  gn_finalize gives one block per
+// (image, group), and a group's cg columns are 16..64 bytes out of every 2 C floats of the statistics: 128 blocks reading 16-byte pieces at a 1 KB stride took 200-340 us
+// for 67 MB.  Level 1: a block takes a contiguous range of row blocks for ALL columns (thread = column: consecutive lanes read consecutive floats), sums in double, then
+// the group's columns through LDS (fixed order) -> part[image][chunk][group][2].  Level 2: one block per image adds the chunks in order and writes mean / rstd.
+constexpr int GNF_MAXC = 2048;
+__global__ __launch_bounds__(256) void gn_finalize_l1(const GnP p, double* __restrict__ part, int nch)
+{
+    __shared__ double cs_[GNF_MAXC], cq_[GNF_MAXC];
+    const int chunk = blockIdx.x, img = blockIdx.y;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        const int src = c >= p.C1;
+        const float* cs = src ? p.cs2 : p.cs1;
+        const int Ci = src ? p.C2 : p.C1, rb = src ? p.rb2 : p.rb1, cc = c - (src ? p.C1 : 0);
+        const int nrb = p.HW / rb;
+        const int k0 = (int)((long)chunk * nrb / nch), k1 = (int)((long)(chunk + 1) * nrb / nch);
+        const float* e = cs + ((long)img * nrb + k0) * 2 * Ci + cc;
+        double s = 0, q = 0;
+        for (int k = k0; k < k1; ++k, e += 2 * Ci) { s += (double)e[0]; q += (double)e[Ci]; }
+        cs_[c] = s; cq_[c] = q;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < p.G; g += 256) {
+        double s = 0, q = 0;
+        for (int j = 0; j < p.cg; ++j) { s += cs_[g * p.cg + j]; q += cq_[g * p.cg + j]; }
+        double* o = part + (((long)img * nch + chunk) * p.G + g) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+__global__ __launch_bounds__(256) void gn_finalize_l2(const GnP p, const double* __restrict__ part, int nch, float* __restrict__ mr)
+{
+    const int img = blockIdx.x;
+    for (int g = threadIdx.x; g < p.G; g += 256) {
+        double s = 0, q = 0;
+        for (int c = 0; c < nch; ++c) { const double* e = part + (((long)img * nch + c) * p.G + g) * 2; s += e[0]; q += e[1]; }
+        const double cnt = (double)p.cg * p.HW;
+        const double mu = s / cnt;
+        double var = q / cnt - mu * mu;
+        if (var < 0) var = 0;
+        mr[((long)img * p.G + g) * 2] = (float)mu;
+        mr[((long)img * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+}
+
 // ONE-DISPATCH GroupNorm for small maps (round 4): SD1.5 batch 1 is bound by its dispatch count (~4.5 us per dependent dispatch, 498 per evaluation), and on
 // the 8x8 .. 32x32 levels an (image, group) slab is 10..80 KB.  One block per (image, group) holds its slab in registers (each element read ONCE), takes the mean
 // and the centred sum of squares with two block reductions (fixed order: deterministic, and better conditioned than single-pass sums), normalises and stores.
@@ -557,6 +600,9 @@ MLSD_API size_t mlsd_groupnorm_ws_bytes(int n_img, int HW, int n_grp)
     return (size_t)n_img * gn_chunks(HW, n_img) * n_grp * 2 * sizeof(float);
 }
 
+static int g_gn_finalize2 = 1;      /* two-level finalize on large maps (mlsd_groupnorm_set_finalize2: A/B timing, parity test) */
+MLSD_API void mlsd_groupnorm_set_finalize2(int on) { g_gn_finalize2 = on ? 1 : 0; }
+
 MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
 {
     const int C = a->C1 + a->C2;
@@ -583,6 +629,17 @@ MLSD_API int mlsd_groupnorm(const mlsd_gn_args* a, void* stream)
         return mlsd_check_launch("gn_small_kernel");
     }
     if (from_producers) {
+        // large maps: two-level finalize (coalesced); the chunk partials sit behind the mean / rstd table in the workspace (mlsd_groupnorm_ws_bytes: >= 64 chunks' worth)
+        const int nrb_min = a->C2 ? (a->HW / a->rb_rows1 < a->HW / a->rb_rows2 ? a->HW / a->rb_rows1 : a->HW / a->rb_rows2) : a->HW / a->rb_rows1;
+        const size_t mr_bytes = ((size_t)a->n_img * p.G * 2 * sizeof(float) + 15) & ~(size_t)15;
+        const size_t wsb = mlsd_groupnorm_ws_bytes(a->n_img, a->HW, a->n_grp);
+        int nch = wsb > mr_bytes ? (int)((wsb - mr_bytes) / ((size_t)a->n_img * p.G * 2 * sizeof(double))) : 0;
+        if (nch > 64) nch = 64;
+        if (g_gn_finalize2 && nrb_min >= 1024 && C <= GNF_MAXC && nch >= 16) {
+            double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(p.ws) + mr_bytes);
+            hipLaunchKernelGGL(gn_finalize_l1, dim3(nch, a->n_img), dim3(256), 0, (hipStream_t)stream, p, part, nch);
+            hipLaunchKernelGGL(gn_finalize_l2, dim3(a->n_img), dim3(256), 0, (hipStream_t)stream, p, (const double*)part, nch, p.ws);
+        } else
         hipLaunchKernelGGL(gn_finalize, dim3(p.G, a->n_img), dim3(256), 0, (hipStream_t)stream, p, p.ws);
         rc = mlsd_check_launch("gn_finalize");
         p.mr = p.ws;

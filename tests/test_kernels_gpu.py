@@ -539,6 +539,61 @@ def test_conv2d_stream_k_128x320(K, n, h, w, cin, cout, res):
     assert not fl.download((4096,), np.uint32).any()
 
 
+@pytest.mark.parametrize("two_sources", [False, True])
+def test_groupnorm_from_producer_statistics_on_a_large_map(K, two_sources):
+    """The VAE's regime: thousands of row blocks per image.  The statistics come from the general tiles (blocks of 32 rows, round 4) and are combined by the two-level
+    finalize (gn_finalize_l1 / _l2); against the one-level finalize on the same statistics (same sums, another order: fp16 outputs equal to an ulp), the two-pass form and numpy."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    L.mlsd_gemm_colstats_rows.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(15 + two_sources)
+    n_img, HW, Kd = 2, 65536, 64
+    Cs = [64, 128] if two_sources else [128]
+    M = n_img * HW
+    maps, stats, keep = [], [], []
+    for i, Cn in enumerate(Cs):
+        A = rng.standard_normal((M, Kd)).astype(np.float16)
+        W = (rng.standard_normal((Cn, Kd)) / np.sqrt(Kd)).astype(np.float16)
+        bias = (rng.standard_normal(Cn) * 4).astype(np.float32)
+        dA, dW, dB = dev(_lib, A), dev(_lib, W), dev(_lib, bias)
+        dC, dS = _lib.DeviceBuffer(M * Cn * 4), _lib.DeviceBuffer(M // 32 * 2 * Cn * 4)
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=Cn, K=Kd, bias=dB.ptr, C32=dC.ptr, ldc32=Cn, tile_variant=2, colstats=dS.ptr)
+        assert L.mlsd_gemm_colstats_rows(ctypes.byref(a)) == 32
+        kernels.gemm(a)
+        maps.append(dC); stats.append(dS); keep += [dA, dW, dB]
+    C = sum(Cs)
+    gamma, beta = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    dG, dBt = dev(_lib, gamma), dev(_lib, beta)
+    ws = _lib.DeviceBuffer(kernels.groupnorm_ws_bytes(n_img, HW, 32))
+    outs = {}
+    for mode in ("two_pass", "one_level", "two_level"):
+        dY = _lib.DeviceBuffer(M * C * 2)
+        g = kernels.GnArgs(x1=maps[0].ptr, ld1=Cs[0], C1=Cs[0], n_img=n_img, HW=HW, n_grp=32, eps=1e-6, gamma=dG.ptr, beta=dBt.ptr, silu=1, y16=dY.ptr, ws=ws.ptr)
+        if two_sources:
+            g.x2, g.ld2, g.C2 = maps[1].ptr, Cs[1], Cs[1]
+        if mode != "two_pass":
+            g.cs1, g.rb_rows1 = stats[0].ptr, 32
+            if two_sources:
+                g.cs2, g.rb_rows2 = stats[1].ptr, 32
+        L.mlsd_groupnorm_set_finalize2(1 if mode == "two_level" else 0)
+        try:
+            kernels.groupnorm(g)
+            first = dY.download((n_img, HW, C), np.float16)
+            kernels.groupnorm(g)
+            assert np.array_equal(first, dY.download((n_img, HW, C), np.float16))          # fixed order
+        finally:
+            L.mlsd_groupnorm_set_finalize2(1)
+        outs[mode] = first.astype(np.float32)
+    x = np.concatenate([m.download((n_img, HW, c), np.float32) for m, c in zip(maps, Cs)], axis=2).astype(np.float64)
+    xg = x.reshape(n_img, HW, 32, C // 32)
+    mu, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+    y = ((xg - mu) / np.sqrt(var + 1e-6)).reshape(n_img, HW, C) * gamma + beta
+    want = y / (1 + np.exp(-y))
+    assert np.abs(outs["two_level"] - outs["one_level"]).max() <= 4e-3 and np.abs(outs["two_level"] - outs["two_pass"]).max() <= 4e-3
+    for o in outs.values():
+        assert rel(o, want) < 1e-3
+
+
 @pytest.mark.parametrize("mode,pp", [(m, pp) for pp in PP_ALL for m in ("bias_res_silu_both", "geglu_f16", "rowbias_gelu", "relu_post", "quick_biasm")
                                      if not (pp in (18, 20, 22, 25, 27) and m == "geglu_f16")])     # GEGLU pairs 32-column blocks: 256-wide tile only
 def test_gemm_pingpong_epilogues(K, mode, pp):
