@@ -1144,7 +1144,7 @@ static int hoist_on(void);
 /* ------------------------------------------------------------------ weight streaming (BASELINE configs[4]; the reference's --unet-split, src/unet.c:390-458)
  * The reference halves the UNet graph and uploads each half's weights before computing it, every evaluation, so that only half the model is resident.  Here
  * (mlctx_set_weight_streaming before the graph is built): weight storage comes from a virtual address range (mlctx_walloc), the master copy sits in pinned host
- * memory in the engine's layout, and at prep the recorded plan is cut into SEGMENTS of consecutive ops whose weights fit one of MLW_NSLAB = 3 device slabs; every weight
+ * memory in the engine's layout, and at prep the recorded plan is cut into SEGMENTS of consecutive ops whose weights fit one of 3..5 device slabs (n_slab); every weight
  * pointer of an op is replaced by its address inside the slab of its segment.  An evaluation then runs  upload(0), upload(1) | compute(0) | upload(2) into slab 0 ||
  * compute(1) | upload(3) into slab 1 || compute(2) ...: hipMemcpyAsync on a copy stream, ordered against the compute stream by events, so the next segment's weights
  * arrive under the current segment's launches.  Same launches, same operands: results are bit-identical to the resident plan.  Resident instead of streamed: the
@@ -1184,7 +1184,8 @@ static void wstream_free(MLCtx* C)
 	free(C->ev_up); free(C->ev_done); C->ev_up = C->ev_done = NULL;
 	if (C->copy_stream) { mlsd_stream_sync(C->copy_stream); mlsd_stream_destroy(C->copy_stream); C->copy_stream = NULL; }   /* (the next evaluation's first segments may be in flight: they read the master and write the slabs freed below) */
 	if (C->pmaster) { mlsd_host_free(C->pmaster); C->pmaster = NULL; }
-	for (int i=0;i<MLW_NSLAB;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
+	for (int i=0;i<MLW_NSLAB_MAX;++i) if (C->slab[i]) { mlsd_free(C->slab[i]); C->slab[i] = NULL; }
+	C->n_slab = 0;
 	C->pf_valid = 0;
 	if (C->pscratch) { mlsd_free(C->pscratch); C->pscratch = NULL; C->pscratch_bytes = 0; }
 	free(C->pv_allocs); C->pv_allocs = NULL; C->n_pv = C->cap_pv = 0; C->pv_size = 0;
@@ -1271,7 +1272,12 @@ static int wstream_setup(MLCtx* C)
 		if (mlsd_host_alloc((void**)&C->pmaster, C->pv_size)) R = mlctx_fail(C, "weight streaming: %zu bytes of pinned host memory not available", C->pv_size);
 		else memset(C->pmaster, 0, C->pv_size);
 	}
-	for (int k=0;k<MLW_NSLAB && R>0;++k) {
+	/* How many slabs: the uploads of the NEXT evaluation's first two segments should run under this evaluation's last segment, i.e. the slabs of segments 0 and 1 must not
+	 * be the last segment's: (n_segs - 1) % n_slab >= 2.  Smallest count in 3..5 that satisfies it (SDXL, 512 MiB slabs: 9 segments -> 3; with 4 slabs segment 0 would
+	 * share its slab with segment 8 and the evaluation period went from 86 to 98 ms). */
+	C->n_slab = 3;
+	for (int n=3; n<=MLW_NSLAB_MAX; ++n) if (C->n_segs > n && (C->n_segs - 1) % n >= 2) { C->n_slab = n; break; }
+	for (int k=0;k<C->n_slab && R>0;++k) {
 		if (mlsd_malloc((void**)&C->slab[k], C->slab_bytes)) R = mlctx_fail(C, "weight streaming: slab allocation failed");
 		else C->mem_params += C->slab_bytes;
 	}
@@ -1289,7 +1295,7 @@ static int wstream_setup(MLCtx* C)
 				int z = 0;
 				for (; z<sg->n; ++z) if (vo >= sg->r[z].voff && vo < sg->r[z].voff + sg->r[z].bytes) break;
 				if (z == sg->n) { R = mlctx_fail(C, "weight streaming: internal (op %d references weights outside its segment)", i); break; }
-				*sl[q] = C->slab[g % MLW_NSLAB] + sg->r[z].soff + (vo - sg->r[z].voff);
+				*sl[q] = C->slab[g % C->n_slab] + sg->r[z].soff + (vo - sg->r[z].voff);
 			}
 		}
 	}
@@ -1325,22 +1331,22 @@ static int compute_streamed(MLCtx* C)
 		const char *e = getenv("MLSD_WSTREAM_TRACE"); trace = e && *e && *e != '0';
 		if (trace) for (int q=0;q<2;++q) for (int g=0;g<64;++g) if (mlsd_event_create(&T0[q][g]) || mlsd_event_create(&T1[q][g]) || mlsd_event_create(&TC[q][g])) return -1;
 	}
-	const int tr = trace && ns <= 64, par = C->info.n_compute & 1;
+	const int tr = trace && ns <= 64, par = C->info.n_compute & 1, NS = C->n_slab;
 #define UPLOAD(g, set) do { const MLWSeg *sg_ = &C->segs[g]; \
 		if (tr && mlsd_event_record(T0[set][g], C->copy_stream)) return -1; \
 		for (int z=0; z<sg_->n; ) { int z1 = z + 1; size_t nb = sg_->r[z].bytes;      /* coalesce ranges contiguous on both sides */ \
 			while (z1 < sg_->n && sg_->r[z1].moff == sg_->r[z1-1].moff + sg_->r[z1-1].bytes && sg_->r[z1].soff == sg_->r[z1-1].soff + sg_->r[z1-1].bytes) { nb += sg_->r[z1].bytes; ++z1; } \
-			if (mlsd_memcpy(C->slab[(g) % MLW_NSLAB] + sg_->r[z].soff, C->pmaster + sg_->r[z].moff, nb, 0, C->copy_stream)) return -1; \
+			if (mlsd_memcpy(C->slab[(g) % NS] + sg_->r[z].soff, C->pmaster + sg_->r[z].moff, nb, 0, C->copy_stream)) return -1; \
 			z = z1; } \
 		if (tr && mlsd_event_record(T1[set][g], C->copy_stream)) return -1; \
 		if (mlsd_event_record(C->ev_up[g], C->copy_stream)) return -1; } while (0)
-	/* Segment g lives in slab g % MLW_NSLAB and is uploaded as soon as the previous user of that slab (segment g - MLW_NSLAB, or the last segment of that slab in the
-	 * previous evaluation) has finished.  The weights do not change between evaluations, so the first MLW_NSLAB segments of the NEXT evaluation are uploaded at the end
+	/* Segment g lives in slab g % n_slab and is uploaded as soon as the previous user of that slab (segment g - n_slab, or the last segment of that slab in the
+	 * previous evaluation) has finished.  The weights do not change between evaluations, so the first n_slab segments of the NEXT evaluation are uploaded at the end
 	 * of this one, behind this evaluation's last users of their slabs: the copy stream never idles across the evaluation boundary (MLSD_WSTREAM_TRACE timeline of the
 	 * two-slab form, profiles/r4_wstream_trace.txt: 9 back-to-back uploads of 9.2 ms, then the last segment's 16 ms of ops and the next evaluation's first upload with
 	 * nothing beside them: 98 + 7 ms per evaluation for 81 ms of copies).  mlctx_param_set / mlctx_params_synth drop the prefetch (pf_valid). */
-#define LAST_USER(k) (ns - 1 - ((ns - 1 - (k)) % MLW_NSLAB))      /* last segment of this plan that lives in slab k (k < ns, k < MLW_NSLAB) */
-	const int lead = ns < MLW_NSLAB ? ns : MLW_NSLAB;
+#define LAST_USER(k) (ns - 1 - ((ns - 1 - (k)) % NS))      /* last segment of this plan that lives in slab k (k < ns, k < n_slab) */
+	const int lead = ns < NS ? ns : NS;
 	if (!C->pf_valid)
 		for (int g=0; g<lead; ++g) {
 			if (C->info.n_compute > 0 && mlsd_stream_wait_event(C->copy_stream, C->ev_done[LAST_USER(g)])) return -1;
@@ -1359,9 +1365,9 @@ static int compute_streamed(MLCtx* C)
 			}
 		}
 		if (mlsd_event_record(C->ev_done[g], C->stream)) return -1;
-		if (g + MLW_NSLAB < ns) {
+		if (g + NS < ns) {
 			if (mlsd_stream_wait_event(C->copy_stream, C->ev_done[g])) return -1;
-			UPLOAD(g + MLW_NSLAB, par);
+			UPLOAD(g + NS, par);
 		}
 	}
 	for (int g=0; g<lead; ++g) {                        /* the next evaluation's first segments */
@@ -1609,7 +1615,7 @@ MLB_API int mlctx_profile_ops(MLCtx* C, float* ms_out, int n_out)
 		if (C->pstream && seg < C->n_segs && C->segs[seg].op0 == i) {     /* streamed weights: this segment's weights into its slab first (blocking: not part of the op's time) */
 			const MLWSeg *sg = &C->segs[seg];
 			for (int z=0; z<sg->n; ++z)
-				if (mlsd_memcpy(C->slab[seg % MLW_NSLAB] + sg->r[z].soff, C->pmaster + sg->r[z].moff, sg->r[z].bytes, 0, C->stream)) return -1;
+				if (mlsd_memcpy(C->slab[seg % C->n_slab] + sg->r[z].soff, C->pmaster + sg->r[z].moff, sg->r[z].bytes, 0, C->stream)) return -1;
 			if (mlsd_stream_sync(C->stream)) return -1;
 			++seg;
 		}

@@ -74,7 +74,7 @@ typedef struct { int kind; char* name; int param; int64_t ne[4]; } MLNameRec;  /
 
 typedef struct { void* ptr; size_t size; int rel_op; } MLFreeBlk;   /* rel_op: ops recorded at release time */
 
-#define MLW_NSLAB 3      /* device slabs of a weight-streaming plan: segment g lives in slab g % MLW_NSLAB */
+#define MLW_NSLAB_MAX 5  /* device slabs of a weight-streaming plan: 3..5 (MLCtx.n_slab, chosen from the segment count at prep); segment g lives in slab g % n_slab */
 struct MLCtx {
 	void* stream;
 	char name[64];
@@ -110,12 +110,12 @@ struct MLCtx {
 	int n_gn_fused;            /* GroupNorms ended in their producers' split-K reduce pass (wire_gn_fold) */
 	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
 	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy
-	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of MLW_NSLAB device slabs, and segment i+MLW_NSLAB is uploaded (copy stream) as soon as segment i is done */
+	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of n_slab device slabs, and segment i+n_slab is uploaded (copy stream) as soon as segment i is done */
 	int pstream, pstream_hold;              /* on (mlctx_set_weight_streaming before the graph is built); hold > 0: allocations stay resident (weights of step-invariant ops) */
 	size_t pv_size;                         /* bytes of virtual weight space handed out */
 	struct MLWAlloc* pv_allocs; int n_pv, cap_pv;
 	char* pmaster;                          /* pinned host master copy [pv_size] (engine layout) */
-	size_t slab_bytes; char* slab[MLW_NSLAB];
+	size_t slab_bytes; char* slab[MLW_NSLAB_MAX]; int n_slab;
 	int pf_valid;                           /* the first segments of the NEXT evaluation are already uploaded / in flight (compute_streamed) */
 	struct MLWSeg* segs; int n_segs;
 	void* copy_stream; void **ev_up, **ev_done;   /* per segment */
