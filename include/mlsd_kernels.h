@@ -297,6 +297,7 @@ int mlsd_solver_taylor3(float* x, const float* dx, float* dp1, float* dp2, float
                         int64_t n, void* stream);                                                            /* solvers.c:150-165 */
 int mlsd_solver_dpmpp2m(float* x, const float* dx, float* dprev, float t_cur, float a, float c, int64_t n, void* stream);   /* :222-229 */
 int mlsd_solver_dpmpp2s(float* x, const float* x1, const float* dx1, float t1, float a, int64_t n, void* stream);           /* :281-284 */
+int mlsd_fill2_f32(float* a, int na, float va, float* b, int nb, float vb, void* stream);   /* a[0..na) = va, b[0..nb) = vb from kernel arguments (per-evaluation scalars: no copy-engine job) */
 int mlsd_noise_add_s(float* x, const float* noise, float s, int64_t n, void* stream);                /* sampling.c:115, scalar sigma */
 int mlsd_mask_apply(float* x, const float* x0, const float* mask /*[HW]*/, int HW, int64_t n, void* stream);   /* sampling.c:98-110 */
 /* sdvae_latent_sample / sdvae_latent_mean (src/vae.c:188-229): moments NHWC fp32 [B][HW][ld] (mean | logvar) -> latent NCHW

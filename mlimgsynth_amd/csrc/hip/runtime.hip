@@ -116,9 +116,22 @@ MLSD_API int mlsd_memset(void* dst, int value, size_t nbytes, void* stream)
 }
 
 // kind: 0 = host->device, 1 = device->host, 2 = device->device
+// device -> device copies run as a kernel: hipMemcpyAsync may hand them to the copy engine, where they queue behind its current job (with streamed weights a 500 MB
+// upload: 10 ms gaps between evaluations, MLSD_ENGINE_TRACE); latents and states are a few MB
+__global__ void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 MLSD_API int mlsd_memcpy(void* dst, const void* src, size_t nbytes, int kind, void* stream)
 {
     if (g_dry) { memcpy(dst, src, nbytes); return 0; }
+    if (kind == 2 && nbytes && !(nbytes & 15) && !(((uintptr_t)dst | (uintptr_t)src) & 15)) {
+        const size_t n16 = nbytes >> 4;
+        const unsigned blocks = (unsigned)(n16 >= (size_t)2048 * 256 ? 2048 : (n16 + 255) / 256);
+        hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+        return mlsd_check_launch("copy16_kernel");
+    }
     hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     MLSD_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, k, (hipStream_t)stream));
     return 0;

@@ -244,6 +244,22 @@ MLSD_API int mlsd_solver_dpmpp2s(float* x, const float* x1, const float* dx1, fl
     return mlsd_check_launch("solver_dpmpp2s");
 }
 
+/* two constants into two short device vectors, from kernel arguments: the per-evaluation scalars of the UNet (timestep for every row, c_in for every image) reach
+ * the device without a copy-engine job (a 64-byte hipMemcpyAsync queues behind whatever that engine is moving: with streamed weights, a 500 MB upload) */
+__global__ void fill2_kernel(float* a, int na, float va, float* b, int nb, float vb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = va;
+    if (i < nb) b[i] = vb;
+}
+MLSD_API int mlsd_fill2_f32(float* a, int na, float va, float* b, int nb, float vb, void* stream)
+{
+    const int n = na > nb ? na : nb;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill2_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, na, va, b, nb, vb);
+    return mlsd_check_launch("fill2_kernel");
+}
+
 MLSD_API int mlsd_noise_add_s(float* x, const float* noise, float s, int64_t n, void* stream)
 {
     hipLaunchKernelGGL(noise_add_s_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, noise, s, (long)n);

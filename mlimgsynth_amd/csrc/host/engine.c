@@ -52,7 +52,6 @@ struct MLIS_AmdCtx {
 	void *up_stream;            /* the draws are uploaded on a stream of their own (a 1 MB copy queued on the compute stream waits behind the copy engine's current job:
 	                             * with streamed weights that is a 500 MB upload, 9 ms of an 80 ms evaluation); ev_draw[k] orders draw k before its consumer */
 	void **ev_draw; int n_ev_draw;
-	float *h_scal;              /* pinned staging ring of per-evaluation scalars (t[N] | c_in[B]) */
 	int32_t *d_nan;
 	void *ev[2 * MAX_STEPS][2];
 	int n_ev;
@@ -88,7 +87,7 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	mlsd_free(S->d_x); mlsd_free(S->d_dx); mlsd_free(S->d_x0); mlsd_free(S->d_lmask); mlsd_free(S->d_img); mlsd_free(S->d_img_in);
 	for (int i=0;i<N_TMP;++i) mlsd_free(S->d_tmp[i]);
 	mlsd_free(S->d_cin); mlsd_free(S->d_noise); mlsd_free(S->d_nan);
-	mlsd_host_free(S->h_noise); mlsd_host_free(S->h_scal);
+	mlsd_host_free(S->h_noise);
 	for (int i=0;i<S->n_ev;++i) { mlsd_event_destroy(S->ev[i][0]); mlsd_event_destroy(S->ev[i][1]); }
 	for (int i=0;i<S->n_ev_draw;++i) mlsd_event_destroy(S->ev_draw[i]);
 	free(S->ev_draw);
@@ -97,7 +96,7 @@ MLB_API void mlis_amd_destroy(MLIS_AmdCtx* S)
 	free(S);
 }
 
-/* buffers whose size follows the step count: noise draws (<= 2 per step + 2), per-evaluation scalars and events (<= 2 per step) */
+/* buffers whose size follows the step count: noise draws (<= 2 per step + 2) and events (<= 2 per step) */
 static int ensure_steps(MLIS_AmdCtx* S, int ns)
 {
 	if (ns >= MAX_STEPS) return fail("too many steps (max 1000)");
@@ -105,12 +104,11 @@ static int ensure_steps(MLIS_AmdCtx* S, int ns)
 	const size_t lat_elems = (size_t)S->B * 4 * S->hw;
 	mlsd_stream_sync(S->stream);
 	if (S->up_stream) mlsd_stream_sync(S->up_stream);
-	mlsd_free(S->d_noise); mlsd_host_free(S->h_noise); mlsd_host_free(S->h_scal);
-	S->d_noise = NULL; S->h_noise = NULL; S->h_scal = NULL; S->cap_steps = 0;
+	mlsd_free(S->d_noise); mlsd_host_free(S->h_noise);
+	S->d_noise = NULL; S->h_noise = NULL; S->cap_steps = 0;
 	S->n_draw_max = 2 * ns + 2;
 	if (mlsd_malloc((void**)&S->d_noise, (size_t)S->n_draw_max*lat_elems*4)) return -1;
 	if (mlsd_host_alloc((void**)&S->h_noise, (size_t)S->n_draw_max*lat_elems*4)) return -1;
-	if (mlsd_host_alloc((void**)&S->h_scal, (size_t)2*ns*(S->N+S->B)*4)) return -1;
 	for (int i=S->n_ev; i<2*ns; ++i) { if (mlsd_event_create(&S->ev[i][0]) || mlsd_event_create(&S->ev[i][1])) return -1; S->n_ev = i+1; }
 	if (!S->up_stream && mlsd_stream_create(&S->up_stream)) return -1;
 	{	void **e = (void**)realloc(S->ev_draw, sizeof(void*) * (size_t)S->n_draw_max);
@@ -341,13 +339,12 @@ static int unet_eval(MLIS_AmdCtx* S, const float* x_eval, float sigma, int prefe
 	const int B = S->B, N = S->N;
 	void *st = S->stream;
 	if (S->i_eval >= 2*S->cap_steps) return fail("internal: too many evaluations");
-	float *hs = S->h_scal + (size_t)S->i_eval*(N+B);
 	const float t = unet_sigma_to_t(P, sigma);
 	const float c_in = 1 / sqrt(sigma*sigma + 1);                /* unet.c:471 */
-	for (int n=0;n<N;++n) hs[n] = t;
-	for (int b=0;b<B;++b) hs[N+b] = c_in;
 	float *d_t_in = (float*)mlctx_input_device_ptr(S->unet.t_t);
-	if (mlsd_memcpy(d_t_in, hs, (size_t)N*4, 0, st) || mlsd_memcpy(S->d_cin, hs + N, (size_t)B*4, 0, st)) return -1;
+	/* the same timestep for every row and the same c_in for every image: written by a kernel from its arguments.  (As two 64-byte copies they queued behind the copy
+	 * engine's current job -- with streamed weights a 500 MB upload: 10 ms gaps in front of 4 of 20 evaluations, MLSD_ENGINE_TRACE.) */
+	if (mlsd_fill2_f32(d_t_in, N, t, S->d_cin, B, c_in, st)) return -1;
 	if (x_eval != S->d_xin && mlsd_memcpy(S->d_xin, x_eval, (size_t)B*4*S->hw*4, 2, st)) return -1;
 	mlsd_event_record(S->ev[S->i_eval][0], st);
 	if (mlctx_compute(S->unet_ctx) < 0) return -1;               /* cond + uncond of all images: one evaluation */
@@ -416,7 +413,16 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 		if (S->c.s_ancestral > 0) dnsamp_ancestral(sigmas[s], sigmas[s+1], S->c.s_ancestral, &s_down, &s_up);   /* :153-166 */
 		const int anc_noise = (s_up > 0 && s+1 != n_step);
 		/* draws to have ready by the end of this step's first evaluation: the ancestral one and the next step's s_noise one */
-		const int k_prefetch = k_draw - 1 + anc_noise + ((S->c.s_noise > 0 && s+1 < n_step) ? 1 : 0);
+		int k_prefetch = k_draw - 1 + anc_noise + ((S->c.s_noise > 0 && s+1 < n_step) ? 1 : 0);
+		/* ... and ONE STEP FURTHER: the draws of step s+1 are generated and submitted while evaluation s is being enqueued.  A draw submitted after an evaluation's
+		 * uploads (weight streaming) sits behind them in the copy engine's queue -- behind the next evaluation's first segments, which wait for the end of this one:
+		 * the noise arrived one upload (10 ms) after the evaluation that needed it (MLSD_ENGINE_TRACE: gaps in front of 4 of 20 evaluations).  Exactly the draws the
+		 * schedule will consume: the generator state at the end of the call does not change. */
+		if (s + 1 < n_step) {
+			float sd2 = sigmas[s+2], su2 = 0;
+			if (S->c.s_ancestral > 0) dnsamp_ancestral(sigmas[s+1], sigmas[s+2], S->c.s_ancestral, &sd2, &su2);
+			k_prefetch += ((su2 > 0 && s+2 != n_step) ? 1 : 0) + ((S->c.s_noise > 0 && s+2 < n_step) ? 1 : 0);
+		}
 
 		/* ---- solver_step(&S->solver, s_down, x)  (src/solvers.c:43-52) */
 		const float t0 = solver_t, t1 = s_down;
@@ -495,6 +501,16 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 	if (mlctx_handoff_check(S->unet_ctx) < 0) return -8;                     /* an in-launch hand-off of the plan gave up waiting: results invalid (mlis_amd_denoise retries) */
 	float tot = 0;
 	for (int i=0; i<S->i_eval; ++i) { float ms = 0; mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &ms); tot += ms; }
+	{	/* diagnostics (MLSD_ENGINE_TRACE=1): per evaluation, its duration on the device and the gap to the next one */
+		static int tr = -1;
+		if (tr < 0) { const char *e = getenv("MLSD_ENGINE_TRACE"); tr = e && *e && *e != '0'; }
+		if (tr) for (int i=0; i<S->i_eval; ++i) {
+			float d = 0, g = 0, t0 = 0;
+			mlsd_event_elapsed_ms(S->ev[0][0], S->ev[i][0], &t0); mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &d);
+			if (i + 1 < S->i_eval) mlsd_event_elapsed_ms(S->ev[i][1], S->ev[i+1][0], &g);
+			fprintf(stderr, "[engine] evaluation %2d: starts at %8.2f ms, runs %7.2f ms, gap to the next %6.2f ms\n", i, t0, d, g);
+		}
+	}
 	S->last_unet_ms = tot;
 	S->unet.nfe += S->last_nfe;
 	S->have_init_latent = 0;                /* f_t_ini / latent use flags are cleared after a generation (mlimgsynth.c:700-706) */
