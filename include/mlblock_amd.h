@@ -50,9 +50,12 @@ int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's st
 int    mlctx_sync(MLCtx* C);
 int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K, LayerNorm statistics) of this plan gave up waiting since the last check: results
                                         * invalid; the flag / counter blocks are zeroed again before the error is returned */
-/* WEIGHT STREAMING (the reference's --unet-split, src/unet.c:390-458; BASELINE configs[4]): the plan's weights live in pinned host memory and pass through two device
- * slabs of slab_bytes each (0 = 512 MiB), uploaded segment by segment under the previous segment's launches.  Call before the graph is built; excludes MLB_F_HIPGRAPH.
- * Results are bit-identical to the resident plan. */
+/* WEIGHT STREAMING (the reference's --unet-split, src/unet.c:390-458; BASELINE configs[4]): the plan's weights live in pinned host memory and pass through THREE TO FIVE device
+ * slabs of slab_bytes each (0 = 512 MiB; the count is chosen at prep from the segment count: 3 for the SDXL UNet's 9 segments), uploaded segment by segment under the previous
+ * segments' launches.  Device cost: n_slab x slab_bytes (1.5 - 2.5 GiB at the default) + the resident weights of the step-invariant ops (SDXL: 0.68 GB) -- 2.2 GiB of UNet
+ * parameters on the device instead of 4.8; smaller slabs trade VRAM for more, shorter uploads (mlctx_weight_streaming_info reports both).  Call before the graph is built;
+ * excludes MLB_F_HIPGRAPH and the tile timing mode.  Only builders whose ops take parameters as GEMM weights / biases / norm affines / embedding tables can stream: prep
+ * fails by name for anything else.  Results are bit-identical to the resident plan. */
 int    mlctx_set_weight_streaming(MLCtx* C, size_t slab_bytes);
 int    mlctx_weight_streaming_copies(const MLCtx* C);   /* host -> device copies per evaluation (the host master is laid out in segment order: one per segment where no weight is needed twice) */
 int    mlctx_weight_streaming_info(const MLCtx* C, int* n_segments, size_t* streamed_bytes_per_eval, size_t* slab_bytes, size_t* host_bytes);   /* 0: the plan does not stream */

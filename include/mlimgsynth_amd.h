@@ -230,6 +230,8 @@ void mlis_prompt_free(MLISPrompt* P);
 /* ---------------------------------------------------------------- RNG / schedule / sampler */
 typedef struct { uint64_t seed; uint32_t offset; } RngPhilox;   /* src/ccommon/rng_philox.h */
 void rng_philox_randn(RngPhilox* S, unsigned n, float* out);
+/* values [i0, i1) of the draw the generator stands at, without advancing it (the engine cuts a draw into ranges over host threads) */
+void rng_philox_randn_range(const RngPhilox* S, unsigned i0, unsigned i1, float* out);
 
 enum { DNSAMP_SCHED_UNIFORM = 1, DNSAMP_SCHED_KARRAS = 2 };      /* src/sampling.h:11-14 */
 enum { SOLVER_METHOD_EULER = 1, SOLVER_METHOD_HEUN = 2, SOLVER_METHOD_TAYLOR3 = 3, SOLVER_METHOD_DPMPP2M = 4,
@@ -257,7 +259,8 @@ typedef struct {
 	float f_t_ini, f_t_end;  /* relative initial / final time: 0,0 -> 1,0 (txt2img); f_t_ini < 1 = img2img */
 	int defer_weights;       /* 1: do not synthesise weights: the caller loads them (mlctx_param_set on the *_ctx handles) */
 	int unet_split;          /* > 0: the UNet's weights are STREAMED (the reference's --unet-split / MLIS_OPT_UNET_SPLIT, src/unet.c:390-458): master copy in pinned host
-	                          * memory, three device slabs of `unet_split` MiB each (1 = the default 512 MiB) filled under the launches; excludes use_hipgraph */
+	                          * memory, three to five device slabs (3 for SDXL) of `unet_split` MiB each (1 = the default 512 MiB: 1.5 GiB of slabs + 0.68 GB of resident step-invariant
+	                          * weights instead of 4.8 GiB) filled under the launches; excludes use_hipgraph */
 } MLIS_AmdConfig;
 
 /* progress callback (MLIS_Callback, include/mlimgsynth.h:405): called after every COMPLETED step (the stream is
@@ -304,7 +307,8 @@ int mlis_amd_last_n_step(MLIS_AmdCtx* S);
 int mlis_amd_handoff_retries(const MLIS_AmdCtx* S);
 /* pieces, for tests and for the multi-GPU driver */
 int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds);               /* latent stays on device */
-int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device; asynchronous */
+int mlis_amd_decode(MLIS_AmdCtx* S);                                        /* image stays on device; asynchronous UNLESS the decoder plan hands data over inside launches
+                                                                             * (stream-K tiles: the SDXL VAE has them): then the stream is drained here to check the hand-offs */
 int mlis_amd_sync(MLIS_AmdCtx* S);                                          /* wait for the engine's stream */
 void* mlis_amd_latent_device(MLIS_AmdCtx* S);                               /* fp32 NCHW [n][4][lh][lw] */
 void* mlis_amd_image_device(MLIS_AmdCtx* S);                                /* fp32 NCHW [n][3][h][w] */

@@ -48,6 +48,7 @@ struct GemmP {
     int M, N, K;
     // conv geometry
     int H, W, Cin, OH, OW, KH, KW, stride, pad, ups;
+    int korder;   // conv, Cin % 64 == 0: 0 = K runs (kh, kw, cin), 1 = (cin / 64, kh, kw, cin % 64): the KH KW taps of a 64-channel slab are consecutive K tiles (mlsd_gemm_args.conv_korder)
     // epilogue
     const float* bias;
     const float* biasm;
@@ -1040,7 +1041,7 @@ int launch(const mlsd_gemm_args* a, hipStream_t st)
     p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_;
     p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
     p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
-    p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample;
+    p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample; p.korder = 0;
     p.bias = a->bias; p.biasm = a->bias_m; p.act_post = a->act_after_resid; p.rowbias = a->rowbias; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
     p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
@@ -1145,6 +1146,7 @@ int device_cus()
 
 // problems the ping-pong kernels take (gemm_pp.hpp); everything else asked of variants 17 / 18 runs on the LDS-transposing
 // tile of the same shape (9 / 16)
+int g_gemm_korder = 0;     // experiment: slab-ordered K for the ping-pong convolutions (timing only until the weights follow)
 bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
     if ((a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
@@ -1218,7 +1220,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_;
     p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
     p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
-    p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample;
+    p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample; p.korder = g_gemm_korder;
     p.bias = a->bias; p.biasm = a->bias_m; p.act_post = a->act_after_resid; p.rowbias = a->rowbias; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
     p.ldrb = a->ldrb; p.resid = a->resid; p.ldr = a->ldr; p.act = a->act;
     p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
@@ -1372,6 +1374,9 @@ static int mlsd_gemm_w4_eligible(const mlsd_gemm_args*, int) { return 0; }
 static int mlsd_gemm_w4(const mlsd_gemm_args*, int, void*, int) { return -1; }
 #endif
 
+extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu);     // gemm_tt.hip: 128 x 160 tile, 4 waves, two blocks per CU (variant 30)
+extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu);
+
 struct Variant { const char* name; int bm, bn, slots; };
 const Variant kVariants[] = {
     {"128x128x64s2", 128, 128, 512},   // 0: 64 KB ring, 2 blocks/CU
@@ -1405,6 +1410,8 @@ const Variant kVariants[] = {
     {"128x320x64ppsk", 128, 320, 256},  // 28: variant 18 as STREAM-K (round 4): N = 320 / 640 / 1280 outputs with FEW tiles and long K -- the 3x3 convolutions of SD1.5 batch 1
                                         //     (8192x320x2880: 64 tiles, 2048x640x5760: 32, 512x1280x11520: 16) -- dealt over all 256 CUs in K-tile units
     {"skinny128x64", 128, 64, 512},     // 29: M <= 128 weight streaming (gemm_skinny.hpp): all rows in one block, weights global -> registers, 7 K steps in flight, K slices + fixed-order reduce
+    {"128x160x64tt", 128, 160, 512},    // 30: TWO tiles in flight per CU (gemm_tt.hip, round 5): 4-wave blocks, two resident per CU in two priority classes, so that one tile's residual
+                                        //     read / output burst runs under the other tile's K loop -- the single-round 8192 x 1280 outputs of the SDXL transformer blocks
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -1471,6 +1478,11 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
     case 29:
         if (skinny_eligible(a)) return launch_skinny(a, st);
         return launch<64, 128, 64, 2, 2, 2>(a, st);
+    case 30:
+        if (mlsd_gemm_tt_eligible(a, g_gemm_ncu)) return mlsd_gemm_tt(a, st, g_gemm_ncu);
+        if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);      // anything else: the ping-pong tile nearest in shape
+        if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
+        return launch<128, 320, 64, 4, 2, 2>(a, st);
     case 28:
         if (sk_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, true>(a, st);
         [[fallthrough]];
@@ -1523,6 +1535,7 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+MLSD_API void mlsd_gemm_set_korder(int k) { g_gemm_korder = k; }
 #ifdef MLSD_GEMM_EXPERIMENTS
 MLSD_API void mlsd_gemm_set_splitk_inline(int on) { g_gemm_sk_inline = on != 0; }
 #else
@@ -1609,6 +1622,7 @@ MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
         if (vec && splitk_slices(a, 64, nullptr) > 1 && !splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)))
             return 2;
     }
+    if (v == 30) { const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu); return (e == 4 || e == 5) ? 1 : 0; }      // (TT_F32_LN / TT_F32_RES_LN)
     if (v != 18 || !ln_eligible(a)) return 0;
     const int e = pp_epilogue_kind(a, 320);
     return (e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN) ? 1 : 0;
@@ -1647,6 +1661,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
         snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", skinny_slices(a, nullptr));
         return buf;
     }
+    if (v == 30 && !mlsd_gemm_tt_eligible(a, g_gemm_ncu)) v = 18;
     if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     auto enter_A = [&](SeqA& s, int second) __attribute__((always_inline)) {
         s.kt = kenter; s.kh = 0; s.kw = 0; s.cin = 0;
         if constexpr (CONV) {
-            if (kenter) { const int k0 = kenter * BK, tap = k0 / p.Cin; s.cin = k0 - tap * p.Cin; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
+            if (kenter) {
+                if (p.korder) { const int kk = p.KH * p.KW, slab = kenter / kk, tap = kenter - slab * kk; s.cin = slab * BK; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
+                else { const int k0 = kenter * BK, tap = k0 / p.Cin; s.cin = k0 - tap * p.Cin; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
+            }
         }
 #pragma unroll
         for (int it = 0; it < NU1; ++it) {
@@ -250,7 +253,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             if constexpr (!CONV) s.ptr[it] += BK;
         }
         s.par ^= 1;
-        if constexpr (CONV) { s.cin += BK; if (s.cin == p.Cin) { s.cin = 0; if (++s.kw == p.KW) { s.kw = 0; ++s.kh; } } }
+        if constexpr (CONV) {
+            if (p.korder) { if (++s.kw == p.KW) { s.kw = 0; if (++s.kh == p.KH) { s.kh = 0; s.cin += BK; } } }      // slab order: the taps of this 64-channel slab first
+            else { s.cin += BK; if (s.cin == p.Cin) { s.cin = 0; if (++s.kw == p.KW) { s.kw = 0; ++s.kh; } } }
+        }
         if (++s.kt == nkt) enter_A(s, second);
     };
     auto issue_B2 = [&]() __attribute__((always_inline)) {
@@ -819,7 +825,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 }
             }
             __builtin_amdgcn_s_barrier();
-            // the slabs are read with agent-scope (sc1) loads: they were written through by blocks of other XCDs (no acquire fence: invalidating the caches of 8 waves costs more)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // program order only: the slab loads below must not be hoisted above the flag poll / barrier by the compiler
+            // the slabs are read with agent-scope (sc1) loads: they were written through by blocks of other XCDs (no AGENT acquire fence: invalidating the caches of 8 waves costs more)
             constexpr int GB = 4;                                                  // slabs in flight per row group: GB * NCB float4 beside the accumulators
             const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_ws + (long)(skw + 1) * (BM * BN)), 0, 0x7fffffff, 0x00020000);
             const int lofs = (wave * (2 * RA * NCB) * 64 + lane) * 16;

@@ -106,6 +106,8 @@ static int param_to_host(MLCtx* C, const char* key, float* out, size_t n)
 	for (int i=0;i<C->n_params;++i) if (C->params[i].key && !strcmp(C->params[i].key, key)) {
 		MLParam *p = &C->params[i];
 		if (p->type != MLT_F32 || p->layout != 0 || p->dev_elems != n) return mlctx_fail(C, "param_to_host(%s): unsupported", key);
+		if (C->pstream && (const char*)p->dev >= MLW_VBASE && (const char*)p->dev < MLW_VBASE + C->pv_size)      /* a virtual (streamed) address is never dereferenced */
+			return mlctx_fail(C, "param_to_host(%s): the parameter is streamed (mlctx_set_weight_streaming): not supported by this builder", key);
 		if (mlsd_memcpy(out, p->dev, n*4, 1, C->stream) || mlsd_stream_sync(C->stream)) return -1;
 		return 1;
 	}

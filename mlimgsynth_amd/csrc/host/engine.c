@@ -18,6 +18,8 @@
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
 #include <math.h>
+#include <pthread.h>
+#include <unistd.h>
 
 int unet_denoise_build(UnetState* S);
 
@@ -61,7 +63,7 @@ struct MLIS_AmdCtx {
 	int own_stream;
 	RngPhilox rng[MAX_BATCH];
 	int cap_steps;
-	int n_draw_max, n_draw_gen;          /* noise draws of the current denoise call: planned / generated so far */
+	int n_draw_max, n_draw_gen, k_draw;  /* noise draws of the current denoise call: planned / generated so far / consumed so far */
 	int i_eval;
 	mlis_amd_progress_fn cb; void* cb_user;
 	/* VAE tiling (MLIS_OPT_VAE_TILE; src/vae.c:245-300,333-391): tile-sized plans, built on first use */
@@ -312,13 +314,45 @@ MLB_API int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask)
  * Every dnsamp_noise_add (src/sampling.c:112-117) is one rng_randn call of the whole latent per image.  Which draws a
  * run makes is known from the schedule alone, so draw k is generated on the host as soon as the evaluation before it
  * has been enqueued (the GPU is busy for tens of ms) and uploaded asynchronously. */
+/* One draw = rng_philox_randn of the whole latent per image (src/ccommon/rng_philox.c:23-51): value i of image b is a pure function of (seed_b, offset_b, i), so the
+ * B x 4 x hw values are cut into ranges over host threads -- bit-identical by construction (round 5: the single-threaded draw of the FIRST noise, 4 x 65 536 Box-Muller values
+ * in fp64 before any GPU work, was 12 ms of every SDXL batch-4 step). */
+typedef struct { const RngPhilox* rng; unsigned i0, i1; float* out; } DrawJob;
+static void* draw_worker(void* arg)
+{
+	const DrawJob *j = arg;
+	rng_philox_randn_range(j->rng, j->i0, j->i1, j->out);
+	return NULL;
+}
+static void draw_all(MLIS_AmdCtx* S, float* hn, size_t per)
+{
+	enum { MAXT = 32, MIN_CHUNK = 8192 };
+	static int ncpu = 0;
+	if (!ncpu) { long n = sysconf(_SC_NPROCESSORS_ONLN); ncpu = n < 1 ? 1 : (n > MAXT ? MAXT : (int)n); }
+	const size_t total = (size_t)S->B * per;
+	int nt = (int)(total / MIN_CHUNK); if (nt > ncpu) nt = ncpu; if (nt < 1) nt = 1;
+	int per_img = (nt + S->B - 1) / S->B; if (per_img < 1) per_img = 1;       /* ranges never straddle images */
+	DrawJob jobs[MAX_BATCH * MAXT]; pthread_t th[MAX_BATCH * MAXT];
+	int nj = 0;
+	for (int b=0;b<S->B;++b) for (int q=0;q<per_img;++q) {
+		const unsigned i0 = (unsigned)(per * q / per_img), i1 = (unsigned)(per * (q + 1) / per_img);
+		jobs[nj++] = (DrawJob){ &S->rng[b], i0, i1, hn + (size_t)b*per + i0 };
+	}
+	int started = 0;
+	for (int j=1;j<nj;++j) { if (pthread_create(&th[j], NULL, draw_worker, &jobs[j])) break; started = j; }
+	draw_worker(&jobs[0]);
+	for (int j=started+1;j<nj;++j) draw_worker(&jobs[j]);                     /* (threads that could not be created: their ranges run here) */
+	for (int j=1;j<=started;++j) pthread_join(th[j], NULL);
+	for (int b=0;b<S->B;++b) S->rng[b].offset++;
+}
+
 static const float* noise_gen(MLIS_AmdCtx* S, int k)
 {	/* generate and upload every draw up to k (upload stream; nothing is enqueued on the compute stream) */
 	const size_t per = (size_t)4 * S->hw, lat_elems = (size_t)S->B * per;
 	if (k >= S->n_draw_max) { fail("internal: too many noise draws"); return NULL; }
 	for (; S->n_draw_gen <= k; S->n_draw_gen++) {
 		float *hn = S->h_noise + (size_t)S->n_draw_gen*lat_elems, *dn = S->d_noise + (size_t)S->n_draw_gen*lat_elems;
-		for (int b=0;b<S->B;++b) rng_philox_randn(&S->rng[b], (unsigned)per, hn + (size_t)b*per);
+		draw_all(S, hn, per);
 		if (mlsd_memcpy(dn, hn, lat_elems*4, 0, S->up_stream) || mlsd_event_record(S->ev_draw[S->n_draw_gen], S->up_stream)) return NULL;
 	}
 	return S->d_noise + (size_t)k*lat_elems;
@@ -367,7 +401,7 @@ static int dxdt_finish(MLIS_AmdCtx* S, const float* x_eval, float sigma, float* 
 	return mlsd_dxdt_cfg(eps, ld, x_eval, dx, S->B, 4, S->hw, S->c.cfg_scale, S->unet_p.vparam, c_out, c_skip, S->stream) ? -1 : 1;
 }
 
-static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
+static int denoise_body(MLIS_AmdCtx* S, const uint64_t* seeds, int* retry_wanted)
 {
 	if (!S->cond_set) return fail("mlis_amd_denoise: conditioning not set");
 	const UnetParams *P = &S->unet_p;
@@ -387,7 +421,7 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 	unsigned i_step_solver = 0;
 	float dt_prev = 0, h_last = 0;                                            /* taylor3 / dpmpp2m scalar state */
 	S->n_draw_gen = 0; S->i_eval = 0; S->last_nfe = 0; S->last_n_step = n_step;
-	int k_draw = 0;
+	S->k_draw = 0;
 	if (mlsd_memset(S->d_nan, 0, 4, st)) return -1;
 	if (!S->have_init_latent && mlsd_memset(S->d_x, 0, (size_t)nel*4, st)) return -1;   /* mlimgsynth.c:1669-1670 */
 	if (method == SOLVER_METHOD_TAYLOR3 || method == SOLVER_METHOD_DPMPP2M) {
@@ -399,13 +433,13 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 		float s_up = 0, s_down = sigmas[s+1];
 		if (s == 0) {                                                         /* sampling.c:129-137 */
 			if (S->have_lmask && mlsd_memcpy(S->d_x0, S->d_x, (size_t)nel*4, 2, st)) return -1;
-			const float *nz = noise_draw(S, k_draw++);
+			const float *nz = noise_draw(S, S->k_draw++);
 			if (!nz || mlsd_noise_add_s(S->d_x, nz, sigmas[0], nel, st)) return -1;
 			if (S->have_lmask && mlsd_mask_apply(S->d_x, S->d_x0, S->d_lmask, S->hw, nel, st)) return -1;
 		}
 		if (S->c.s_noise > 0 && s > 0) {                                      /* :139-151 */
 			float s_curr = sigmas[s], s_hat = s_curr * sqrt(2) * S->c.s_noise, s_n = sqrt(s_hat*s_hat - s_curr*s_curr);
-			const float *nz = noise_draw(S, k_draw++);
+			const float *nz = noise_draw(S, S->k_draw++);
 			if (!nz || mlsd_noise_add_s(S->d_x, nz, s_n, nel, st)) return -1;
 			if (S->have_lmask && mlsd_mask_apply(S->d_x, S->d_x0, S->d_lmask, S->hw, nel, st)) return -1;
 			solver_t = s_hat;
@@ -413,7 +447,7 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 		if (S->c.s_ancestral > 0) dnsamp_ancestral(sigmas[s], sigmas[s+1], S->c.s_ancestral, &s_down, &s_up);   /* :153-166 */
 		const int anc_noise = (s_up > 0 && s+1 != n_step);
 		/* draws to have ready by the end of this step's first evaluation: the ancestral one and the next step's s_noise one */
-		int k_prefetch = k_draw - 1 + anc_noise + ((S->c.s_noise > 0 && s+1 < n_step) ? 1 : 0);
+		int k_prefetch = S->k_draw - 1 + anc_noise + ((S->c.s_noise > 0 && s+1 < n_step) ? 1 : 0);
 		/* ... and ONE STEP FURTHER: the draws of step s+1 are generated and submitted while evaluation s is being enqueued.  A draw submitted after an evaluation's
 		 * uploads (weight streaming) sits behind them in the copy engine's queue -- behind the next evaluation's first segments, which wait for the end of this one:
 		 * the noise arrived one upload (10 ms) after the evaluation that needed it (MLSD_ENGINE_TRACE: gaps in front of 4 of 20 evaluations).  Exactly the draws the
@@ -433,10 +467,10 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 			if (!P->vparam) {   /* fused: CFG mix, x += dx*dt and the ancestral noise of sampling.c:170-172 in one launch */
 				int64_t ld = 0;
 				const float *eps = mlctx_tensor_device_f32(S->unet_ctx, S->unet.t_out, &ld);
-				const float *nz = anc_noise ? noise_draw(S, k_draw) : NULL;
+				const float *nz = anc_noise ? noise_draw(S, S->k_draw) : NULL;
 				if (anc_noise && !nz) return -1;
 				if (mlsd_euler_cfg_update(S->d_x, eps, ld, B, 4, S->hw, S->c.cfg_scale, t1 - t0, nz, s_up, st)) return -1;
-				if (nz) { k_draw++; s_up = -1; }                               /* noise already added */
+				if (nz) { S->k_draw++; s_up = -1; }                               /* noise already added */
 			} else {
 				if (dxdt_finish(S, S->d_x, t0, S->d_dx) < 0) return -1;
 				if (mlsd_vec_axpy(S->d_x, S->d_x, S->d_dx, t1 - t0, nel, st)) return -1;
@@ -484,7 +518,7 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 		solver_t = t1; i_step_solver++;                                       /* solvers.c:49-50 */
 
 		if (s_up > 0 && s+1 != n_step) {                                      /* sampling.c:170-174 */
-			const float *nz = noise_draw(S, k_draw++);
+			const float *nz = noise_draw(S, S->k_draw++);
 			if (!nz || mlsd_noise_add_s(S->d_x, nz, s_up, nel, st)) return -1;
 		}
 		if (anc_noise) solver_t = sigmas[s+1];
@@ -498,7 +532,10 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 	}
 	int32_t nan_count = 0;
 	if (mlsd_memcpy(&nan_count, S->d_nan, 4, 1, st) || mlsd_stream_sync(st)) return -1;
-	if (mlctx_handoff_check(S->unet_ctx) < 0) return -8;                     /* an in-launch hand-off of the plan gave up waiting: results invalid (mlis_amd_denoise retries) */
+	if (mlctx_handoff_check(S->unet_ctx) < 0) {                              /* an in-launch hand-off of the plan gave up waiting: results invalid (mlis_amd_denoise retries) */
+		if (retry_wanted) *retry_wanted = 1;                                 /* out of band: a user callback may abort with any negative value, -8 included */
+		return -1;
+	}
 	float tot = 0;
 	for (int i=0; i<S->i_eval; ++i) { float ms = 0; mlsd_event_elapsed_ms(S->ev[i][0], S->ev[i][1], &ms); tot += ms; }
 	{	/* diagnostics (MLSD_ENGINE_TRACE=1): per evaluation, its duration on the device and the gap to the next one */
@@ -518,6 +555,21 @@ static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds)
 	return 1;
 }
 
+/* denoise_body + the clean-up of a call that ends early (callback abort, error): the one-step-ahead prefetch has generated -- and advanced the Philox states past -- draws
+ * the loop never consumed, and their uploads may still be pending while the next call rewrites h_noise.  The upload stream is drained and every image's
+ * generator is rewound to the draws actually consumed, so a following call with seeds = NULL continues the stream where this one stopped. */
+static int denoise_once(MLIS_AmdCtx* S, const uint64_t* seeds, int* retry_wanted)
+{
+	const int r = denoise_body(S, seeds, retry_wanted);
+	if (r < 0) {
+		if (S->up_stream) mlsd_stream_sync(S->up_stream);
+		const int ahead = S->n_draw_gen - S->k_draw;
+		if (ahead > 0) for (int b=0;b<S->B;++b) S->rng[b].offset -= (uint32_t)ahead;
+		S->n_draw_gen = S->k_draw;
+	}
+	return r;
+}
+
 /* The denoising loop with ONE retry on the hand-off-free plan: a timed-out in-launch hand-off (stream-K slab, LayerNorm statistics: a partner block
  * was not resident -- CUs shared with another process, CU-masked stream) is detected when the results are read back; the loop is deterministic in (initial latent,
  * Philox states, conditioning), so those are kept and the whole loop runs again with plain tiles and separate LayerNorm launches.  Never by restarting the process. */
@@ -535,15 +587,16 @@ MLB_API int mlis_amd_denoise(MLIS_AmdCtx* S, const uint64_t* seeds)
 			if (mlsd_memcpy(S->d_xsave, S->d_x, xbytes, 2, S->stream)) return -1;
 		}
 	}
-	int r = denoise_once(S, NULL);
-	if (r != -8 || !guard) return r;
+	int retry = 0;
+	int r = denoise_once(S, NULL, &retry);
+	if (!retry || !guard) return r;
 	mlctx_handoffs_off(S->unet_ctx);
 	S->n_handoff_retries++;
 	memcpy(S->rng, keep, sizeof(S->rng[0]) * (size_t)S->B);
 	S->have_init_latent = had_init;
 	if (had_init && mlsd_memcpy(S->d_x, S->d_xsave, xbytes, 2, S->stream)) return -1;
-	r = denoise_once(S, NULL);
-	return r == -8 ? -1 : r;
+	retry = 0;
+	return denoise_once(S, NULL, &retry);
 }
 
 /* ------------------------------------------------------------------ VAE tiling

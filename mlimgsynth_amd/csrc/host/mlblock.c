@@ -22,6 +22,7 @@
 #define VARIANT_STREAMK 20      /* tile_variant (1-based) of the stream-K ping-pong tile (256 x 256) */
 #define VARIANT_STREAMK2 29     /* the same on the 128 x 320 tile (round 4) */
 #define IS_STREAMK(v) ((v) == VARIANT_STREAMK || (v) == VARIANT_STREAMK2)
+#define VARIANT_TT 31           /* two tiles in flight per CU (gemm_tt.hip, round 5) */
 #define VARIANT_SKINNY 30       /* the skinny-M weight-streaming kernel (gemm_skinny.hpp): always runs through the split-K workspace */
 #define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile; word 4095: sticky give-up */
 #define LN_CNT_WORDS 8192       /* LayerNorm fold: arrival / departure counters per (row block, wave row); word 8191: sticky give-up */
@@ -179,6 +180,7 @@ MLB_API int mlctx_handoffs_off(MLCtx* C)
 		if ((IS_STREAMK(g->tile_variant) || g->ksplit > 1) && g->sk_flags) { g->sk_flags = NULL; ++n; }     /* (split-K: back to the two-launch form) */
 	}
 	if (n && C->graph_exec) { mlsd_graph_destroy(C->graph_exec); C->graph_exec = NULL; }
+	C->static_valid = 0;      /* the timed-out launch may have been a hoisted step-invariant op (stream-K is not excluded for `once` ops): every caller's re-run recomputes them */
 	return n;
 }
 
@@ -193,7 +195,6 @@ MLB_API int mlctx_compute_checked(MLCtx* C)
 	if (mlctx_handoff_check(C) == 0) return 1;
 	mlctx_handoffs_off(C);
 	g_handoff_retries++;
-	C->static_valid = 0;                                     /* (the step-invariant ops may have been hit too) */
 	if (mlctx_compute(C) < 0 || mlsd_stream_sync(C->stream)) return -1;
 	return mlctx_handoff_check(C) == 0 ? 1 : -1;
 }
@@ -248,7 +249,7 @@ static int is_virtual(const MLCtx* C, const void* p) { return C->pstream && (con
 
 void* mlctx_walloc(MLCtx* C, size_t nbytes)
 {
-	if (!C->pstream || C->pstream_hold) return dalloc_ex(C, nbytes, 1, 0x7fffffff);
+	if (!C->pstream) return dalloc_ex(C, nbytes, 1, 0x7fffffff);
 	nbytes = ALIGN_UP(nbytes ? nbytes : 256, 256);
 	MLWAlloc *a = VEC_PUSH(C, C->pv_allocs, C->n_pv, C->cap_pv, MLWAlloc);
 	a->voff = C->pv_size; a->bytes = nbytes; a->moff = a->voff;
@@ -776,6 +777,15 @@ static int select_gemm(MLCtx* C, MLOp* op)
 		if (ks > 1 && (size_t)ks * g->M * g->N * sizeof(float) > SPLITK_WS_BYTES) g->ksplit = 1;
 		if (g->ksplit > 1 && streamk_get(C, g)) return -1;
 		if ((IS_STREAMK(best) || best == VARIANT_SKINNY) && streamk_get(C, g)) return -1;
+		/* The 128 x 160 two-tiles-per-CU kernel (gemm_tt.hip, round 5) instead of the 128 x 320 ping-pong tile WHERE THAT TILE FILLS AT MOST HALF OF THE CUs (a pure function
+		 * of the shape).  In-plan A/B, same box (profiles/r5_gemm_tt_inplan.txt): SDXL b2 evaluation -2.4 %, b1 -0.9 %, SD1.5 b2 -1.1 %; on the full-chip single-round
+		 * launches of SDXL b4 it LOSES (+0.4 .. +0.7 %: its loop is 25 % slower than the ping-pong loop, which eats the overlap it buys) and is not used there.
+		 * MLSD_TT: 0 = never, 1 = also where K >= 2560, 2 = on every shape it takes (the A/B settings of that study), 3 / unset = the rule above. */
+		static int tt_mode = -1;
+		if (tt_mode < 0) { const char *e = getenv("MLSD_TT"); tt_mode = e && *e ? atoi(e) : 3; }
+		if (tt_mode > 0 && (best == 19 || best == 21) && !g->conv && g->act == MLSD_ACT_NONE && !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->ksplit <= 1 &&
+		    !g->rowbias && !g->bias_m && (tt_mode == 2 || (tt_mode == 1 && g->K >= 2560) || (tt_mode >= 1 && (long)(g->M / 128) * ((g->N + 319) / 320) <= 128)) &&
+		    !(C->cu_budget > 0 && C->cu_budget < 256)) g->tile_variant = VARIANT_TT;
 		return 1;
 	}
 	g->tile_variant = 0; g->ksplit = 1;
@@ -1099,8 +1109,9 @@ static void wire_ln_fold(MLCtx* C)
 			if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
 			/* two forms (mlsd_gemm_ln_fused): inside a single-round launch of the 128x320 ping-pong tile (needs scratch for the row statistics), or -- round 4 -- in the
 			 * reduce pass of a split-K launch (no scratch, no hand-off) */
-			const int pp_form = !(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1);
-			const size_t need = pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
+			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1);      /* (N / 160 partner tiles per row block) */
+			const int pp_form = tt_form || (!(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
+			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 8 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
 			if (!pass) { if (need > need_max) need_max = need; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }
 			if (need > C->ln_ws_bytes) continue;
 			if (!pp_form && !(g->ksplit > 1)) continue;
@@ -1189,7 +1200,7 @@ static void wstream_free(MLCtx* C)
 	C->pf_valid = 0;
 	if (C->pscratch) { mlsd_free(C->pscratch); C->pscratch = NULL; C->pscratch_bytes = 0; }
 	free(C->pv_allocs); C->pv_allocs = NULL; C->n_pv = C->cap_pv = 0; C->pv_size = 0;
-	C->stream_bytes_per_eval = 0; C->pstream_hold = 0;      /* (pstream / slab_bytes are settings of the context, like its flags: they survive mlctx_begin) */
+	C->stream_bytes_per_eval = 0;      /* (pstream / slab_bytes are settings of the context, like its flags: they survive mlctx_begin) */
 }
 
 /* slab_bytes: size of each of the device slabs (0 = default 512 MiB); call before the graph is built */
@@ -1297,6 +1308,18 @@ static int wstream_setup(MLCtx* C)
 				if (z == sg->n) { R = mlctx_fail(C, "weight streaming: internal (op %d references weights outside its segment)", i); break; }
 				*sl[q] = C->slab[g % C->n_slab] + sg->r[z].soff + (vo - sg->r[z].voff);
 			}
+		}
+	}
+	/* Nothing may still point into the virtual range: only the slots of op_weight_slots are patched, and mlctx_set_weight_streaming is a public per-context
+	 * switch -- a builder whose ops take a parameter through ANOTHER field would launch on a never-mapped address and fault the GPU.  Every pointer-sized word of every
+	 * op's argument block is checked (the virtual base is an address no host or device allocation has), and prep fails by name instead. */
+	for (int i=0; i<C->n_ops && R>0; ++i) {
+		const MLOp *o = &C->ops[i];
+		const unsigned char *u = (const unsigned char*)&o->u;
+		for (size_t off=0; off + sizeof(void*) <= sizeof(o->u); off += sizeof(void*)) {
+			const void *pp; memcpy(&pp, u + off, sizeof(pp));
+			if (is_virtual(C, pp)) { R = mlctx_fail(C, "weight streaming: op %d (%s) takes a streamed parameter through a field the streaming plan does not patch "
+				"(argument word %zu): this builder cannot run with mlctx_set_weight_streaming", i, o->label, off / sizeof(void*)); break; }
 		}
 	}
 	if (R > 0) {
@@ -1474,6 +1497,9 @@ MLB_API int mlctx_compute(MLCtx* C)
 		return mlctx_fail(C, "parameter '%s' was never loaded", C->params[i].key);
 	double t0 = now_s();
 	if (!C->tuned && autotune_on() && !mlsd_runtime_is_dry()) {
+		/* (a weight-streaming plan's ops point into slabs that only compute_streamed fills: the eager pass would time -- and return -- garbage, ADVICE r4.  Its GEMM
+		 * shapes are those of the resident plan: tune that one.) */
+		if (C->pstream && C->n_segs) return mlctx_fail(C, "tile timing mode (MLSD_AUTOTUNE / mlctx_set_autotune) on a weight-streaming context: tune the resident plan, the shapes are the same");
 		/* first evaluation: run eagerly, timing the tile variants of every not-yet-seen GEMM shape on its real
 		 * operands (the ops before it have already produced them) */
 		for (int i=0;i<C->n_ops;++i) {

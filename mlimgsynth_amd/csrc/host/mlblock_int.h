@@ -111,7 +111,7 @@ struct MLCtx {
 	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
 	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy
 	 * lives in pinned host memory, the plan is cut into segments whose weights fit one of n_slab device slabs, and segment i+n_slab is uploaded (copy stream) as soon as segment i is done */
-	int pstream, pstream_hold;              /* on (mlctx_set_weight_streaming before the graph is built); hold > 0: allocations stay resident (weights of step-invariant ops) */
+	int pstream;                            /* on (mlctx_set_weight_streaming before the graph is built) */
 	size_t pv_size;                         /* bytes of virtual weight space handed out */
 	struct MLWAlloc* pv_allocs; int n_pv, cap_pv;
 	char* pmaster;                          /* pinned host master copy [pv_size] (engine layout) */

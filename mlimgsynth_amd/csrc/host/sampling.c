@@ -13,10 +13,12 @@ static const uint32_t philox_w[2] = {0x9E3779B9, 0xBB67AE85};
 static const double two_pow32_inv     = 2.3283064365386963e-10;   /*   1/2^32 */
 static const double two_pow32_inv_2pi = 1.4629180792671596e-09;   /* 2pi/2^32 */
 
-MLB_API void rng_philox_randn(RngPhilox* S, unsigned n, float* out)
+/* values [i0, i1) of the draw the generator stands at (counter (offset, 0, i, 0)); does not advance it */
+MLB_API void rng_philox_randn_range(const RngPhilox* S, unsigned i0, unsigned i1, float* out)
 {
 	const uint32_t k0 = (uint32_t)S->seed, k1 = (uint32_t)(S->seed >> 32);
-	for (unsigned i=0; i<n; ++i) {
+	out -= i0;
+	for (unsigned i=i0; i<i1; ++i) {
 		uint32_t c0 = S->offset, c1 = 0, c2 = i, c3 = 0, ka = k0, kb = k1;
 		for (unsigned r=0; r<10; ++r) {
 			const uint64_t v1 = (uint64_t)c0 * philox_m[0], v2 = (uint64_t)c2 * philox_m[1];
@@ -28,6 +30,11 @@ MLB_API void rng_philox_randn(RngPhilox* S, unsigned n, float* out)
 		const double v = ((double)c1 + 0.5) * two_pow32_inv_2pi;
 		out[i] = sqrt(-2.0 * log(u)) * sin(v);
 	}
+}
+
+MLB_API void rng_philox_randn(RngPhilox* S, unsigned n, float* out)
+{
+	rng_philox_randn_range(S, 0, n, out);
 	S->offset++;
 }
 

@@ -48,55 +48,74 @@ void orc_round_f16(float* x, int64_t n)
 		x[i] = _cvtsh_ss(_cvtss_sh(x[i], _MM_FROUND_TO_NEAREST_INT|_MM_FROUND_NO_EXC));
 }
 
-/* ------------------------------------------------------------------ SGEMM
- * C[M][N] = A[M][K] . B[N][K]^T, fp32, k-ordered accumulation inside KC blocks.
- * BLIS-style: pack B panels (NR=16 wide), pack A panels (MR=6 tall), 6x16 AVX2 micro-kernel.
- */
-#define MR 6
-#define NR 16
-#define KC 384
-#define MC 120   /* multiple of MR */
-#define NC 2048  /* multiple of NR */
-
-static void pack_B(int64_t kc, int64_t nc, const float* B, int64_t ldb, float* Bp)
-{	/* B is [N][K]; panel j holds kc x NR with layout [k][NR] */
-	for (int64_t j=0; j<nc; j+=NR) {
-		int64_t nr = nc-j < NR ? nc-j : NR;
-		for (int64_t k=0; k<kc; ++k) {
-			for (int64_t jj=0; jj<nr; ++jj) Bp[k*NR+jj] = B[(j+jj)*ldb + k];
-			for (int64_t jj=nr; jj<NR; ++jj) Bp[k*NR+jj] = 0;
-		}
-		Bp += kc*NR;
-	}
-}
-
-static void pack_A(int64_t kc, int64_t mc, const float* A, int64_t lda, float* Ap)
-{	/* A is [M][K]; panel i holds kc x MR with layout [k][MR] */
-	for (int64_t i=0; i<mc; i+=MR) {
-		int64_t mr = mc-i < MR ? mc-i : MR;
-		for (int64_t k=0; k<kc; ++k) {
-			for (int64_t ii=0; ii<mr; ++ii) Ap[k*MR+ii] = A[(i+ii)*lda + k];
-			for (int64_t ii=mr; ii<MR; ++ii) Ap[k*MR+ii] = 0;
-		}
-		Ap += kc*MR;
-	}
-}
-
-static inline void ukernel_6x16(int64_t kc, const float* Ap, const float* Bp,
-	float* C, int64_t ldc, int mr, int nr, int accumulate)
+/* dst = src rounded through binary16 (one parallel pass: a fresh destination's pages are first touched by all threads) */
+void orc_round_f16_copy(float* dst, const float* src, int64_t n)
 {
-	__m256 c[MR][2];
-	for (int i=0;i<MR;++i) { c[i][0]=_mm256_setzero_ps(); c[i][1]=_mm256_setzero_ps(); }
+	#pragma omp parallel for schedule(static) if (n > 65536)
+	for (int64_t i=0; i<n-7; i+=8)
+		_mm256_storeu_ps(dst+i, _mm256_cvtph_ps(_mm256_cvtps_ph(_mm256_loadu_ps(src+i), _MM_FROUND_TO_NEAREST_INT|_MM_FROUND_NO_EXC)));
+	for (int64_t i=n&~(int64_t)7; i<n; ++i)
+		dst[i] = _cvtsh_ss(_cvtss_sh(src[i], _MM_FROUND_TO_NEAREST_INT|_MM_FROUND_NO_EXC));
+}
+
+/* ------------------------------------------------------------------ SGEMM
+ * C[M][N] = A[M][K] . B[N][K]^T, fp32.  Every element is accumulated by FMAs in k order inside K chunks of KC, the chunks are added to C in order: the result does
+ * not depend on the tile sizes, the thread count or the vector width -- the AVX2 (6 x 16) and AVX-512 (12 x 32, chosen at run time where the CPU has it)
+ * micro-kernels are bit-identical (tests/test_oracle_ops.py).
+ * Round 5 (the CPU baseline ran this at 183 GFLOP/s on 64 threads): per K chunk, A and B are packed ONCE by all threads into shared panel
+ * buffers ([k][MR] / [k][NR], 8 x 8 in-register transposes for the K-contiguous sources), then all threads walk the (row block x column block) tiles of C; two
+ * barriers per chunk instead of one per (column block, chunk), no per-tile re-packing.
+ */
+#define KC 384
+#define MR2 6
+#define NR2 16
+#define MR5 12
+#define NR5 32
+
+static int g_isa = -1;      /* -1: choose at first use; 2 = AVX2 micro-kernel, 5 = AVX-512 */
+void orc_set_isa(int isa) { g_isa = (isa == 5 && __builtin_cpu_supports("avx512f")) ? 5 : (isa == 2 ? 2 : -1); }
+int orc_get_isa(void)
+{
+	if (g_isa < 0) g_isa = __builtin_cpu_supports("avx512f") ? 5 : 2;
+	return g_isa;
+}
+
+/* rows [r0, r0 + w) of S ([rows][ld], K-contiguous), columns [0, kc) -> panel [k][R] (rows beyond w: zeros) */
+static void pack_panel(int64_t kc, int w, int R, const float* S, int64_t ld, float* P)
+{
+	int64_t k = 0;
+	for (; k + 8 <= kc; k += 8) {
+		for (int r0 = 0; r0 < R; r0 += 8) {
+			__m256 v[8];
+			for (int i=0;i<8;++i) v[i] = r0 + i < w ? _mm256_loadu_ps(S + (int64_t)(r0 + i)*ld + k) : _mm256_setzero_ps();
+			__m256 t0 = _mm256_unpacklo_ps(v[0], v[1]), t1 = _mm256_unpackhi_ps(v[0], v[1]), t2 = _mm256_unpacklo_ps(v[2], v[3]), t3 = _mm256_unpackhi_ps(v[2], v[3]);
+			__m256 t4 = _mm256_unpacklo_ps(v[4], v[5]), t5 = _mm256_unpackhi_ps(v[4], v[5]), t6 = _mm256_unpacklo_ps(v[6], v[7]), t7 = _mm256_unpackhi_ps(v[6], v[7]);
+			__m256 u0 = _mm256_shuffle_ps(t0, t2, 0x44), u1 = _mm256_shuffle_ps(t0, t2, 0xEE), u2 = _mm256_shuffle_ps(t1, t3, 0x44), u3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+			__m256 u4 = _mm256_shuffle_ps(t4, t6, 0x44), u5 = _mm256_shuffle_ps(t4, t6, 0xEE), u6 = _mm256_shuffle_ps(t5, t7, 0x44), u7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+			__m256 o[8] = { _mm256_permute2f128_ps(u0, u4, 0x20), _mm256_permute2f128_ps(u1, u5, 0x20), _mm256_permute2f128_ps(u2, u6, 0x20), _mm256_permute2f128_ps(u3, u7, 0x20),
+			                _mm256_permute2f128_ps(u0, u4, 0x31), _mm256_permute2f128_ps(u1, u5, 0x31), _mm256_permute2f128_ps(u2, u6, 0x31), _mm256_permute2f128_ps(u3, u7, 0x31) };
+			const int n = R - r0 < 8 ? R - r0 : 8;
+			if (n == 8) for (int kk=0;kk<8;++kk) _mm256_storeu_ps(P + (k + kk)*R + r0, o[kk]);
+			else { float tmp[8]; for (int kk=0;kk<8;++kk) { _mm256_storeu_ps(tmp, o[kk]); for (int i=0;i<n;++i) P[(k + kk)*R + r0 + i] = tmp[i]; } }
+		}
+	}
+	for (; k < kc; ++k) for (int r=0;r<R;++r) P[k*R + r] = r < w ? S[(int64_t)r*ld + k] : 0.f;
+}
+
+static inline void ukernel_6x16(int64_t kc, const float* Ap, const float* Bp, float* C, int64_t ldc, int mr, int nr, int accumulate)
+{
+	__m256 c[MR2][2];
+	for (int i=0;i<MR2;++i) { c[i][0]=_mm256_setzero_ps(); c[i][1]=_mm256_setzero_ps(); }
 	for (int64_t k=0; k<kc; ++k) {
-		__m256 b0 = _mm256_loadu_ps(Bp + k*NR), b1 = _mm256_loadu_ps(Bp + k*NR + 8);
-		for (int i=0;i<MR;++i) {
-			__m256 a = _mm256_broadcast_ss(Ap + k*MR + i);
+		__m256 b0 = _mm256_loadu_ps(Bp + k*NR2), b1 = _mm256_loadu_ps(Bp + k*NR2 + 8);
+		for (int i=0;i<MR2;++i) {
+			__m256 a = _mm256_broadcast_ss(Ap + k*MR2 + i);
 			c[i][0] = _mm256_fmadd_ps(a, b0, c[i][0]);
 			c[i][1] = _mm256_fmadd_ps(a, b1, c[i][1]);
 		}
 	}
-	if (mr == MR && nr == NR) {
-		for (int i=0;i<MR;++i) {
+	if (mr == MR2 && nr == NR2) {
+		for (int i=0;i<MR2;++i) {
 			float *cp = C + i*ldc;
 			if (accumulate) {
 				_mm256_storeu_ps(cp,   _mm256_add_ps(_mm256_loadu_ps(cp),   c[i][0]));
@@ -106,60 +125,106 @@ static inline void ukernel_6x16(int64_t kc, const float* Ap, const float* Bp,
 			}
 		}
 	} else {
-		float tmp[MR][NR];
-		for (int i=0;i<MR;++i) { _mm256_storeu_ps(tmp[i], c[i][0]); _mm256_storeu_ps(tmp[i]+8, c[i][1]); }
+		float tmp[MR2][NR2];
+		for (int i=0;i<MR2;++i) { _mm256_storeu_ps(tmp[i], c[i][0]); _mm256_storeu_ps(tmp[i]+8, c[i][1]); }
 		for (int i=0;i<mr;++i) for (int j=0;j<nr;++j) {
 			if (accumulate) C[i*ldc+j] += tmp[i][j]; else C[i*ldc+j] = tmp[i][j];
 		}
 	}
 }
 
-void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,
-	const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc)
+__attribute__((target("avx512f")))
+static void ukernel_12x32(int64_t kc, const float* Ap, const float* Bp, float* C, int64_t ldc, int mr, int nr, int accumulate)
+{
+	__m512 c[MR5][2];
+	for (int i=0;i<MR5;++i) { c[i][0]=_mm512_setzero_ps(); c[i][1]=_mm512_setzero_ps(); }
+	for (int64_t k=0; k<kc; ++k) {
+		const __m512 b0 = _mm512_loadu_ps(Bp + k*NR5), b1 = _mm512_loadu_ps(Bp + k*NR5 + 16);
+		for (int i=0;i<MR5;++i) {
+			const __m512 a = _mm512_set1_ps(Ap[k*MR5 + i]);
+			c[i][0] = _mm512_fmadd_ps(a, b0, c[i][0]);
+			c[i][1] = _mm512_fmadd_ps(a, b1, c[i][1]);
+		}
+	}
+	const __mmask16 m0 = nr >= 16 ? 0xFFFF : (__mmask16)((1u << nr) - 1), m1 = nr >= 32 ? 0xFFFF : (nr > 16 ? (__mmask16)((1u << (nr - 16)) - 1) : 0);
+	for (int i=0;i<mr;++i) {
+		float *cp = C + i*ldc;
+		if (accumulate) {
+			_mm512_mask_storeu_ps(cp,      m0, _mm512_add_ps(_mm512_maskz_loadu_ps(m0, cp),      c[i][0]));
+			_mm512_mask_storeu_ps(cp + 16, m1, _mm512_add_ps(_mm512_maskz_loadu_ps(m1, cp + 16), c[i][1]));
+		} else {
+			_mm512_mask_storeu_ps(cp, m0, c[i][0]); _mm512_mask_storeu_ps(cp + 16, m1, c[i][1]);
+		}
+	}
+}
+
+/* B operand given by a callback (implicit im2col, o_ops.c): fill panel P[k][R] with columns j0 .. j0 + w - 1 (zero-padded to R) for k in [k0, k0 + kc) */
+typedef void (*orc_bpack_fn)(void* ctx, int64_t j0, int w, int64_t k0, int64_t kc, int R, float* P);
+
+static void sgemm_core(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, orc_bpack_fn bpack, void* bctx, float* C, int64_t ldc)
 {
 	if (M<=0 || N<=0) return;
 	if (K<=0) { for (int64_t i=0;i<M;++i) memset(C+i*ldc, 0, (size_t)N*sizeof(float)); return; }
-	int nth = orc_get_threads();
-	float *Bp = NULL;
-	if (posix_memalign((void**)&Bp, 64, (size_t)KC*NC*sizeof(float))) return;
-	for (int64_t jc=0; jc<N; jc+=NC) {
-		int64_t nc = N-jc < NC ? N-jc : NC;
-		for (int64_t pc=0; pc<K; pc+=KC) {
-			int64_t kc = K-pc < KC ? K-pc : KC;
-			/* pack B (parallel over panels) */
-			int64_t npan = (nc+NR-1)/NR;
-			#pragma omp parallel for schedule(static) num_threads(nth)
-			for (int64_t jp=0; jp<npan; ++jp) {
-				int64_t j = jp*NR, w = nc-j < NR ? nc-j : NR;
-				pack_B(kc, w, B + (jc+j)*ldb + pc, ldb, Bp + jp*kc*NR);
+	const int nth = orc_get_threads();
+	const int isa = orc_get_isa();
+	const int MR = isa == 5 ? MR5 : MR2, NR = isa == 5 ? NR5 : NR2;
+	/* columns in chunks of NC (the packed B chunk, NC x KC floats, stays near the cores; a convolution's N is its pixel count: 10^6 at 1024 x 1024) */
+	const int64_t NC = nth > 64 ? 16384 : 8192;
+	const int64_t npm = (M + MR - 1) / MR, ncmax = N < NC ? N : NC, npn_max = (ncmax + NR - 1) / NR;
+	float *Ap = NULL, *Bp = NULL;
+	if (posix_memalign((void**)&Ap, 64, (size_t)npm*MR*KC*sizeof(float)) || posix_memalign((void**)&Bp, 64, (size_t)npn_max*NR*KC*sizeof(float))) { free(Ap); return; }
+	/* tiles of C inside a chunk: TM row panels x TN column panels, sized so that a tile's A panels (TM MR KC floats) stay in L2 and there are >= 4 tiles per thread */
+	int64_t TM = 96 / MR, TN = 512 / NR;
+	while (TN > 2 && ((npm + TM - 1) / TM) * ((npn_max + TN - 1) / TN) < 4 * (int64_t)nth) TN /= 2;
+	while (TM > 2 && ((npm + TM - 1) / TM) * ((npn_max + TN - 1) / TN) < 4 * (int64_t)nth) TM /= 2;
+	const int64_t ntm = (npm + TM - 1) / TM;
+	#pragma omp parallel num_threads(nth)
+	for (int64_t pc=0; pc<K; pc+=KC) {
+		const int64_t kc = K-pc < KC ? K-pc : KC;
+		#pragma omp for schedule(static)
+		for (int64_t ip=0; ip<npm; ++ip) {
+			const int64_t i = ip*MR; const int w = (int)(M-i < MR ? M-i : MR);
+			pack_panel(kc, w, MR, A + i*lda + pc, lda, Ap + ip*kc*MR);
+		}
+		for (int64_t jc=0; jc<N; jc+=NC) {
+			const int64_t nc = N-jc < NC ? N-jc : NC, npn = (nc + NR - 1) / NR, ntn = (npn + TN - 1) / TN;
+			#pragma omp for schedule(static)
+			for (int64_t jp=0; jp<npn; ++jp) {
+				const int64_t j = jc + jp*NR; const int w = (int)(N-j < NR ? N-j : NR);
+				if (bpack) bpack(bctx, j, w, pc, kc, NR, Bp + jp*kc*NR);
+				else pack_panel(kc, w, NR, B + j*ldb + pc, ldb, Bp + jp*kc*NR);
 			}
-			/* 2-D tile parallelism (row blocks x column chunks): convs have few output channels (M) but many
-			 * pixels (N), linears the opposite; each tile packs its own A block (<1 % overhead) */
-			const int64_t nblk = (M+MC-1)/MC, JB = 256, njb = (nc+JB-1)/JB;
-			#pragma omp parallel num_threads(nth)
-			{
-				float *Ap = NULL;
-				if (posix_memalign((void**)&Ap, 64, (size_t)KC*MC*sizeof(float))) Ap = NULL;
-				#pragma omp for schedule(dynamic,1) collapse(2)
-				for (int64_t ib=0; ib<nblk; ++ib)
-				for (int64_t jb=0; jb<njb; ++jb) {
-					int64_t ic = ib*MC, mc = M-ic < MC ? M-ic : MC;
-					int64_t j0 = jb*JB, j1 = j0+JB < nc ? j0+JB : nc;
-					pack_A(kc, mc, A + ic*lda + pc, lda, Ap);
-					for (int64_t jr=j0; jr<j1; jr+=NR) {
-						int nr = (int)(nc-jr < NR ? nc-jr : NR);
-						for (int64_t ir=0; ir<mc; ir+=MR) {
-							int mr = (int)(mc-ir < MR ? mc-ir : MR);
-							ukernel_6x16(kc, Ap + (ir/MR)*kc*MR, Bp + (jr/NR)*kc*NR,
-								C + (ic+ir)*ldc + jc+jr, ldc, mr, nr, pc>0);
-						}
+			/* (implicit barrier: every panel of this chunk is packed) */
+			#pragma omp for schedule(dynamic,1) collapse(2)
+			for (int64_t tm=0; tm<ntm; ++tm)
+			for (int64_t tn=0; tn<ntn; ++tn) {
+				const int64_t ip1 = (tm+1)*TM < npm ? (tm+1)*TM : npm, jp1 = (tn+1)*TN < npn ? (tn+1)*TN : npn;
+				for (int64_t jp=tn*TN; jp<jp1; ++jp) {
+					const int64_t j = jc + jp*NR;
+					const int nr = (int)(N - j < NR ? N - j : NR);
+					for (int64_t ip=tm*TM; ip<ip1; ++ip) {
+						const int mr = (int)(M - ip*MR < MR ? M - ip*MR : MR);
+						if (isa == 5) ukernel_12x32(kc, Ap + ip*kc*MR, Bp + jp*kc*NR, C + ip*MR*ldc + j, ldc, mr, nr, pc>0);
+						else ukernel_6x16(kc, Ap + ip*kc*MR, Bp + jp*kc*NR, C + ip*MR*ldc + j, ldc, mr, nr, pc>0);
 					}
 				}
-				free(Ap);
 			}
+			/* (implicit barrier: the B chunk buffer is free again) */
 		}
 	}
-	free(Bp);
+	free(Ap); free(Bp);
+}
+
+void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,
+	const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc)
+{
+	sgemm_core(M, N, K, A, lda, B, ldb, NULL, NULL, C, ldc);
+}
+
+/* C[M][N] = A[M][K] . Bgen[N][K]^T with the rows of Bgen produced panel by panel by `bpack` (never materialised) */
+void orc_sgemm_nt_gen(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, orc_bpack_fn bpack, void* bctx, float* C, int64_t ldc)
+{
+	sgemm_core(M, N, K, A, lda, NULL, 0, bpack, bctx, C, ldc);
 }
 
 /* ------------------------------------------------------------------ synthetic weights

@@ -54,6 +54,10 @@ ORACLE_API void orc_set_threads(int n);
 ORACLE_API void orc_set_act_rounding(int on);
 ORACLE_API void orc_set_trace(void (*cb)(const char* path, const struct OT* t));
 ORACLE_API int  orc_get_threads(void);
+/* SGEMM micro-kernel: 2 = AVX2 6x16, 5 = AVX-512 12x32 (only where the CPU has it), anything else = choose at first use; both give the same bits */
+ORACLE_API void orc_set_isa(int isa);
+ORACLE_API int  orc_get_isa(void);
+ORACLE_API void orc_prof_dump(int reset);      /* diagnostics: wall-clock seconds per op family since the last reset, to stderr */
 
 /* C[M][N] = sum_k A[M][K] * B[N][K]   (ggml_mul_mat semantics: both K-contiguous) */
 ORACLE_API void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,

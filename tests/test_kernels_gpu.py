@@ -912,6 +912,69 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         kernels.gemm(a2)
 
 
+@pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (32768, 640, 640, 1), (1024, 320, 2560, 0)])
+def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
+    """Tile variant 30 (gemm_tt.hip, round 5): 128x160 tiles on 4-wave blocks, two resident per CU, so that one tile's residual read / output burst runs under the other
+    tile's K loop; chosen by the plan where the 128x320 ping-pong tiles would fill at most half of the CUs (SDXL batch 1 / 2, SD1.5).  Every epilogue it has -- fp16,
+    fp32, fp32 + residual, and the latter two ending with the LayerNorm of the rows (N / 160 partner tiles exchange their row statistics in the launch) -- against
+    orc_linear (src/mlblock_nn.c:16-28) and, bit for bit, against the ping-pong tile (same MFMA order along K); LayerNorm rows against the separate launch; repeatable."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_ln_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    b = (rng.standard_normal(N) * 2).astype(np.float32)
+    R = (rng.standard_normal((M, N)) * 3 + 1.5).astype(np.float32)
+    dA, dW, dB, dR = dev(_lib, A), dev(_lib, W), dev(_lib, b), dev(_lib, R)
+    dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
+    dY0, dY1, dH = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
+    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 128 * 8)
+    cnt = dev(_lib, np.zeros(8192, np.uint32))
+
+    def mk(variant, dst, ln=False, f16=False):
+        a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, tile_variant=variant + 1)
+        if f16: a.C16, a.ldc16 = dst.ptr, N
+        else: a.C32, a.ldc32 = dst.ptr, N
+        if res and not f16: a.resid, a.ldr = dR.ptr, N
+        if ln: a.ln_y16, a.ldln, a.ln_gamma, a.ln_beta, a.ln_eps, a.ln_ws, a.ln_cnt = dY1.ptr, N, dG.ptr, dBt.ptr, 1e-5, ws.ptr, cnt.ptr
+        return a
+    assert "128x160x64tt" in kernels.gemm_variant(mk(30, dC1))
+    # fp32 (+ residual): the oracle on a sample of rows, the general tile bit for bit
+    kernels.gemm(mk(0, dC0)); kernels.gemm(mk(30, dC1))
+    c_ref, c = dC0.download((M, N), np.float32), dC1.download((M, N), np.float32)
+    rows = np.unique(np.concatenate([np.arange(min(M, 130)), rng.integers(0, M, 64), [M - 1]]))
+    P = O.Params()
+    lin = O.from_ot(O.L().orc_linear(O.to_ot(A[rows].astype(np.float32).reshape(1, 1, len(rows), Kd)), P.set("w", W.astype(np.float32), f16=True), P.set("b", b))).reshape(len(rows), N)
+    assert rel(c[rows], lin + (R[rows] if res else 0)) < 2e-5          # fp32 outputs (header)
+    assert rel(c, c_ref) < 1e-6
+    # fp16 output
+    kernels.gemm(mk(30, dH, f16=True))
+    h = dH.download((M, N), np.float16).astype(np.float32)
+    assert rel(h[rows], lin) < 1e-3                                   # fp16 outputs
+    # the launch that ends with the LayerNorm
+    a_ln = mk(30, dC1, ln=True)
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(a_ln)) == 1
+    kernels.layernorm(dC1.ptr, N, M, N, 1e-5, dG.ptr, dBt.ptr, dY0.ptr)
+    y_ref = dY0.download((M, N), np.float16).astype(np.float32)
+    c_bits = dC1.download((M, N), np.uint32)
+    first = None
+    for rep in range(3):
+        _lib.check(L.mlsd_memset(_lib.vp(dC1.ptr), 0xff, ctypes.c_size_t(M * N * 4), None))
+        _lib.check(L.mlsd_memset(_lib.vp(dY1.ptr), 0xff, ctypes.c_size_t(M * N * 2), None))
+        kernels.gemm(a_ln)
+        assert np.array_equal(dC1.download((M, N), np.uint32), c_bits), rep
+        raw = dY1.download((M, N), np.uint16)
+        y = raw.view(np.float16).astype(np.float32)
+        assert np.isfinite(y).all(), rep
+        assert np.abs(y - y_ref).max() <= 2.0 ** -9 * np.maximum(1.0, np.abs(y_ref)).max(), rep      # one fp16 digit
+        assert rel(y, y_ref) < 2e-4, rep
+        if first is None: first = raw
+        assert np.array_equal(raw, first), rep
+        assert not cnt.download((8192,), np.uint32).any(), rep
+
+
 @pytest.mark.parametrize("M,N,Kd,ksplit,variant,res,conv", [(512, 1280, 1280, 3, 2, 1, 0), (512, 1280, 5120, 6, 2, 1, 0), (128, 1280, 1280, 10, 2, 1, 0), (2048, 640, 2560, 6, 1, 1, 0),
                                                             (512, 1280, 1280, 3, 2, 0, 1), (154, 768, 3072, 4, 2, 1, 0), (100, 264, 1096, 5, 2, 0, 0)])
 def test_split_k_reduce_pass_that_ends_with_the_layernorm(K, M, N, Kd, ksplit, variant, res, conv):

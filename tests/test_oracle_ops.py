@@ -29,6 +29,31 @@ def test_sgemm_nt_matches_numpy():
         assert rel(C, A.astype(np.float64) @ B.astype(np.float64).T) < 2e-6, (M, N, K)
 
 
+def test_sgemm_micro_kernels_give_the_same_bits():
+    """AVX2 6x16 and AVX-512 12x32 micro-kernels (run-time choice, oracle/o_core.c): every element is FMA-accumulated in k order inside the same K chunks, so
+    the vector width, the tile sizes and the thread count do not change a bit.  Ragged shapes, K across chunk borders, strided C."""
+    L = O.L()
+    rng = np.random.default_rng(3)
+    L.orc_set_isa(5)
+    if L.orc_get_isa() != 5:
+        pytest.skip("no AVX-512 on this CPU")
+    try:
+        for M, N, K in [(1, 1, 1), (13, 33, 385), (130, 70, 777), (257, 300, 1153), (6, 2049, 64), (640, 31, 2880)]:
+            A = rng.standard_normal((M, K)).astype(np.float32); B = rng.standard_normal((N, K)).astype(np.float32)
+            out = {}
+            for isa, th in ((2, 0), (5, 0), (5, 1), (2, 3)):
+                L.orc_set_isa(isa)
+                if th:
+                    L.orc_set_threads(th)
+                C = np.full((M, N + 5), np.float32(7.0)); L.orc_sgemm_nt(M, N, K, O.fptr(A), K, O.fptr(B), K, O.fptr(C), N + 5)
+                assert np.all(C[:, N:] == 7.0)
+                out[(isa, th)] = C[:, :N].copy()
+            ref = out[(2, 0)]
+            assert all(np.array_equal(ref, v) for v in out.values()), (M, N, K)
+    finally:
+        L.orc_set_isa(-1); L.orc_set_threads(0)
+
+
 def test_round_f16_is_rne():
     x = np.array([1.0, 1.0 + 2**-11, 1.0 + 3 * 2**-11, 65504.0, 1e-8, -2.5, 0.1, 70000.0], np.float32)
     y = x.copy()

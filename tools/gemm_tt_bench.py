@@ -1,0 +1,69 @@
+"""Two tiles in flight per CU (tile variant 30, gemm_tt.hip) against the 128x320 ping-pong tile (variant 18) on the single-round outputs of the SDXL transformer
+blocks: fp32 + residual, with and without the LayerNorm at the end of the launch; WARM (one operand set, back to back) and COLD (NSET operand sets in rotation:
+residual, output and activations come from HBM, as in the plan).  Checks the results first (bit-identical fp32 output expected: same MFMA order along K).
+usage: python3 tools/gemm_tt_bench.py [nset]"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, ".")
+from mlimgsynth_amd import _lib, kernels
+L = _lib.lib(); vp = _lib.vp
+NSET = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+ev = [vp(), vp()]
+for e in ev: L.mlsd_event_create(ctypes.byref(e))
+rng = np.random.default_rng(0)
+
+def timeit(fns, reps=24):
+    n = len(fns)
+    for i in range(n): fns[i]()
+    L.mlsd_event_record(ev[0], None)
+    for i in range(reps): fns[i % n]()
+    L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
+    ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)); return ms.value / reps * 1e3
+
+def layernorm_ref(x, g, b, eps):
+    x = x.astype(np.float64); mu = x.mean(-1, keepdims=True); var = x.var(-1, keepdims=True)
+    return ((x - mu) / np.sqrt(var + eps) * g + b)
+
+for (M, N, Kd) in [(8192, 1280, 1280), (8192, 1280, 5120), (32768, 640, 640), (32768, 640, 2560), (4096, 1280, 1280)]:
+    sets = []
+    W = _lib.from_numpy((rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)); B = _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
+    Gm = _lib.from_numpy((1 + 0.1 * rng.standard_normal(N)).astype(np.float32)); Bt = _lib.from_numpy((0.1 * rng.standard_normal(N)).astype(np.float32))
+    hA = rng.standard_normal((M, Kd)).astype(np.float16); hR = rng.standard_normal((M, N)).astype(np.float32)
+    for s in range(NSET):
+        sets.append(dict(A=_lib.from_numpy(hA), R=_lib.from_numpy(hR), C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
+    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 1024); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    def args(s, variant, ln, res=True):
+        d = sets[s]
+        kw = dict(A=d["A"].ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=d["C"].ptr, ldc32=N, tile_variant=variant + 1)
+        if res: kw.update(resid=d["R"].ptr, ldr=N)
+        if ln: kw.update(ln_y16=d["Y"].ptr, ldln=N, ln_gamma=Gm.ptr, ln_beta=Bt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+        return kernels.GemmArgs(**kw)
+    # ---- results
+    a18, a30 = args(0, 18, True), args(1, 30, True)
+    print(f"{M}x{N}x{Kd}: {kernels.gemm_variant(a18)} | {kernels.gemm_variant(a30)}", flush=True)
+    kernels.gemm(a18); kernels.gemm(a30); kernels.sync()
+    c18 = sets[0]["C"].download((M, N), np.float32); c30 = sets[1]["C"].download((M, N), np.float32)
+    y18 = sets[0]["Y"].download((M, N), np.float16); y30 = sets[1]["Y"].download((M, N), np.float16)
+    ref = hA[:256].astype(np.float32) @ W.download((N, Kd), np.float16).astype(np.float32).T + B.download((N,), np.float32) + hR[:256]
+    e32 = np.linalg.norm(c30[:256] - ref) / np.linalg.norm(ref)
+    yref = layernorm_ref(c30[:256], Gm.download((N,), np.float32), Bt.download((N,), np.float32), 1e-5)
+    ey = np.linalg.norm(y30[:256].astype(np.float64) - yref) / np.linalg.norm(yref)
+    print(f"   fp32 rel-L2 vs numpy {e32:.2e}; bit-identical to the ping-pong tile: {np.array_equal(c18, c30)}; LayerNorm rows rel-L2 vs numpy {ey:.2e}; "
+          f"fp16 rows equal to the ping-pong launch's: {np.mean(y18 == y30) * 100:.3f} % (max |diff| {np.abs(y18.astype(np.float32) - y30.astype(np.float32)).max():.2e})", flush=True)
+    kernels.gemm(a30); kernels.sync()
+    print(f"   bit-repeatable: {np.array_equal(c30, sets[1]['C'].download((M, N), np.float32)) and np.array_equal(y30, sets[1]['Y'].download((M, N), np.float16))}", flush=True)
+    # ---- timing
+    for ln in (False, True):
+        row = []
+        for (name, variant, prio) in (("pp 128x320", 18, 1), ("tt prio", 30, 1), ("tt no prio", 30, 0)):
+            L.mlsd_gemm_tt_set_prio(prio)
+            warm = timeit([lambda a=args(0, variant, ln): kernels.gemm(a)])
+            cold = timeit([(lambda a=args(s, variant, ln): kernels.gemm(a)) for s in range(NSET)])
+            row.append(f"{name}: warm {warm:6.1f} cold {cold:6.1f} us ({2.0 * M * N * Kd / cold / 1e6:5.0f} TFLOP/s)")
+        L.mlsd_gemm_tt_set_prio(1)
+        print(f"   f32+res{'+LN' if ln else '   '}  " + " | ".join(row), flush=True)
+    if ln is True:
+        lnt = timeit([(lambda s=s: kernels.layernorm(sets[s]['C'].ptr, N, M, N, 1e-5, Gm.ptr, Bt.ptr, sets[s]['Y'].ptr)) for s in range(NSET)])
+        print(f"   separate LayerNorm launch (cold): {lnt:.1f} us", flush=True)
+    for d in sets:
+        for k in d: d[k].free() if hasattr(d[k], "free") else None
