@@ -75,6 +75,8 @@ void   mlctx_set_autotune(int on);
 void   mlctx_set_hoist(int on);             /* 0: run the step-invariant ops (cross-attention K/V of the context) in every evaluation, like the reference's graph */
 int    mlctx_once_ops(const MLCtx* C);      /* number of step-invariant ops of the plan */
 int    mlctx_plan_tune_misses(const MLCtx* C);   /* the same count for one prepared plan (tests / bench assert 0 on the benchmark plans) */
+void   mlctx_set_nearest_tile(int on);          /* 0: exact table hits only (A/B against the static rule); default on, MLSD_NO_NEAREST_TILE=1 switches it off */
+int    mlctx_plan_tune_nearest(const MLCtx* C);  /* of those, the shapes a table entry with the NEAREST row count (same N, K, epilogue, geometry; within 4 x) lent its tile to; the rest use the static rule */
 int    mlctx_tune_misses(void);           /* GEMM shapes prepared so far that the table does not list (static choice used) */
 /* IN-PLAN tuning (offline, tools/tune_inplan.py): times every candidate tile of every GEMM shape of a prepared plan where it runs (op by op, whole
  * plan, `reps` passes per candidate round) and switches a shape when a challenger beats the current choice by 3 %; winners go to the process table

@@ -1146,7 +1146,7 @@ int device_cus()
 
 // problems the ping-pong kernels take (gemm_pp.hpp); everything else asked of variants 17 / 18 runs on the LDS-transposing
 // tile of the same shape (9 / 16)
-int g_gemm_korder = 0;     // experiment: slab-ordered K for the ping-pong convolutions (timing only until the weights follow)
+int g_gemm_korder = 0;     // experiment (EXPERIMENTS builds): slab-ordered K for the ping-pong convolutions, timing only -- see mlsd_gemm_set_korder
 bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
     if ((a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
@@ -1535,7 +1535,15 @@ MLSD_API void mlsd_gemm_set_mode(int mode) { mlsd_gemm_set_panel(mode); }
 MLSD_API void mlsd_gemm_force_variant(int v) { g_gemm_variant = v; }
 MLSD_API void mlsd_gemm_set_epilogue(int e) { g_gemm_epi = e; }
 MLSD_API void mlsd_gemm_set_debug(int d) { g_gemm_dbg = d; }
+/* Round-5 experiment (profiles/r5_conv_korder_experiment.txt, tools/conv_korder_bench.py; TIMING ONLY -- the weights keep their (kh, kw, cin) order): the ping-pong convolutions
+ * walk K slab by slab ((cin / 64, kh, kw, 64): the 9 taps of a 64-channel slab in consecutive K tiles) so that an input pixel's slab is re-read within 9 K tiles instead of once per
+ * tap pass over all channels.  Measured 0 .. 4 % on the SDXL conv shapes once the clocks have settled: the long-K conv loops are not bound by that re-fetch (it hits the MALL), so
+ * the weight re-layout + the three kernels' gather changes were not made.  EXPERIMENTS builds only. */
+#ifdef MLSD_GEMM_EXPERIMENTS
 MLSD_API void mlsd_gemm_set_korder(int k) { g_gemm_korder = k; }
+#else
+MLSD_API void mlsd_gemm_set_korder(int k) { (void)k; }
+#endif
 #ifdef MLSD_GEMM_EXPERIMENTS
 MLSD_API void mlsd_gemm_set_splitk_inline(int on) { g_gemm_sk_inline = on != 0; }
 #else

@@ -317,7 +317,8 @@ unsigned long long* g_tt_tbuf = nullptr;      // 0: no priority classes (A/B)
 // problems the tile takes; returns the epilogue kind (TT_*) or 0.  `ncu`: CUs of the stream (partner tiles of a *_LN launch must be resident together)
 extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu)
 {
-    if (a->conv || (a->K & 63) || a->K < 128 || (a->M % 128) || (a->N % 160)) return 0;
+    const bool linear = !a->conv || (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && !a->upsample && a->K == a->Cin);      // (a 1 x 1 convolution of an NHWC image IS a linear layer over its pixels)
+    if (!linear || (a->K & 63) || a->K < 128 || (a->M % 128) || (a->N % 160)) return 0;
     if (a->rowbias || a->bias_m || a->colstats || a->act != MLSD_ACT_NONE || a->ksplit > 1) return 0;
     if (a->bias && ((uintptr_t)a->bias & 15)) return 0;
     if (a->C16 && !a->C32 && !a->resid && !a->ln_y16) return (!(a->ldc16 & 7) && !((uintptr_t)a->C16 & 15)) ? TT_F16 : 0;

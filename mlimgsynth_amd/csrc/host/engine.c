@@ -326,7 +326,7 @@ static void* draw_worker(void* arg)
 }
 static void draw_all(MLIS_AmdCtx* S, float* hn, size_t per)
 {
-	enum { MAXT = 32, MIN_CHUNK = 8192 };
+	enum { MAXT = 16, MIN_CHUNK = 8192 };      /* (a thread per 8192 values at least, 16 at most: creating them costs ~20 us each) */
 	static int ncpu = 0;
 	if (!ncpu) { long n = sysconf(_SC_NPROCESSORS_ONLN); ncpu = n < 1 ? 1 : (n > MAXT ? MAXT : (int)n); }
 	const size_t total = (size_t)S->B * per;

@@ -83,7 +83,7 @@ static void ctx_reset_(MLCtx* C)
 	wstream_free(C);
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
-	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->static_valid = 0; C->n_once = 0;
+	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->n_tune_near = 0; C->static_valid = 0; C->n_once = 0;
 	C->n_ln_fused = 0; C->n_ln_alias = 0; C->n_gn_fused = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->epb, 0, sizeof(C->epb));
@@ -693,6 +693,7 @@ static int autotune_on(void)
 MLB_API void mlctx_set_autotune(int on) { g_autotune = on ? 1 : 0; }
 MLB_API int mlctx_tune_misses(void) { return g_tune_miss; }
 MLB_API int mlctx_plan_tune_misses(const MLCtx* C) { return C ? C->n_tune_miss : 0; }   /* GEMM shapes of THIS plan the table does not list */
+MLB_API int mlctx_plan_tune_nearest(const MLCtx* C) { return C ? C->n_tune_near : 0; }   /* ... of which a table entry with the nearest row count lent its tile (the rest: static rule) */
 
 static TuneKey tune_key(const mlsd_gemm_args* g)
 {
@@ -719,6 +720,34 @@ static int tune_lookup(const TuneKey* k, int* best, int* ksplit)
 	if (ignore_builtin < 0) { const char *e = getenv("MLSD_TUNE_IGNORE_TABLE"); ignore_builtin = (e && *e && *e != '0') ? 1 : 0; }
 	for (const TuneKey *t = k_tune_builtin; !found && !ignore_builtin && t->conv >= 0; ++t)
 		if (tune_eq(t, k)) { *best = t->best; *ksplit = t->ksplit; found = 1; }
+	return found;
+}
+
+/* NEAREST-SHAPE lookup (round 5): the table is keyed on exact shapes, and a size nobody tuned (SDXL 768 x 768, 1024 x 768: every GEMM has another M) fell to the static
+ * rule -- measured 1.9 x the tuned plan's time per FLOP (tests/test_unet_gpu.py::test_unet_sizes_nobody_tuned_parity_and_speed).  The tile that suits a problem depends on
+ * N, K, the epilogue kind and the MAGNITUDE of M: on an exact miss the entry that agrees in everything but the row count (and the image height that goes with it) and whose
+ * M is nearest on a log scale (within 4 x) lends its variant and K split.  Still a pure function of the shape: plans stay deterministic. */
+static int g_nearest_off = -1;
+MLB_API void mlctx_set_nearest_tile(int on) { g_nearest_off = on ? 0 : 1; }      /* A/B: 0 = exact table hits only (misses take the static rule), as before round 5 */
+static int tune_lookup_nearest(const TuneKey* k, int* best, int* ksplit)
+{
+	if (g_nearest_off < 0) { const char *e = getenv("MLSD_NO_NEAREST_TILE"); g_nearest_off = (e && *e && *e != '0') ? 1 : 0; }
+	if (g_nearest_off || k->M <= 0) return 0;
+	double dbest = 1e30; int found = 0;
+	for (int pass=0; pass<2; ++pass) {
+		const TuneKey *t = pass ? k_tune_builtin : g_tune;
+		const int n = pass ? (int)(sizeof(k_tune_builtin) / sizeof(k_tune_builtin[0])) - 1 : g_ntune;
+		if (!pass) pthread_mutex_lock(&g_tune_mu);
+		for (int i=0;i<n;++i) {
+			const TuneKey *q = &t[i];
+			if (q->conv != k->conv || q->N != k->N || q->K != k->K || q->act != k->act || q->stride != k->stride || q->ups != k->ups || q->out != k->out ||
+			    q->Cin != k->Cin || q->KH != k->KH || q->rb != k->rb || q->M <= 0) continue;
+			double d = log((double)q->M / (double)k->M); if (d < 0) d = -d;
+			if (d > 1.3863 /* ln 4 */) continue;
+			if (d < dbest || (d == dbest && q->M > k->M)) { dbest = d; *best = q->best; *ksplit = q->ksplit; found = 1; }
+		}
+		if (!pass) pthread_mutex_unlock(&g_tune_mu);
+	}
 	return found;
 }
 
@@ -770,7 +799,9 @@ static int select_gemm(MLCtx* C, MLOp* op)
 	mlsd_gemm_args *g = &op->u.gemm;
 	const TuneKey k = tune_key(g);
 	int best = 0, ks = 1;
-	if (tune_lookup(&k, &best, &ks)) {
+	int exact = tune_lookup(&k, &best, &ks);
+	if (!exact && tune_lookup_nearest(&k, &best, &ks)) { exact = 2; C->n_tune_near++; }
+	if (exact) {
 		/* a plan on a CU-masked stream (mlctx_set_cus): no in-launch hand-offs -- a stream-K entry runs as the plain tile of its shape */
 		if (IS_STREAMK(best) && C->cu_budget > 0 && C->cu_budget < 256) best = best == VARIANT_STREAMK ? 18 : 19;
 		g->tile_variant = best; g->ksplit = ks;
@@ -786,7 +817,7 @@ static int select_gemm(MLCtx* C, MLOp* op)
 		if (tt_mode > 0 && (best == 19 || best == 21) && !g->conv && g->act == MLSD_ACT_NONE && !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->ksplit <= 1 &&
 		    !g->rowbias && !g->bias_m && (tt_mode == 2 || (tt_mode == 1 && g->K >= 2560) || (tt_mode >= 1 && (long)(g->M / 128) * ((g->N + 319) / 320) <= 128)) &&
 		    !(C->cu_budget > 0 && C->cu_budget < 256)) g->tile_variant = VARIANT_TT;
-		return 1;
+		return exact;
 	}
 	g->tile_variant = 0; g->ksplit = 1;
 	return 0;
@@ -1089,6 +1120,21 @@ static void wire_gn_stats(MLCtx* C)
  * 128x320 ping-pong launch, fp32 (+ residual) epilogue) is handed to that launch -- gamma, beta, eps, the fp16 output buffer, scratch for the row blocks' partial
  * statistics and the plan's ticket counters -- and its own op is skipped (MLOp.fused).  Same producer rule as the GroupNorm statistics: the op that DEFINES the input
  * tensor, still writing exactly this matrix, no writer in between.  MLSD_NO_LN_FOLD=1 keeps the separate launches (A/B timing, reference of the parity test). */
+static int tt_ln_on(void)
+{
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("MLSD_TT_LN"); on = (e && *e == '0') ? 0 : 1; }
+	return on;
+}
+/* producers moved to the 128 x 160 kernel for a LayerNorm that then could not be handed over (alias rule, scratch) go back to the table's tile */
+static void restore_unfolded_promotions(MLCtx* C)
+{
+	for (int i=0;i<C->n_ops;++i) {
+		MLOp *o = &C->ops[i];
+		if (o->kind == OP_GEMM && o->saved_variant) { o->u.gemm.tile_variant = o->saved_variant < 0 ? 0 : o->saved_variant; o->saved_variant = 0; }
+	}
+}
+
 static void wire_ln_fold(MLCtx* C)
 {
 	const char *e = getenv("MLSD_NO_LN_FOLD");
@@ -1109,6 +1155,17 @@ static void wire_ln_fold(MLCtx* C)
 			if (o->kind != OP_GEMM || o->once || g->C32 != l->u.ln.x || g->ldc32 != l->u.ln.ldx || g->N != l->u.ln.d || g->M != l->u.ln.rows || g->ln_y16) continue;
 			/* two forms (mlsd_gemm_ln_fused): inside a single-round launch of the 128x320 ping-pong tile (needs scratch for the row statistics), or -- round 4 -- in the
 			 * reduce pass of a split-K launch (no scratch, no hand-off) */
+			/* Round 5: a producer whose tile cannot end with the LayerNorm (the general tiles of SD1.5's 8192 x 320 / 2048 x 640 projections: 30 of its 48 LayerNorms kept a
+			 * dispatch of their own) moves to the 128 x 160 two-tiles-per-CU kernel when that kernel takes the shape: its N / 160 partner tiles exchange the row statistics.
+			 * Only for N <= 640 (at most 4 partner tiles): in-plan A/B, same box (profiles/r5_gemm_tt_ln_inplan.txt): SD1.5 b1 evaluation -0.8 %, b2 -0.9 % (30 dispatches
+			 * fewer); at N = 1280 (8 partners; SDXL b1 / b2's 2048 x 1280 projections) the same move cost +1.0 / +1.2 % and is not made.
+			 * MLSD_TT_LN=0 keeps the table's tile and the separate LayerNorm. */
+			if (!pass && tt_ln_on() && g->tile_variant != VARIANT_TT && !(g->ksplit > 1) && !(g->tile_variant == 19 && !(g->N % 320)) && g->N <= 640 &&
+			    !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m && !g->colstats && !g->C16 &&
+			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && g->M / 128 <= 256) {
+				o->saved_variant = g->tile_variant ? g->tile_variant : -1;
+				g->tile_variant = VARIANT_TT;
+			}
 			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1);      /* (N / 160 partner tiles per row block) */
 			const int pp_form = tt_form || (!(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
 			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 8 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
@@ -1131,7 +1188,7 @@ static void wire_ln_fold(MLCtx* C)
 				               !((const char*)g->W_ < y1 && y0 < (const char*)g->W_ + rd[2].n))) { C->n_ln_alias++; continue; }
 			}
 			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
-			if (mlsd_gemm_ln_fused(g) >= 1) { l->fused = 1; C->n_ln_fused++; }
+			if (mlsd_gemm_ln_fused(g) >= 1) { l->fused = 1; C->n_ln_fused++; o->saved_variant = 0; }
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
 		if (!pass) {
@@ -1149,6 +1206,7 @@ static void wire_ln_fold(MLCtx* C)
 			}
 		}
 	}
+	restore_unfolded_promotions(C);
 }
 
 static int hoist_on(void);
@@ -1462,7 +1520,7 @@ MLB_API int mlctx_prep(MLCtx* C)
 			if (!op->u.gemm.C32 && !op->u.gemm.C16) return mlctx_fail(C, "op %d (%s): output never consumed", i, op->label);
 			if (op->u.gemm.conv) nconv++;
 			/* tile selection: a pure function of the shape (table), unless the offline timing mode is on */
-			if (!autotune_on()) { int r = select_gemm(C, op); if (r < 0) return -1; if (!r) { C->n_tune_miss++; g_tune_miss++; } }
+			if (!autotune_on()) { int r = select_gemm(C, op); if (r < 0) return -1; if (r != 1) { C->n_tune_miss++; g_tune_miss++; } }     /* (2: a neighbour's tile; 0: the static rule) */
 		}
 		fl += op->flops;
 	}

@@ -21,6 +21,7 @@ typedef struct MLOp {
 	char label[56];
 	int gn_src[2];          /* OP_GN: index of the op that PRODUCES each fp32 source (MLTensor.prod), -1 = not a GEMM/conv output */
 	int fused;              /* OP_LN: the producer's launch ends with this LayerNorm (wire_ln_fold): the op itself does nothing */
+	int saved_variant;      /* OP_GEMM, during wire_ln_fold: the table's tile of a producer that was moved to the 128 x 160 kernel for its LayerNorm (-1: the static rule); 0 = not moved / fold done */
 	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
 	                         * re-runs it only after such an input was written (mlctx_input_set / mlctx_input_device_ptr) */
 	union {
@@ -100,7 +101,7 @@ struct MLCtx {
 	/* batched time-embedding projections of the resnets (they all read silu(emb)): one GEMM, row-bias slices for the convs */
 	struct { MLTensor* emb; char* wbase; float* bbase; float* out32; int n_in, n_total, n_used; } epb;
 	const struct MLTStore* tstore;   /* parameters for mlctx_run_ (mlctx_set_tstore) */
-	int prepared, tuned, n_tune_miss;
+	int prepared, tuned, n_tune_miss, n_tune_near;
 	int static_valid;       /* the outputs of the `once` ops are current (no static_src input was written since they last ran) */
 	int n_once, graph_hoisted;
 	int dry;                /* built in the dry runtime: its memory is host memory whatever the mode at destruction */

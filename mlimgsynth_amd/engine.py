@@ -160,6 +160,12 @@ class MLCtx:
         f.argtypes = [vp]
         return int(f(self.h))
 
+    def tune_nearest(self):
+        """... of which a table entry with the nearest row count lent its tile (mlctx_plan_tune_nearest); the others use the static rule."""
+        f = L().mlctx_plan_tune_nearest
+        f.argtypes = [vp]
+        return int(f(self.h))
+
     def compute(self):
         check1(L().mlctx_compute(self.h), "mlctx_compute")
 

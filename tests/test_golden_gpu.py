@@ -135,6 +135,32 @@ def test_hip_unet_bench_plan_sdxl_batch8_vs_independent_golden(slot):
     assert e < TOL
 
 
+def test_hip_unet_config4_streamed_plan_as_benched_vs_resident_and_golden():
+    """BASELINE configs[4] AS BENCHED: the SDXL batch-8 plan at latent 128 with its weights STREAMED through 512 MiB slabs (bench.py's sdxl_tae_split leg:
+    9 segments, the cut the reference's --unet-split makes per half, src/unet.c:390-458).  Two evaluations in a row (slab reuse, uploads across the evaluation boundary, other
+    inputs): bit-identical to the resident plan's, and the golden input in slot 5 within the parity bound of the independent torch vector."""
+    from mlimgsynth_amd import engine
+    key, model, lat, n, slot = "unet_sdxl_128", "sdxl", 128, 8, 5
+    x1, c1, l1 = G.unet_inputs(key, model, lat, 1)
+    res = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED)
+    st = engine.Unet(model, lat, lat, n, seed=G.WEIGHT_SEED, stream_weights_mib=512)
+    nseg, per_eval, slab, host = st.ctx.streaming_info()
+    print(f"streamed plan: {nseg} segments, {per_eval / 2**20:.0f} MiB per evaluation through {slab / 2**20:.0f} MiB slabs")
+    assert nseg == 9 and slab == 512 << 20 and st.ctx.tune_misses() == 0
+    for rep in range(2):
+        r = np.random.default_rng(3000 + rep)
+        x = (r.standard_normal((n, 4, lat, lat)) * 3).astype(np.float32)
+        cond = r.standard_normal((n, 77, c1.shape[2])).astype(np.float32)
+        label = r.standard_normal((n, l1.shape[1])).astype(np.float32)
+        sig = r.uniform(0.1, 14.0, n).astype(np.float32)
+        x[slot], cond[slot], label[slot], sig[slot] = x1[0], c1[0], l1[0], 3.0
+        a, b = res.run(x, cond, label, sig), st.run(x, cond, label, sig)
+        assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), rep
+        e = rel(b[slot], HEAD[key][0])
+        print(key, "streamed, evaluation", rep, e)
+        assert e < TOL
+
+
 @pytest.mark.parametrize("slot", [0, 1])
 def test_hip_unet_bench_plan_sd15_batch2_hipgraph_vs_independent_golden(slot):
     from mlimgsynth_amd import engine

@@ -258,6 +258,23 @@ def test_progress_callback_and_abort():
     with pytest.raises(_lib.MlsdError):
         g.generate([1])
     assert calls == [(1, 6, 2), (2, 6, 4), (3, 6, 6)]
+    # (1) the abort leaves the Philox state at the draws CONSUMED (the loop generates one step ahead): 1 initial + 3 ancestral draws were added to the latent when
+    # step 3 reported; (2) a callback that aborts with -8 -- the value the loop once used in band for "hand-off timed out, run again" -- aborts, it does not re-run the loop
+    l2 = engine._proto2()
+    l2.mlis_amd_rng_offset.argtypes = [ctypes.c_void_p]; l2.mlis_amd_rng_offset.restype = ctypes.c_uint32
+    l2.mlis_amd_handoff_retries.argtypes = [ctypes.c_void_p]
+    assert l2.mlis_amd_rng_offset(g.h) == 4
+    calls.clear()
+
+    def cb8(user, step, n_step, nfe):
+        calls.append(step)
+        return -8 if step == 2 else 1
+    cbc8 = CB(cb8)
+    l2.mlis_amd_set_callback(g.h, ctypes.cast(cbc8, ctypes.c_void_p), None)
+    with pytest.raises(_lib.MlsdError):
+        g.generate([1])
+    assert calls == [1, 2] and l2.mlis_amd_handoff_retries(g.h) == 0
+    assert l2.mlis_amd_rng_offset(g.h) == 3
 
 
 @pytest.mark.parametrize("model,side", [("tiny", 64), ("sd1", 64)])

@@ -310,6 +310,56 @@ def test_generation_survives_a_timed_out_handoff():
     assert np.array_equal(again, got) and L.mlis_amd_handoff_retries(g.h) == 1
 
 
+@pytest.mark.parametrize("lw,lh", [(112, 112), (144, 112)])
+def test_unet_sizes_nobody_tuned_parity_and_speed(lw, lh):
+    """the tile table is keyed on exact GEMM shapes; SDXL 896 x 896 and 1152 x 896 at batch 1 (cond + uncond: N = 2) are in no tuned set.  Until round 5
+    their GEMMs fell to the static rule (measured at 768 x 768: 1.91 x the tuned 1024 x 1024 plan's time per FLOP); now they take the tile of the table entry with the nearest row
+    count (select_gemm's nearest-shape lookup; at 768 x 768 / 1024 x 768 a full in-plan tuning pass improved on it by 1.1 / 2.2 %, profiles/r5_tune_inplan_768.txt -- those two
+    sizes have since been tuned and merged).  One whole evaluation against the oracle (unet_denoise_run, src/unet.c:460-498) at the full size; the evaluation must beat the
+    static rule's and stay within 1.5 x the FLOP-scaled time of the tuned 1024 x 1024 plan (a smaller problem fills the chip worse whatever the tiles)."""
+    import time
+    from mlimgsynth_amd import engine, _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(lw * 7 + lh)
+    n = 2
+
+    def eval_ms(u):
+        for _ in range(2): u.ctx.compute()
+        u.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5): u.ctx.compute()
+        u.ctx.sync()
+        return (time.perf_counter() - t0) / 5 * 1e3
+    ut = engine.Unet("sdxl", 128, 128, n)
+    ms_t, fl_t, miss_t = eval_ms(ut), ut.ctx.info().flops, ut.ctx.tune_misses()
+    ut.ctx.destroy()
+    L.mlctx_set_nearest_tile(0)
+    try:
+        us = engine.Unet("sdxl", lw, lh, n)
+        ms_s, near_s = eval_ms(us), us.ctx.tune_nearest()
+        us.ctx.destroy()
+    finally:
+        L.mlctx_set_nearest_tile(1)
+    un = engine.Unet("sdxl", lw, lh, n)
+    P = un.P
+    x = rng.standard_normal((n, 4, lh, lw)).astype(np.float32) * 3
+    cond = rng.standard_normal((n, 77, P.n_ctx)).astype(np.float32)
+    label = rng.standard_normal((n, P.ch_adm_in)).astype(np.float32)
+    sigma = np.array([2.5, 9.0], np.float32)
+    got = un.run(x, cond, label, sigma)
+    ms_u, fl_u, miss_u, near_u = eval_ms(un), un.ctx.info().flops, un.ctx.tune_misses(), un.ctx.tune_nearest()
+    ratio = (ms_u / fl_u) / (ms_t / fl_t)
+    OPs = O.Params(1234)
+    ref = O.from_ot(O.L().orc_unet_denoise_run(OPs.h, b"unet", O.unet_params("sdxl"), O.to_ot(x[:1]), O.to_ot(cond[0][None, None]), O.to_ot(label[0][None, None, None]), 2.5))
+    e = rel(got[0], ref[0])
+    print(f"sdxl b1 latent {lw}x{lh}: {miss_u} GEMM shapes outside the tile table ({near_u} served by the nearest row count's entry), rel-L2 vs oracle {e:.2e}; {ms_u:.2f} ms "
+          f"(static rule: {ms_s:.2f} ms) against {ms_t:.2f} ms at 128x128 ({miss_t} misses): time per FLOP untuned / tuned = {ratio:.3f}")
+    assert np.isfinite(got).all() and e < T.EVAL
+    assert miss_t == 0 and near_s == 0 and miss_u > 0 and near_u == miss_u
+    assert ms_u < 0.95 * ms_s, "the nearest-shape lookup no longer beats the static tile rule"      # (measured: -13 % at 896 x 896, -29 % at 768 x 768)
+    assert ratio < 1.5
+
+
 @pytest.mark.parametrize("model,lat,n,mib", [("tinyxl", 8, 2, 1), ("sdxl", 32, 2, 256), ("tinyxl", 8, 2, 8), ("tinyxl", 8, 2, 64)])     # 17, 20, 2 and 1 segment(s) through the 3 slabs
 def test_weight_streaming_is_bit_identical_to_the_resident_plan(model, lat, n, mib):
     """BASELINE configs[4], the reference's --unet-split (src/unet.c:390-458: two half-graphs, weights uploaded per half, every evaluation).  Here the UNet's weights

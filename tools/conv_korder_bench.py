@@ -16,6 +16,8 @@ def timeit(fns):
     for i in range(reps): fns[i % len(fns)]()
     L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
     ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)); return ms.value / reps * 1e3
+if not L.mlsd_has_experiments():
+    sys.exit("needs a library built with `make EXPERIMENTS=1` (mlsd_gemm_set_korder is a no-op in the product build)")
 for (n, h, w, cin, cout, variant) in [(8, 32, 32, 1280, 1280, 20), (8, 32, 32, 2560, 1280, 20), (8, 64, 64, 640, 640, 20), (8, 64, 64, 1920, 640, 20), (8, 128, 128, 320, 320, 18), (8, 128, 128, 640, 320, 20),
                                       (4, 256, 256, 512, 512, 20), (4, 512, 512, 256, 256, 20)]:
     M, N, K = n * h * w, cout, 9 * cin

@@ -25,8 +25,9 @@ def eval_ms(ctx, k=5):
 
 for spec in plans:
     kind, model, lat, n = spec.split(":")
-    lat, n = int(lat), int(n)
-    obj = engine.Unet(model, lat, lat, n) if kind == "unet" else engine.Decoder(model, lat, lat, n, tae=(kind == "tae"))
+    lw, lh = (int(v) for v in lat.split("x")) if "x" in lat else (int(lat), int(lat))      # latent size: 128 or 128x96
+    n = int(n)
+    obj = engine.Unet(model, lw, lh, n) if kind == "unet" else engine.Decoder(model, lw, lh, n, tae=(kind == "tae"))
     ctx = obj.ctx
     t0 = eval_ms(ctx)
     nch = L.mlctx_tune_inplan(ctx.h, 3)
