@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-nfe", type=int, default=2, help="(kept for compatibility: the CPU baseline sample times one sampler step = 2 UNet evaluations)")
-    ap.add_argument("--cpu-decode-budget", type=float, default=60.0, help="seconds the CPU baseline may spend on a full-size VAE decode; above the estimate the decode is priced, and the record says so")
+    ap.add_argument("--cpu-timeout", type=float, default=150.0, help="hard limit (s) of each CPU-baseline child process; what it measured before that is used")
+    ap.add_argument("--cpu-decode-budget", type=float, default=40.0, help="seconds the CPU baseline may spend on a full-size VAE decode; above the estimate the decode is priced, and the record says so")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel time table of one UNet evaluation to this file")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (sd15, sdxl + TAESD) reported beside the headline")
     ap.add_argument("--extra-steps", type=int, default=3)
@@ -213,31 +214,54 @@ def cpu_sample(model, width, height, cfg, denoise_steps, threads, nfe, plist):
     return tu.value / max(n, 1), n
 
 
-def cpu_sample_e2e(model, width, height, cfg, denoise_steps, threads, plist, decode_budget_s=60.0):
-    """BASELINE.md section 3 as a bounded sample: the text towers of one prompt pair, ONE sampler step = 2 batch-1 UNet evaluations (cond + uncond)
-    and ONE full-size VAE decode of the oracle (CPU restatement of the reference path), each timed, composed into seconds per image:
-        s_img = clip + (denoise_steps / 2) * step + decode        (denoise_steps = UNet evaluations per image)
-    The decode is measured, not priced -- unless its estimate (decode FLOPs at the measured UNet rate x 2) exceeds decode_budget_s, which the record then says."""
+def host_threads(cap=64):
+    """OpenMP threads for the CPU baseline: the CPUs this process may really use -- scheduler affinity and cgroup quota, not os.cpu_count() -- capped.  (Round 5, on the GPU
+    box's 2 x 64-core / 256-thread host: the oracle's SGEMM ran at 7.4 TFLOP/s on 64 threads, 1.3 on 128 and 0.06 on 256: threads beyond the cores the box grants spin in
+    OpenMP barriers.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s, decode_flops_1):
+    """CHILD PROCESS of the CPU-baseline leg (python bench.py --cpu-child ...): never touches the GPU (the plan that names the weights is built in the dry runtime).
+    BASELINE.md section 3 as a bounded sample: the text towers of one prompt pair, ONE sampler step = 2 batch-1 UNet evaluations (cond + uncond) and ONE
+    full-size VAE decode of the oracle (CPU restatement of the reference path), each timed and printed as soon as it is known (the parent uses what arrived before its
+    timeout):   s_img = towers + denoise_steps x evaluation + decode."""
     import time
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    from mlimgsynth_amd import _lib, engine
+    _lib.lib().mlsd_runtime_dry(1)
     Lo = O.L()
     Lo.orc_set_threads(threads)
     U = O.unet_params(model)
-    vmodel = "sdxl" if model == "sdxl" else "sd1"
-    V = O.vae_params(vmodel)
+    V = O.vae_params("sdxl" if model == "sdxl" else "sd1")
     OP = O.Params(1234)
     lw, lh = width // 8, height // 8
     rng = np.random.default_rng(7)
-    rec = {}
+    un = engine.Unet(model, lw, lh, 2, synth=False)
+    unet_flops_1 = un.ctx.info().flops / 2
+    plist = un.ctx.param_list()
+    emit = lambda **kw: print("CPU " + json.dumps(kw), flush=True)
+    emit(threads=threads, unet_flops=unet_flops_1, decode_flops=decode_flops_1)
     # ---- weights first (same (seed, name, shape) rule as the engine): the UNet's from the plan's parameter list, the VAE's / towers' by one run at 8 x 8 / as is
     for key, typ, ne in plist:
         OP.get(key, typ == 1, [d for d in ne[::-1]])
-    z_small = rng.standard_normal((1, 4, 8, 8)).astype(np.float32)
-    Lo.ot_free(Lo.orc_vae_decode(OP.h, b"vae", V, O.to_ot(z_small)))
+    Lo.ot_free(Lo.orc_vae_decode(OP.h, b"vae", V, O.to_ot(rng.standard_normal((1, 4, 8, 8)).astype(np.float32))))
     # SD1.5: CLIP-L, last layer + final norm; SDXL: CLIP-L and bigG at clip-skip 2 without the norm, + bigG's pooled feature (src/mlimgsynth.c:1501-1563)
     towers = [("vit_l", b"clip", 2 if model == "sdxl" else 1, model != "sdxl", False)] + ([("vit_bigg", b"clip2", 2, False, False), ("vit_bigg", b"clip2", -1, True, True)] if model == "sdxl" else [])
+
     def run_towers():
         for name, prefix, skip, norm, feat in towers:
             K = O.clip_params(name)
@@ -246,7 +270,8 @@ def cpu_sample_e2e(model, width, height, cfg, denoise_steps, threads, plist, dec
             ptr = full.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
             Lo.ot_free(Lo.orc_clip_text_encode(OP.h, prefix, K, ptr, skip, int(norm), int(feat), 10 if feat else 0))
     run_towers()                                   # (synthesises the towers' weights)
-    t0 = time.perf_counter(); run_towers(); run_towers(); rec["clip_s"] = time.perf_counter() - t0        # prompt + negative prompt
+    t0 = time.perf_counter(); run_towers(); run_towers(); clip_s = time.perf_counter() - t0        # prompt + negative prompt
+    emit(clip_s=clip_s)
     # ---- one sampler step: cond + uncond evaluation
     cond = rng.standard_normal((77, U.n_ctx)).astype(np.float32)
     lab_ = rng.standard_normal(max(U.ch_adm_in, 1)).astype(np.float32)
@@ -256,25 +281,52 @@ def cpu_sample_e2e(model, width, height, cfg, denoise_steps, threads, plist, dec
     n = Lo.orc_generate_latent(OP.h, b"unet", U, lw, lh, ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
                                ot(cond[None, None]), ot(lab_[None, None, None]) if U.ch_adm_in else None,
                                cfg, denoise_steps, 1.0, 42, 2, O.fptr(lat), ctypes.byref(tu))
-    rec["unet_eval_s"] = tu.value / max(n, 1); rec["unet_evals_timed"] = int(n)
-    return rec, OP, V, O
-
-
-def cpu_decode_sample(rec, OP, V, O, width, height, unet_flops_1, decode_flops_1, decode_budget_s):
-    import time
-    import numpy as np
-    est = decode_flops_1 / (unet_flops_1 / rec["unet_eval_s"]) * 2.0
+    unet_eval_s = tu.value / max(n, 1)
+    emit(unet_eval_s=unet_eval_s, unet_evals_timed=int(n))
+    est = decode_flops_1 / (unet_flops_1 / unet_eval_s) * 2.0
     if est > decode_budget_s:
-        rec["decode_s"] = est / 2.0; rec["decode"] = f"priced at the UNet's measured FLOP rate (estimate {est:.0f} s over the {decode_budget_s:.0f} s budget)"
-        return rec
-    z = np.random.default_rng(8).standard_normal((1, 4, height // 8, width // 8)).astype(np.float32)
+        emit(decode_s=est / 2.0, decode=f"priced at the UNet's measured FLOP rate (estimate {est:.0f} s over the {decode_budget_s:.0f} s budget)")
+        return
+    z = rng.standard_normal((1, 4, lh, lw)).astype(np.float32)
     t0 = time.perf_counter()
-    O.L().ot_free(O.L().orc_vae_decode(OP.h, b"vae", V, O.to_ot(z)))
-    rec["decode_s"] = time.perf_counter() - t0; rec["decode"] = "measured"
-    return rec
+    Lo.ot_free(Lo.orc_vae_decode(OP.h, b"vae", V, O.to_ot(z)))
+    emit(decode_s=time.perf_counter() - t0, decode="measured")
+
+
+def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_s, timeout_s, flop_img, decode_flops_1, name):
+    """Runs cpu_child in its own process (its OpenMP settings and a hard timeout never touch the product process) and composes the record from what it printed."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="PASSIVE", OMP_PROC_BIND="false", OMP_DYNAMIC="false")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", model, str(width), str(height), str(cfg), str(denoise_steps), str(threads), str(decode_budget_s), str(decode_flops_1)]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    timed_out = False
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill(); out, err = p.communicate(); timed_out = True
+    rec = {}
+    for line in out.splitlines():
+        if line.startswith("CPU "):
+            rec.update(json.loads(line[4:]))
+    if "unet_eval_s" not in rec:
+        raise RuntimeError(("timed out after %d s" % timeout_s if timed_out else "child failed") + ": " + (err.strip().splitlines()[-1] if err.strip() else "no output"))
+    if "clip_s" not in rec:
+        rec["clip_s"] = 0.0
+    if "decode_s" not in rec:       # the decode did not finish inside the timeout: priced like the UNet
+        rec["decode_s"] = rec["decode_flops"] / (rec["unet_flops"] / rec["unet_eval_s"]); rec["decode"] = f"priced at the UNet's measured FLOP rate (the measurement did not finish in {timeout_s} s)"
+    s_img = rec["clip_s"] + denoise_steps * rec["unet_eval_s"] + rec["decode_s"]
+    return {"value": round(1.0 / s_img, 6), "unit": "images/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "s_per_unet_eval": round(rec["unet_eval_s"], 3), "s_text_towers": round(rec["clip_s"], 3), "s_vae_decode": round(rec["decode_s"], 3),
+            "decode": rec["decode"], "unet_gflops": round(rec["unet_flops"] / rec["unet_eval_s"] / 1e9, 1), "job_gflops": round(flop_img / s_img / 1e9, 1),
+            "sample": f"{name}: text towers of a prompt pair + {rec['unet_evals_timed']} of {denoise_steps} batch-1 UNet evaluations (one sampler step) + one VAE decode "
+                      f"({rec['decode']}); oracle/ = fp32 CPU restatement of the reference path, AVX-512 / AVX2 SGEMM, OpenMP {threads} threads of {os.cpu_count()} host CPUs "
+                      f"(those the box grants, capped at 64); s per image = towers + {denoise_steps} x evaluation + decode"}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-child":
+        m, w, h, cfg, ds, th, bud, dfl = sys.argv[2:10]
+        return cpu_child(m, int(w), int(h), float(cfg), int(ds), int(th), float(bud), float(dfl))
     a = parse()
     import numpy as np
     import torch
@@ -423,31 +475,18 @@ def main():
             except Exception as e:
                 out[key] = {"value": None, "error": str(e)}
 
-    # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded samples of the WHOLE path (towers, sampler step, decode)
+    # ---- CPU baseline (rank 0, N=1 only): the oracle = CPU restatement of the reference path, bounded samples of the WHOLE path (towers, sampler step, decode), each in
+    # a child process with a hard timeout
     if world == 1 and not a.no_cpu_baseline:
-        threads = a.cpu_threads or (os.cpu_count() or 1)
-
-        def cpu_record(model_, w_, h_, plist_, unet_flops_1, decode_flops_1, flop_img, name):
-            rec, OP, V, O = cpu_sample_e2e(model_, w_, h_, a.cfg, a.denoise_steps, threads, plist_)
-            cpu_decode_sample(rec, OP, V, O, w_, h_, unet_flops_1, decode_flops_1, a.cpu_decode_budget)
-            OP.free()
-            s_img = rec["clip_s"] + a.denoise_steps * rec["unet_eval_s"] + rec["decode_s"]
-            return {"value": round(1.0 / s_img, 6), "unit": "images/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-                    "s_per_unet_eval": round(rec["unet_eval_s"], 3), "s_text_towers": round(rec["clip_s"], 3), "s_vae_decode": round(rec["decode_s"], 3),
-                    "decode": rec["decode"], "unet_gflops": round(unet_flops_1 / rec["unet_eval_s"] / 1e9, 1),
-                    "job_gflops": round(flop_img / s_img / 1e9, 1),
-                    "sample": f"{name}: text towers of a prompt pair + {rec['unet_evals_timed']} of {a.denoise_steps} batch-1 UNet evaluations (one sampler step) + one VAE decode "
-                              f"({rec['decode']}); oracle/ = fp32 CPU restatement of the reference path, AVX-512/AVX2 SGEMM, OpenMP {threads} threads; "
-                              f"s per image = towers + {a.denoise_steps} x evaluation + decode"}
+        threads = a.cpu_threads or host_threads()
         try:
-            unet_flops_1 = info["unet_flops"] / (2 * B if a.cfg > 1 else B)
-            out["cpu_baseline"] = cpu_record(model, width, height, plist, unet_flops_1, info["decode_flops"] / B, flop_per_img, f"one {a.workload} {width}x{height} image")
+            out["cpu_baseline"] = cpu_record(model, width, height, a.cfg, a.denoise_steps, threads, a.cpu_decode_budget, a.cpu_timeout, flop_per_img, info["decode_flops"] / B, f"one {a.workload} {width}x{height} image")
         except Exception as e:  # the baseline is a report, never the product path
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         # BASELINE.md section 3 / configs[0] name SD1.5 fp32 512x512 on the CPU: the same sample of that path
         if aux15:
             try:
-                out["cpu_baseline"]["sd15"] = cpu_record("sd1", 512, 512, aux15["plist"], aux15["unet_flops_b1"], aux15["decode_flops_b1"], aux15["flop_per_img"], "one SD1.5 512x512 image")
+                out["cpu_baseline"]["sd15"] = cpu_record("sd1", 512, 512, a.cfg, a.denoise_steps, threads, a.cpu_decode_budget, a.cpu_timeout, aux15["flop_per_img"], aux15["decode_flops_b1"], "one SD1.5 512x512 image")
             except Exception as e:
                 out["cpu_baseline"]["sd15"] = {"value": None, "sample": f"failed: {e}"}
     print(json.dumps(out), flush=True)

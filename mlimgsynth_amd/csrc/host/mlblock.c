@@ -732,7 +732,9 @@ MLB_API void mlctx_set_nearest_tile(int on) { g_nearest_off = on ? 0 : 1; }     
 static int tune_lookup_nearest(const TuneKey* k, int* best, int* ksplit)
 {
 	if (g_nearest_off < 0) { const char *e = getenv("MLSD_NO_NEAREST_TILE"); g_nearest_off = (e && *e && *e != '0') ? 1 : 0; }
-	if (g_nearest_off || k->M <= 0) return 0;
+	/* (M >= 1024: plans whose largest launches are smaller than that -- test-sized latents -- are bound by their dispatch count whatever the tile, and the entries nearest to
+	 * them belong to SD1.5 batch 1's 8 x 8 level, with K splits 20-45 deep) */
+	if (g_nearest_off || k->M < 1024) return 0;
 	double dbest = 1e30; int found = 0;
 	for (int pass=0; pass<2; ++pass) {
 		const TuneKey *t = pass ? k_tune_builtin : g_tune;

@@ -11,12 +11,66 @@
 #include <omp.h>
 
 /* ------------------------------------------------------------------ tensors */
+/* ------------------------------------------------------------------ block cache
+ * Every op output, every rounded operand copy and the SGEMM's panel buffers used to be a fresh posix_memalign / free pair: above glibc's mmap threshold that is an mmap, first-touch
+ * page faults taken by ALL OpenMP threads at once inside the next parallel loop, and an munmap with its TLB shoot-down -- on the GPU box's 2 x 64-core host this, not arithmetic, was
+ * the CPU baseline's time (round 5: the new SGEMM ran at 7.4 TFLOP/s stand-alone on 64 threads and the SD1.5 evaluation still took 4.6 s, 87 % of it inside orc_sgemm_nt calls).
+ * Blocks of >= 256 KB are kept on a small free list and handed out again (best fit within 25 %); the capacity sits in a 64-byte header in front of the data. */
+#include <pthread.h>
+#define OBC_MIN ((size_t)256 << 10)
+#define OBC_SLOTS 96
+#define OBC_MAX_BYTES ((size_t)24 << 30)
+static struct { void* p; size_t cap; } g_obc[OBC_SLOTS];
+static size_t g_obc_bytes = 0;
+static pthread_mutex_t g_obc_mu = PTHREAD_MUTEX_INITIALIZER;
+
+void* orc_balloc(size_t bytes)
+{
+	if (bytes < OBC_MIN) { void *p = NULL; if (posix_memalign(&p, 64, bytes + 64)) return NULL; ((size_t*)p)[0] = 0; return (char*)p + 64; }
+	void *hit = NULL; size_t hcap = 0;
+	pthread_mutex_lock(&g_obc_mu);
+	int best = -1;
+	for (int i=0;i<OBC_SLOTS;++i) if (g_obc[i].p && g_obc[i].cap >= bytes && g_obc[i].cap <= bytes + bytes / 4 && (best < 0 || g_obc[i].cap < g_obc[best].cap)) best = i;
+	if (best >= 0) { hit = g_obc[best].p; hcap = g_obc[best].cap; g_obc[best].p = NULL; g_obc_bytes -= hcap; }
+	pthread_mutex_unlock(&g_obc_mu);
+	if (hit) { ((size_t*)hit)[0] = hcap; return (char*)hit + 64; }
+	void *p = NULL;
+	if (posix_memalign(&p, 64, bytes + 64)) return NULL;
+	((size_t*)p)[0] = bytes;
+	return (char*)p + 64;
+}
+
+void orc_bfree(void* d)
+{
+	if (!d) return;
+	void *p = (char*)d - 64;
+	const size_t cap = ((size_t*)p)[0];
+	if (cap >= OBC_MIN) {
+		pthread_mutex_lock(&g_obc_mu);
+		int slot = -1;
+		if (g_obc_bytes + cap <= OBC_MAX_BYTES) for (int i=0;i<OBC_SLOTS;++i) if (!g_obc[i].p) { slot = i; break; }
+		if (slot >= 0) { g_obc[slot].p = p; g_obc[slot].cap = cap; g_obc_bytes += cap; }
+		pthread_mutex_unlock(&g_obc_mu);
+		if (slot >= 0) return;
+	}
+	free(p);
+}
+
+void orc_bcache_drop(void)      /* returns the cached blocks to the system */
+{
+	pthread_mutex_lock(&g_obc_mu);
+	for (int i=0;i<OBC_SLOTS;++i) if (g_obc[i].p) { free(g_obc[i].p); g_obc[i].p = NULL; }
+	g_obc_bytes = 0;
+	pthread_mutex_unlock(&g_obc_mu);
+}
+
 OT* ot_new(int64_t n0, int64_t n1, int64_t n2, int64_t n3)
 {
 	OT *t = (OT*)calloc(1, sizeof(OT));
 	t->ne[0]=n0; t->ne[1]=n1; t->ne[2]=n2; t->ne[3]=n3;
 	int64_t n = n0*n1*n2*n3;
-	if (posix_memalign((void**)&t->d, 64, (size_t)(n>0?n:1)*sizeof(float))) { free(t); return NULL; }
+	t->d = (float*)orc_balloc((size_t)(n>0?n:1)*sizeof(float));
+	if (!t->d) { free(t); return NULL; }
 	return t;
 }
 
@@ -27,7 +81,7 @@ OT* ot_from(const float* src, int64_t n0, int64_t n1, int64_t n2, int64_t n3)
 	return t;
 }
 
-void ot_free(OT* t) { if (t) { free(t->d); free(t); } }
+void ot_free(OT* t) { if (t) { orc_bfree(t->d); free(t); } }
 
 int64_t ot_nel(const OT* t) { return t->ne[0]*t->ne[1]*t->ne[2]*t->ne[3]; }
 
@@ -171,8 +225,8 @@ static void sgemm_core(int64_t M, int64_t N, int64_t K, const float* A, int64_t 
 	/* columns in chunks of NC (the packed B chunk, NC x KC floats, stays near the cores; a convolution's N is its pixel count: 10^6 at 1024 x 1024) */
 	const int64_t NC = nth > 64 ? 16384 : 8192;
 	const int64_t npm = (M + MR - 1) / MR, ncmax = N < NC ? N : NC, npn_max = (ncmax + NR - 1) / NR;
-	float *Ap = NULL, *Bp = NULL;
-	if (posix_memalign((void**)&Ap, 64, (size_t)npm*MR*KC*sizeof(float)) || posix_memalign((void**)&Bp, 64, (size_t)npn_max*NR*KC*sizeof(float))) { free(Ap); return; }
+	float *Ap = (float*)orc_balloc((size_t)npm*MR*KC*sizeof(float)), *Bp = (float*)orc_balloc((size_t)npn_max*NR*KC*sizeof(float));
+	if (!Ap || !Bp) { orc_bfree(Ap); orc_bfree(Bp); return; }
 	/* tiles of C inside a chunk: TM row panels x TN column panels, sized so that a tile's A panels (TM MR KC floats) stay in L2 and there are >= 4 tiles per thread */
 	int64_t TM = 96 / MR, TN = 512 / NR;
 	while (TN > 2 && ((npm + TM - 1) / TM) * ((npn_max + TN - 1) / TN) < 4 * (int64_t)nth) TN /= 2;
@@ -212,7 +266,7 @@ static void sgemm_core(int64_t M, int64_t N, int64_t K, const float* A, int64_t 
 			/* (implicit barrier: the B chunk buffer is free again) */
 		}
 	}
-	free(Ap); free(Bp);
+	orc_bfree(Ap); orc_bfree(Bp);
 }
 
 void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,

@@ -21,6 +21,8 @@
 /* o_core.c */
 typedef void (*orc_bpack_fn)(void* ctx, int64_t j0, int w, int64_t k0, int64_t kc, int R, float* P);
 void orc_round_f16_copy(float* dst, const float* src, int64_t n);
+void* orc_balloc(size_t bytes);
+void orc_bfree(void* d);
 void orc_sgemm_nt_gen(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, orc_bpack_fn bpack, void* bctx, float* C, int64_t ldc);
 
 /* wall-clock buckets (diagnostics of the CPU baseline: orc_prof_dump) */
@@ -50,14 +52,14 @@ OT* orc_linear(const OT* x, const OParam* w, const OParam* b)
 	float *xr = NULL;
 	PF_T0;
 	if (w->type == ORC_F16 && g_round_act) {
-		xr = (float*)malloc((size_t)n_in*T*sizeof(float));
+		xr = (float*)orc_balloc((size_t)n_in*T*sizeof(float));
 		orc_round_f16_copy(xr, x->d, n_in*T);
 		xs = xr;
 	}
 	PF_ADD(PF_ROUND);
 	orc_sgemm_nt(T, n_out, n_in, xs, n_in, w->d, n_in, y->d, n_out);
 	PF_ADD(PF_SGEMM);
-	free(xr);
+	orc_bfree(xr);
 	if (b) {
 		#pragma omp parallel for schedule(static) if (T*n_out > 65536)
 		for (int64_t t=0; t<T; ++t)
@@ -113,7 +115,7 @@ OT* orc_conv2d(const OT* x, const OParam* w, const OParam* b, int s, int p)
 	PF_T0;
 	float *xr = NULL;
 	if (g_round_act) {
-		xr = (float*)malloc((size_t)N*W*H*Cin*sizeof(float));
+		xr = (float*)orc_balloc((size_t)N*W*H*Cin*sizeof(float));
 		orc_round_f16_copy(xr, x->d, N*W*H*Cin);
 	}
 	PF_ADD(PF_ROUND);
@@ -123,7 +125,7 @@ OT* orc_conv2d(const OT* x, const OParam* w, const OParam* b, int s, int p)
 		orc_sgemm_nt_gen(Cout, M, K, w->d, K, conv_bpack, &cg, y->d + n*M*Cout, M);
 	}
 	PF_ADD(PF_SGEMM);
-	free(xr);
+	orc_bfree(xr);
 	if (b) {
 		#pragma omp parallel for collapse(2) schedule(static) if (N*Cout*M > 65536)
 		for (int64_t n=0; n<N; ++n)
@@ -234,9 +236,9 @@ OT* orc_attention(const OT* q, const OT* k, const OT* v, int n_head, int causal)
 	const int64_t dh = D/n_head;
 	const float scale = 1.0f/sqrtf((float)dh);
 	OT *o = ot_new(D, Tq, 1, 1);
-	float *S = (float*)malloc((size_t)Tq*Tk*sizeof(float));
-	float *vt = (float*)malloc((size_t)dh*Tk*sizeof(float));
-	float *oh = (float*)malloc((size_t)Tq*dh*sizeof(float));
+	float *S = (float*)orc_balloc((size_t)Tq*Tk*sizeof(float));
+	float *vt = (float*)orc_balloc((size_t)dh*Tk*sizeof(float));
+	float *oh = (float*)orc_balloc((size_t)Tq*dh*sizeof(float));
 	PF_T0;
 	for (int h=0; h<n_head; ++h) {
 		/* S[Tq][Tk] = q_h[Tq][dh] . k_h[Tk][dh]^T */
@@ -266,7 +268,7 @@ OT* orc_attention(const OT* q, const OT* k, const OT* v, int n_head, int causal)
 		for (int64_t i=0;i<Tq;++i) memcpy(o->d + i*D + h*dh, oh + i*dh, (size_t)dh*sizeof(float));
 		PF_ADD(PF_ATT_MISC);
 	}
-	free(S); free(vt); free(oh);
+	orc_bfree(S); orc_bfree(vt); orc_bfree(oh);
 	return o;
 }
 

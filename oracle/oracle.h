@@ -57,7 +57,8 @@ ORACLE_API int  orc_get_threads(void);
 /* SGEMM micro-kernel: 2 = AVX2 6x16, 5 = AVX-512 12x32 (only where the CPU has it), anything else = choose at first use; both give the same bits */
 ORACLE_API void orc_set_isa(int isa);
 ORACLE_API int  orc_get_isa(void);
-ORACLE_API void orc_prof_dump(int reset);      /* diagnostics: wall-clock seconds per op family since the last reset, to stderr */
+ORACLE_API void orc_prof_dump(int reset);
+ORACLE_API void orc_bcache_drop(void);         /* the block cache (op outputs / scratch of >= 256 KB are kept for reuse) back to the system */      /* diagnostics: wall-clock seconds per op family since the last reset, to stderr */
 
 /* C[M][N] = sum_k A[M][K] * B[N][K]   (ggml_mul_mat semantics: both K-contiguous) */
 ORACLE_API void orc_sgemm_nt(int64_t M, int64_t N, int64_t K,

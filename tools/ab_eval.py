@@ -18,6 +18,9 @@ def t(ctx, k):
     L.mlsd_event_record(ev[1], st); L.mlsd_event_sync(ev[1])
     ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)); return ms.value / k
 out = []
+if os.environ.get("AB_ONLY") == "sdxl_b8":        # (one rank's share of BASELINE configs[3]: the batch-16 plan)
+    u = engine.Unet("sdxl", 128, 128, 16, stream=st.value); out.append(("sdxl_b8_unet_eval_ms", t(u.ctx, 6))); u.ctx.destroy()
+    print("RESULT " + " ".join(f"{k}={v:.3f}" for k, v in out)); sys.exit(0)
 if os.environ.get("AB_ONLY") == "sdxl_b4":        # (the headline plan alone: a quick A/B of one setting)
     u = engine.Unet("sdxl", 128, 128, 8, stream=st.value); out.append(("sdxl_b4_unet_eval_ms", t(u.ctx, 10))); out.append(("ln_fused", u.ctx.ln_fused() if hasattr(u.ctx, "ln_fused") else -1)); u.ctx.destroy()
     print("RESULT " + " ".join(f"{k}={v:.3f}" for k, v in out)); sys.exit(0)
