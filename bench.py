@@ -236,7 +236,7 @@ def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s
     """CHILD PROCESS of the CPU-baseline leg (python bench.py --cpu-child ...): never touches the GPU (the plan that names the weights is built in the dry runtime).
     BASELINE.md section 3 as a bounded sample: the text towers of one prompt pair, ONE sampler step = 2 batch-1 UNet evaluations (cond + uncond) and ONE
     full-size VAE decode of the oracle (CPU restatement of the reference path), each timed and printed as soon as it is known (the parent uses what arrived before its
-    timeout):   s_img = towers + denoise_steps x evaluation + decode."""
+    timeout):   s_img = towers + (evaluations per image) x evaluation + decode."""
     import time
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -294,6 +294,7 @@ def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s
 
 
 def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_s, timeout_s, flop_img, decode_flops_1, name):
+    nfe = denoise_steps * (2 if cfg > 1 else 1)          # UNet evaluations per image (mlis_denoise_dxdt, src/mlimgsynth.c:1565-1587: cond + uncond)
     """Runs cpu_child in its own process (its OpenMP settings and a hard timeout never touch the product process) and composes the record from what it printed."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="PASSIVE", OMP_PROC_BIND="false", OMP_DYNAMIC="false")
@@ -314,13 +315,13 @@ def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_
         rec["clip_s"] = 0.0
     if "decode_s" not in rec:       # the decode did not finish inside the timeout: priced like the UNet
         rec["decode_s"] = rec["decode_flops"] / (rec["unet_flops"] / rec["unet_eval_s"]); rec["decode"] = f"priced at the UNet's measured FLOP rate (the measurement did not finish in {timeout_s} s)"
-    s_img = rec["clip_s"] + denoise_steps * rec["unet_eval_s"] + rec["decode_s"]
+    s_img = rec["clip_s"] + nfe * rec["unet_eval_s"] + rec["decode_s"]
     return {"value": round(1.0 / s_img, 6), "unit": "images/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "s_per_unet_eval": round(rec["unet_eval_s"], 3), "s_text_towers": round(rec["clip_s"], 3), "s_vae_decode": round(rec["decode_s"], 3),
             "decode": rec["decode"], "unet_gflops": round(rec["unet_flops"] / rec["unet_eval_s"] / 1e9, 1), "job_gflops": round(flop_img / s_img / 1e9, 1),
-            "sample": f"{name}: text towers of a prompt pair + {rec['unet_evals_timed']} of {denoise_steps} batch-1 UNet evaluations (one sampler step) + one VAE decode "
+            "sample": f"{name}: text towers of a prompt pair + {rec['unet_evals_timed']} of {nfe} batch-1 UNet evaluations (one sampler step) + one VAE decode "
                       f"({rec['decode']}); oracle/ = fp32 CPU restatement of the reference path, AVX-512 / AVX2 SGEMM, OpenMP {threads} threads of {os.cpu_count()} host CPUs "
-                      f"(those the box grants, capped at 64); s per image = towers + {denoise_steps} x evaluation + decode"}
+                      f"(those the box grants -- cgroup quota / affinity -- capped at 64); s per image = towers + {nfe} x evaluation + decode"}
 
 
 def main():

@@ -1,4 +1,5 @@
-"""Host-CPU probe for the bench's CPU baseline (oracle SGEMM rate against the OpenMP thread count; the SD1.5 sample's parts).  usage: python3 tools/cpu_probe.py"""
+"""Host-CPU probe for the bench's CPU baseline (oracle SGEMM rate against the OpenMP thread count; the SD1.5 sample's parts).  usage: python3 tools/cpu_probe.py
+Measured on the GPU box (2 x EPYC 9575F, 256 logical CPUs, cgroup quota 16 CPUs; profiles/r5_cpu_probe.txt): 16 threads 2.9 TFLOP/s, 32: 5.1, 64: 7.4 in short bursts."""
 import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ def run(M, N, K, reps=2):
     for _ in range(reps):
         t = time.time(); L.orc_sgemm_nt(M, N, K, O.fptr(A), K, O.fptr(B), K, O.fptr(C), N); best = min(best, time.time() - t)
     return 2.0 * M * N * K / best / 1e9
-for th in (16, 32, 64, 128, 256):
+for th in (8, 16, 32, 64):      # (never more: on the GPU box -- cgroup quota 16 CPUs of 256 -- 128 threads ran at 1.3 TFLOP/s and 256 at 0.06: spinning in barriers; the 256-thread pass alone took 15 minutes)
     if th > (os.cpu_count() or 1): break
     L.orc_set_threads(th)
     print(f"threads {th:3d}: 4096x4096x3840 {run(4096, 4096, 3840):8.1f} GFLOP/s   8192x1280x5120 {run(8192, 1280, 5120):8.1f}   1280x16384x2880 {run(1280, 16384, 2880):8.1f}   320x4096x2880 {run(320, 4096, 2880):8.1f}", flush=True)
@@ -23,7 +24,7 @@ from mlimgsynth_amd import _lib, engine
 _lib.lib().mlsd_runtime_dry(1)
 un = engine.Unet("sd1", 64, 64, 2, synth=False)
 plist = un.ctx.param_list()
-for th in (64, os.cpu_count() or 1):
+for th in (bench.host_threads(), 32):
     t0 = time.time()
     rec, OP, V, Oo = bench.cpu_sample_e2e("sd1", 512, 512, 7.0, 40, th, plist)
     t1 = time.time()
