@@ -199,8 +199,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         s.kt = kenter; s.kh = 0; s.kw = 0; s.cin = 0;
         if constexpr (CONV) {
             if (kenter) {
+#ifdef MLSD_GEMM_EXPERIMENTS      /* slab-ordered K (round-5 experiment, timing only: mlsd_gemm_set_korder) */
                 if (p.korder) { const int kk = p.KH * p.KW, slab = kenter / kk, tap = kenter - slab * kk; s.cin = slab * BK; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
-                else { const int k0 = kenter * BK, tap = k0 / p.Cin; s.cin = k0 - tap * p.Cin; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
+                else
+#endif
+                { const int k0 = kenter * BK, tap = k0 / p.Cin; s.cin = k0 - tap * p.Cin; s.kh = tap / p.KW; s.kw = tap - s.kh * p.KW; }
             }
         }
 #pragma unroll
@@ -254,8 +257,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         }
         s.par ^= 1;
         if constexpr (CONV) {
+#ifdef MLSD_GEMM_EXPERIMENTS
             if (p.korder) { if (++s.kw == p.KW) { s.kw = 0; if (++s.kh == p.KH) { s.kh = 0; s.cin += BK; } } }      // slab order: the taps of this 64-channel slab first
-            else { s.cin += BK; if (s.cin == p.Cin) { s.cin = 0; if (++s.kw == p.KW) { s.kw = 0; ++s.kh; } } }
+            else
+#endif
+            { s.cin += BK; if (s.cin == p.Cin) { s.cin = 0; if (++s.kw == p.KW) { s.kw = 0; ++s.kh; } } }
         }
         if (++s.kt == nkt) enter_A(s, second);
     };
@@ -598,14 +604,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 unsigned spins = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
                 if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // departures: the last of the nbn pollers of this (row block, wave row) clears both counters for the next launch
-                if (lane == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old == (unsigned)(nbn - 1)) {
-                        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
             }
             __builtin_amdgcn_s_barrier();
             // (no acquire fence: 2048 waves invalidating their caches cost 15 us per launch; the partials are read with agent-scope loads instead)
@@ -647,6 +645,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 }
                 if constexpr (NCB & 1)
                     *reinterpret_cast<f16x4*>(p.ln_y + (long)(wrow0 + l15 + row_of(r)) * p.ldln + wcol0 + (NCB - 1) * 16 + 4 * lg) = y4(NCB - 1);
+            }
+            // departures: the last of the nbn pollers of this (row block, wave row) clears both counters for the next launch.  AFTER the rows are on their way (round 5): the
+            // returned ticket is needed for nothing but this reset, and waiting for it in front of the barrier held all 8 waves for an L2 round trip per launch
+            if (wc == 0 && lane == 0) {
+                const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)(nbn - 1)) {
+                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     };

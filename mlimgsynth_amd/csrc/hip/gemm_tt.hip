@@ -261,13 +261,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             unsigned spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
             if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) {
-                const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)(nbn - 1)) {
-                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
         }
         __builtin_amdgcn_s_barrier();
         float mean_r[NI], rstd_r[NI];
@@ -304,6 +297,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 *reinterpret_cast<u32x4*>(rowp + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
             }
             *reinterpret_cast<f16x4*>(p.ln_y + (long)(wrow0 + l15 + i * 16) * p.ldln + wcol0 + (NC - 1) * 16 + 4 * lg) = y4(NC - 1);
+        }
+        // departures (after the rows are on their way: see gemm_pp.hpp): the last poller of this (row block, wave row) clears both counters for the next launch
+        if (wc == 0 && lane == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)(nbn - 1)) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (p.tbuf && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.tbuf[(long)v * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
