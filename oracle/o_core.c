@@ -19,7 +19,7 @@
 #include <pthread.h>
 #define OBC_MIN ((size_t)256 << 10)
 #define OBC_SLOTS 96
-#define OBC_MAX_BYTES ((size_t)24 << 30)
+#define OBC_MAX_BYTES ((size_t)8 << 30)
 static struct { void* p; size_t cap; } g_obc[OBC_SLOTS];
 static size_t g_obc_bytes = 0;
 static pthread_mutex_t g_obc_mu = PTHREAD_MUTEX_INITIALIZER;
