@@ -85,7 +85,7 @@ def kernel_roofline(g, workload, B):
     # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
     traffic, traffic_src, mfma_busy = None, None, None
     for kind in ("traffic", "mfma"):
-        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r4", "r3", "r2", "r1")) if os.path.exists(p_)), "")
+        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r5", "r4", "r3", "r2", "r1")) if os.path.exists(p_)), "")
         if not pmc:
             continue
         try:
