@@ -875,6 +875,9 @@ static int gemm_candidates(MLCtx* C, mlsd_gemm_args* g, int cv[32], int cs[32])
 			const long t320 = (long)((g->M + 127) / 128) * ((g->N + 319) / 320);
 			if (t320 % 256 && t320 < 256 && t320 * (g->K / 64) >= 256 * 4 && !streamk_get(C, g)) { cv[nc]=28; cs[nc++]=1; }
 		}
+		/* two tiles in flight per CU (gemm_tt.hip, round 5): linear / 1x1 problems made of whole 128 x 160 tiles */
+		if (!(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m &&
+		    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && !(g->C32 && g->C16)) { cv[nc]=30; cs[nc++]=1; }
 		/* (the narrow 256x128 ping-pong tile, variant 25, is NOT a candidate: it wins this warm, back-to-back timing on the VAE's N = 128
 		 * convolutions (+9..16 %) and loses in the plan (-16 %, profiles/r3_gemm_narrow_tile.txt): those launches are bound by their fp32
 		 * output + residual traffic, which two co-resident blocks overlap with each other's K loops and one persistent block cannot) */
