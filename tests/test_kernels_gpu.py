@@ -311,6 +311,40 @@ def test_gemm_stream_k_matches_plain_pingpong_tile(K, M, N, Kd, mode):
         assert not fl.download((1024,), np.uint32).any(), rep           # every flag consumed and cleared
 
 
+@pytest.mark.parametrize("M,N,Kd", [(512, 1280, 11520), (2048, 640, 5760), (8192, 320, 2880)])
+def test_gemm_stream_k_128x320_cold_caches_cross_xcd(K, M, N, Kd):
+    """the batched gather of the 128x320 stream-K tile (variant 28) reads its contributors' slabs with agent-scope loads after relaxed flag polls and a barrier (+ a
+    workgroup fence since round 5: program order only).  Stress of exactly that ordering: many launches with the caches thrown away in between (a 600 MB fill: every L2 and the
+    MALL turn over, so the slabs and flags of the next launch start cold; contributors and owners of a tile sit on different XCDs for these shapes), operands rotated, every
+    launch bit-identical to the first of its operand set and within fp32 noise of the plain tile of the same shape; the flags come back cleared."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_streamk_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(M + Kd)
+    nset = 3
+    As = [dev(_lib, rng.standard_normal((M, Kd)).astype(np.float16)) for _ in range(nset)]
+    W = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+    ws = _lib.DeviceBuffer(L.mlsd_gemm_streamk_ws_bytes())
+    fl = dev(_lib, np.zeros(4096, np.uint32))
+    dC = _lib.DeviceBuffer(M * N * 4)
+    trash = _lib.DeviceBuffer(600 << 20)
+    mk = lambda s, v: kernels.GemmArgs(A=As[s].ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=v + 1, ws=ws.ptr, ws_bytes=ws.nbytes, sk_flags=fl.ptr)
+    assert "ppsk" in kernels.gemm_variant(mk(0, 28))
+    first = []
+    for s_ in range(nset):
+        kernels.gemm(mk(s_, 18)); plain = dC.download((M, N), np.float32)
+        kernels.gemm(mk(s_, 28)); got = dC.download((M, N), np.float32)
+        assert rel(got, plain) < 1e-6, s_
+        first.append(got.view(np.uint32).copy())
+    for rep in range(60):
+        s_ = rep % nset
+        _lib.check(L.mlsd_memset(_lib.vp(trash.ptr), rep & 0xff, ctypes.c_size_t(600 << 20), None))
+        _lib.check(L.mlsd_memset(_lib.vp(dC.ptr), 0x7C, ctypes.c_size_t(M * N * 4), None))
+        kernels.gemm(mk(s_, 28))
+        assert np.array_equal(dC.download((M, N), np.uint32), first[s_]), rep
+    assert not fl.download((4096,), np.uint32).any()
+
+
 def test_gemm_stream_k_rows_do_not_depend_on_their_tile(K):
     """The stream-K shares divide a tile's K-tile count, so every output tile is cut at the same K positions: identical rows in different
     tiles (what an image in another batch slot is) come out bit-identical -- with the even share ceil(units / blocks) they did not."""
