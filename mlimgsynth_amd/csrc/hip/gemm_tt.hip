@@ -1,11 +1,15 @@
 // gemm_tt: 128 x 160 x 64 GEMM tile on FOUR waves, TWO blocks resident per CU ("two tiles in flight"; round 5, tile variant 30).
 //
-// Why.  The single-round 8192 x 1280 outputs of the SDXL transformer blocks (out-projections, feed-forward outputs: 19 % of an evaluation) run one 128 x 320 ping-pong
-// tile per CU: every CU loops, then every CU reads its residual tile and bursts its fp32 (+ fp16) output -- 105 MB at once with the matrix pipes idle, after 22 us with
-// HBM idle (profiles/NOTES.md "Where a single-round GEMM spends its time").  Two HALF tiles per CU in flight let one tile's burst run under the other
-// tile's K loop -- if they are out of step.  Two co-resident blocks that start together stay in step, so the blocks come in two PRIORITY CLASSES (s_setprio for the whole
-// kernel): the first half of the grid (one block per CU) gets the issue slots whenever it can use them and finishes its loop early; its residual read / output burst then
-// overlaps the second class's remaining loop.  The tiles of a row block share a class (they exchange LayerNorm statistics and must not wait for a slower partner).
+// Why.  A launch of 128 x 320 ping-pong tiles gives every CU ONE block: all CUs loop, then all CUs read their residual tile and burst their output with the matrix pipes idle
+// (profiles/NOTES.md "Round 5").  Two HALF tiles per CU in flight let one tile's burst run under the other tile's K loop -- if they are out of step.
+// MEASURED (tools/gemm_tt_trace.py, 100 MHz stamps + HW_ID): they are, without help -- the block dispatched first on a CU gets the issue slots (oldest first): on 8192x1280x1280
+// class 0 (blocks 0..255) ends its loop at 19.1 us and exits at 24.6 while class 1 loops until 27.4 and exits at 33.2; an explicit s_setprio for class 0 (kept: mlsd_gemm_tt_set_prio)
+// changes nothing.  What the stagger buys is eaten on the full-chip single-round launches that end with a LayerNorm (the two co-resident loops run at 880 TFLOP/s against 1220 for
+// the ping-pong loop: +0.4 .. +0.7 % in the plan), so the plan uses this kernel where it wins (same-box A/B, profiles/r5_gemm_tt_*.txt, r5_tune_inplan_tt_candidate.txt):
+//   * launches whose 128 x 320 tiles would fill at most half of the CUs (SDXL batch 1 / 2: evaluation -1 .. -3.5 %),
+//   * fp16-output and 1 x 1 launches, chosen by the in-plan tile pass (SDXL b4: the cross-attention q projections 36.2 -> 33.5 us, skip convolutions -10 .. -25 %),
+//   * LayerNorm producers on general tiles with N <= 640 (SD1.5: 30 LayerNorm dispatches gone).
+// The tiles of a row block are consecutive blocks of one XCD and share a class (they exchange LayerNorm statistics and must not wait for a slower partner).
 //
 // Block: 4 waves 2 x 2, wave tile 64 x 80 (the ping-pong kernel's: 80 accumulator registers), one wave per SIMD; the second block of the CU supplies the second wave per SIMD.
 // LDS: two stages of A (128 rows) + two of B (160 rows) x 128 B = 72 KB (+ 2 KB for the *_LN epilogue): two blocks per CU.  The loop is software-pipelined inside the wave
