@@ -224,11 +224,16 @@ def host_threads(cap=64):
     except Exception:
         pass
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
         if q != "max":
             n = min(n, max(1, int(int(q) / int(per))))
     except Exception:
-        pass
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())      # cgroup v1
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
     return max(1, min(n, cap))
 
 
