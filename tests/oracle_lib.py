@@ -51,6 +51,28 @@ class Rng(ctypes.Structure):
 _L = None
 
 
+def host_threads(cap=64):
+    """OpenMP threads for the oracle: the CPUs this process may really use (scheduler affinity, cgroup quota), capped.  The GPU boxes show 256 logical CPUs and grant 16
+    (cpu.max): the oracle's SGEMM ran at 2.9 TFLOP/s on 16 threads, 1.3 on 128 and 0.06 on 256 (profiles/r5_cpu_probe.txt).  Same rule as bench.py's host_threads()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
 def L():
     global _L
     if _L is None:
@@ -58,8 +80,7 @@ def L():
             import subprocess
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         l = ctypes.CDLL(ORACLE_SO)
-        # (the GPU boxes show 256 CPUs shared between pods: OpenMP's default of one thread per CPU oversubscribes them; bench.py's cpu_baseline uses 64 too)
-        l.orc_set_threads(min(os.cpu_count() or 8, 64))
+        l.orc_set_threads(host_threads())          # (never OpenMP's default of one thread per logical CPU: see host_threads)
         OTP = ctypes.POINTER(OT)
         OPP = ctypes.POINTER(OParam)
         l.ot_new.restype = OTP

@@ -51,7 +51,7 @@ def test_sgemm_micro_kernels_give_the_same_bits():
             ref = out[(2, 0)]
             assert all(np.array_equal(ref, v) for v in out.values()), (M, N, K)
     finally:
-        L.orc_set_isa(-1); L.orc_set_threads(0)
+        L.orc_set_isa(-1); L.orc_set_threads(O.host_threads())
 
 
 def test_round_f16_is_rne():

@@ -54,7 +54,7 @@ def test_vae_decode_512_parity():
     by tools/full_size_latent_parity.py)."""
     import os
     from mlimgsynth_amd import engine
-    O.L().orc_set_threads(min(os.cpu_count() or 8, 64))
+    O.L().orc_set_threads(O.host_threads())
     rng = np.random.default_rng(5)
     lat = 32
     z = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 0.5

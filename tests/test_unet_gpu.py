@@ -184,7 +184,7 @@ def test_unet_sdxl_headline_size_parity():
     from mlimgsynth_amd import engine
     rng = np.random.default_rng(11)
     lat = 128
-    O.L().orc_set_threads(min(os.cpu_count() or 8, 64))
+    O.L().orc_set_threads(O.host_threads())
     un = engine.Unet("sdxl", lat, lat, 1)
     P = un.P
     x = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 4
