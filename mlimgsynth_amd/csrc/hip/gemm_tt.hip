@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "mlsd_kernels.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
         constexpr bool NEXT = decltype(NEXT_)::value;
         half(0, std::true_type{}, 1, s, std::false_type{}, 0);
         if constexpr (NEXT) {
+            // WAR on stage s: the k-step-1 fragments read above are consumed AFTER the barrier, and the first thing another wave does behind the barrier is LDS-DMA into
+            // stage s.  Weight K tiles that the CU's other block has just fetched come back from the vector L1 in ~100 clocks -- sooner than a fragment read queued behind two
+            // blocks' LDS traffic: the reads must have RETURNED before this wave lets the others through.  (Found by tests/test_determinism_gpu.py on the SDXL b4 plan: one
+            // generation in a few differed in the last bits; the 2000-launch soak of single shapes did not hit it.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             tt_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -332,9 +338,15 @@ extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu)
         if (a->resid && ((a->ldr & 3) || ((uintptr_t)a->resid & 15))) return 0;
         if (a->ln_y16) {
             if (!a->ln_gamma || !a->ln_beta || !a->ln_ws || !a->ln_cnt || (a->ldln & 7) || ((uintptr_t)a->ln_y16 & 15) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return 0;
-            // the N / 160 tiles of a row block are consecutive blocks of one XCD; blocks are dispatched in order, so the oldest unfinished row block always has (or is
-            // next to get) all of its tiles resident; counters: 16 words per (row block, wave row) in 8192 words
-            if (a->M / 128 > 256 || ncu < 256) return 0;
+            // The N / 160 tiles of a row block exchange their statistics through ONE XCD's L2 (write-through partials, agent-scope loads): they must sit on one XCD, which holds for the
+            // workgroups the dispatcher places up front -- id % 8 is the XCD -- and that is only certain for grids of at most ONE block per CU (what the ping-pong kernels' exchange
+            // runs on).  Round 5's first version took any grid and, on 1024-block grids about once in fifty launches, a tile read a partner's partials of the PREVIOUS launch from a
+            // stale line of its own XCD's L2 -- near-identical statistics, an error in the last bits of one image that no soak on fixed operands could see (the stale values ARE the
+            // fresh ones); tests/test_determinism_gpu.py did.  512-block grids (exactly two per CU) still showed it once in a few hundred launches (tools/soak_r5.py on alternating
+            // operand sets): later blocks go wherever a slot frees up.  Counters: 16 words per (row block, wave row) in 8192 words.
+            static int anygrid = -1;      // MLSD_TT_LN_ANYGRID=1: reproduce the hazard (tools/soak_r5.py anygrid)
+            if (anygrid < 0) { const char* e = getenv("MLSD_TT_LN_ANYGRID"); anygrid = (e && *e == '1') ? 1 : 0; }
+            if (a->M / 128 > 256 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > (long)ncu)) return 0;
             return a->resid ? TT_F32_RES_LN : TT_F32_LN;
         }
         return a->resid ? TT_F32_RES : TT_F32;

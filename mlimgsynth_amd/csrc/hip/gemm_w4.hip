@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const W4P p)
         if (t == 0 && stored) w4_wait_vmcnt<W_MID_ST>();
         else if (t + 2 < nkt) w4_wait_vmcnt<W_MID>();
         else w4_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the k-step-1 fragments of this stage must have returned before the staging behind the barrier may overwrite it: gemm_tt.hip)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         half(1, 0, sa ^ 1, sb1, ISSUE_A_, ISSUE_B_, sa, sb);

@@ -804,6 +804,11 @@ static int select_gemm(MLCtx* C, MLOp* op)
 	int exact = tune_lookup(&k, &best, &ks);
 	if (!exact && tune_lookup_nearest(&k, &best, &ks)) { exact = 2; C->n_tune_near++; }
 	if (exact) {
+		{	/* MLSD_NO_TT=1 (A/B, debugging): table entries of the 128 x 160 kernel run on the 128 x 320 ping-pong tile */
+			static int no_tt = -1;
+			if (no_tt < 0) { const char *e = getenv("MLSD_NO_TT"); no_tt = (e && *e && *e != '0') ? 1 : 0; }
+			if (no_tt && best == VARIANT_TT) best = 19;
+		}
 		/* a plan on a CU-masked stream (mlctx_set_cus): no in-launch hand-offs -- a stream-K entry runs as the plain tile of its shape */
 		if (IS_STREAMK(best) && C->cu_budget > 0 && C->cu_budget < 256) best = best == VARIANT_STREAMK ? 18 : 19;
 		g->tile_variant = best; g->ksplit = ks;
@@ -1167,12 +1172,13 @@ static void wire_ln_fold(MLCtx* C)
 			 * MLSD_TT_LN=0 keeps the table's tile and the separate LayerNorm. */
 			if (!pass && tt_ln_on() && g->tile_variant != VARIANT_TT && !(g->ksplit > 1) && !(g->tile_variant == 19 && !(g->N % 320)) && g->N <= 640 &&
 			    !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m && !g->colstats && !g->C16 &&
-			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && g->M / 128 <= 256) {
+			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && (long)(g->M / 128) * (g->N / 160) <= 256) {
 				o->saved_variant = g->tile_variant ? g->tile_variant : -1;
 				g->tile_variant = VARIANT_TT;
 			}
-			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1);      /* (N / 160 partner tiles per row block) */
-			const int pp_form = tt_form || (!(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
+			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1) &&
+			                    (long)(g->M / 128) * (g->N / 160) <= 256;      /* (N / 160 partner tiles per row block; at most one block per CU: all placed up front, gemm_tt.hip) */
+			const int pp_form = tt_form || (g->tile_variant != VARIANT_TT && !(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
 			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 8 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
 			if (!pass) { if (need > need_max) need_max = need; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }
 			if (need > C->ln_ws_bytes) continue;

@@ -946,7 +946,21 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         kernels.gemm(a2)
 
 
-@pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (32768, 640, 640, 1), (1024, 320, 2560, 0)])
+def test_gemm_two_tiles_per_cu_layernorm_only_on_grids_placed_up_front(K):
+    """The partner tiles of a row block exchange their statistics through ONE XCD's L2: they must be blocks the dispatcher places up front (id % 8 = XCD), i.e. the grid may hold
+    at most ONE block per CU (the ping-pong kernels' condition).  Larger grids must REFUSE the LayerNorm ending: round 5's first version took them and read a partner's stale
+    statistics from another XCD's L2 once in ~50 launches at 1024 blocks, once in a few hundred at 512 (tools/soak_r5.py with MLSD_TT_LN_ANYGRID=1 reproduces it)."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_ln_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    d = _lib.DeviceBuffer(1 << 20)
+    mk = lambda M, N: kernels.GemmArgs(A=d.ptr, lda=640, W_=d.ptr, ldb=640, M=M, N=N, K=640, C32=d.ptr, ldc32=N, tile_variant=31, ln_y16=d.ptr, ldln=N, ln_gamma=d.ptr, ln_beta=d.ptr,
+                                       ln_eps=1e-5, ln_ws=d.ptr, ln_cnt=d.ptr)
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(32768, 640))) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(16384, 640))) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(8192, 1280))) == 0
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(8192, 640))) == 1 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(4096, 1280))) == 1
+
+
+@pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 640, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 320, 640, 1), (1024, 320, 2560, 0)])
 def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
     """Tile variant 30 (gemm_tt.hip, round 5): 128x160 tiles on 4-wave blocks, two resident per CU, so that one tile's residual read / output burst runs under the other
     tile's K loop; chosen by the plan where the 128x320 ping-pong tiles would fill at most half of the CUs (SDXL batch 1 / 2, SD1.5).  Every epilogue it has -- fp16,
@@ -1007,6 +1021,30 @@ def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
         assert not cnt.download((8192,), np.uint32).any(), rep
+
+
+@pytest.mark.parametrize("N,Kd,f16", [(1280, 1280, 1), (640, 640, 1), (1280, 2560, 0), (320, 960, 0)])
+def test_gemm_two_tiles_per_cu_rows_do_not_depend_on_their_tile(K, N, Kd, f16):
+    """An image in another batch slot is the same rows in other tiles: the 128x160 kernel (every tile walks K in the same order, no split) must give identical rows wherever
+    they sit -- also when the grid is several rounds of resident blocks, with launches back to back (tests/test_determinism_gpu.py failed on exactly this in round 5)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(N + Kd)
+    reps, rows = 16, 1024
+    A0 = rng.standard_normal((rows, Kd)).astype(np.float16)
+    A = np.ascontiguousarray(np.tile(A0, (reps, 1)))
+    W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = dev(_lib, A), dev(_lib, W)
+    M = A.shape[0]
+    dC = _lib.DeviceBuffer(M * N * 4)
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, tile_variant=31)
+    if f16: a.C16, a.ldc16 = dC.ptr, N
+    else: a.C32, a.ldc32 = dC.ptr, N
+    assert "128x160x64tt" in kernels.gemm_variant(a)
+    for launch in range(20):
+        kernels.gemm(a)
+        out = dC.download((reps, rows, N), np.uint16 if f16 else np.uint32)
+        for r in range(1, reps):
+            assert np.array_equal(out[r], out[0]), (launch, r)
 
 
 @pytest.mark.parametrize("M,N,Kd,ksplit,variant,res,conv", [(512, 1280, 1280, 3, 2, 1, 0), (512, 1280, 5120, 6, 2, 1, 0), (128, 1280, 1280, 10, 2, 1, 0), (2048, 640, 2560, 6, 1, 1, 0),

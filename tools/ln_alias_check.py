@@ -1,0 +1,33 @@
+"""LayerNorm-ending launches whose fp16 rows land EXACTLY on their A operand (K == N, same base, same stride: the overlap wire_ln_fold accepts), many launches, against the same
+launch with a separate output buffer: ping-pong tile (variant 18) and the 128x160 kernel (variant 30).  usage: python3 tools/ln_alias_check.py [launches]"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, ".")
+from mlimgsynth_amd import _lib, kernels
+L = _lib.lib()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(0)
+for (M, N) in [(8192, 1280), (32768, 640)]:
+    Kd = N
+    A = rng.standard_normal((M, Kd)).astype(np.float16)
+    W = _lib.from_numpy((rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)); B = _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
+    G = _lib.from_numpy((1 + 0.1 * rng.standard_normal(N)).astype(np.float32)); Bt = _lib.from_numpy((0.1 * rng.standard_normal(N)).astype(np.float32))
+    dA = _lib.from_numpy(A); dA0 = _lib.from_numpy(A); dC = _lib.DeviceBuffer(M * N * 4); dY = _lib.DeviceBuffer(M * N * 2)
+    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 1024); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    for variant in (18, 30):
+        def args(y):
+            return kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=dC.ptr, ldc32=N, tile_variant=variant + 1,
+                                    ln_y16=y, ldln=N, ln_gamma=G.ptr, ln_beta=Bt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+        L.mlsd_memcpy(_lib.vp(dA.ptr), _lib.vp(dA0.ptr), ctypes.c_size_t(M * Kd * 2), 2, None)
+        kernels.gemm(args(dY.ptr)); kernels.sync()
+        ref_y = dY.download((M, N), np.uint16); ref_c = dC.download((M, N), np.uint32)
+        bad = 0
+        for r in range(reps):
+            L.mlsd_memcpy(_lib.vp(dA.ptr), _lib.vp(dA0.ptr), ctypes.c_size_t(M * Kd * 2), 2, None)      # the launch overwrites its A operand with the LayerNorm rows
+            kernels.gemm(args(dA.ptr))
+            y = dA.download((M, N), np.uint16); c = dC.download((M, N), np.uint32)
+            if not (np.array_equal(y, ref_y) and np.array_equal(c, ref_c)):
+                bad += 1
+                rows = np.unique(np.nonzero((y != ref_y) | (c != ref_c))[0])
+                print(f"  launch {r}: {len(rows)} rows differ (row blocks {sorted(set((rows // 128).tolist()))[:8]}), fp32 differs: {not np.array_equal(c, ref_c)}", flush=True)
+        print(f"{kernels.gemm_variant(args(dY.ptr))} {M}x{N}x{Kd}: LayerNorm rows written onto the A operand, {reps} launches: {'%d MISMATCHES' % bad if bad else 'all bit-identical to the launch with its own output buffer'}", flush=True)

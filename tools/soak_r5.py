@@ -1,6 +1,6 @@
 """Race soak for the round-5 kernel: the 128x160 two-tiles-per-CU GEMM (tile variant 30) in every form that hands data over inside the launch -- the LayerNorm exchange with
-2 / 4 / 8 partner tiles per row block, single-round and multi-round grids (1024 blocks on 512 slots: partner tiles resident by dispatch order), K = 128 .. 5120 -- many
-launches on fixed operands, fp32 output and fp16 rows bit-identical to the first, counters back at zero; then the plans that use it (SD1.5 batch 1 as a hipGraph, SDXL batch 2
+2 / 4 / 8 partner tiles per row block, grids of up to 256 blocks (one per CU: the blocks the dispatcher places up front), K = 128 .. 5120 -- many launches on TWO alternating
+operand sets that share one scratch block, fp32 output and fp16 rows bit-identical to the set's first launch, counters back at zero; then the plans that use it (SD1.5 batch 1 as a hipGraph, SDXL batch 2
 and batch 1), every evaluation bit-identical to the first and no hand-off retry.
 usage: python3 tools/soak_r5.py [launches_per_case] [evals_per_plan]"""
 import ctypes, os, sys, time
@@ -15,35 +15,52 @@ rng = np.random.default_rng(0)
 bad = 0
 t0 = time.time()
 cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
-for (M, N, K, res) in [(8192, 320, 320, 1), (8192, 320, 1280, 1), (2048, 640, 640, 1), (2048, 640, 2560, 0), (4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 1),
-                       (32768, 640, 640, 1), (128, 160, 128, 0), (16384, 1280, 1280, 1)]:
-    dA = _lib.from_numpy(rng.standard_normal((M, K)).astype(np.float16))
+ws = _lib.DeviceBuffer(512 * 1024)           # ONE scratch block for every case, as in a plan: the partials of the previous launch (other shape, other values) lie where the next one reads
+CASES = [(8192, 320, 320, 1), (8192, 320, 1280, 1), (2048, 640, 640, 1), (2048, 640, 2560, 0), (4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 640, 640, 1),
+         (16384, 320, 640, 1), (128, 160, 128, 0), (8192, 640, 2560, 0)]
+if os.environ.get("MLSD_TT_LN_ANYGRID") == "1":      # the hazard itself: grids of more than one block per CU (partner tiles can end up on different XCDs); expect MISMATCH lines
+    CASES = [(32768, 640, 640, 1), (8192, 1280, 5120, 1), (32768, 640, 2560, 0)]
+    ws = _lib.DeviceBuffer(2 << 20)
+VARIANT, TAG = 31, "128x160x64tt"
+if len(sys.argv) > 3 and sys.argv[3] == "pp":       # the same alternating-operand soak on the ping-pong kernels' exchange (tile variant 18: single-round and whole-round grids)
+    VARIANT, TAG = 19, "128x320x64pp"
+    CASES = [(8192, 1280, 1280, 1), (8192, 1280, 5120, 1), (32768, 640, 640, 1), (32768, 640, 2560, 0), (4096, 1280, 1280, 1), (16384, 1280, 320, 1), (128, 1280, 192, 1)]
+    ws = _lib.DeviceBuffer(2 << 20)
+for (M, N, K, res) in CASES:
+    # TWO operand sets with different values, launched alternately: a tile that read a partner's partials of the PREVIOUS launch would produce other bits than its set's first launch
+    # (with one set the stale values are the fresh ones: the first version of this soak could not see the bug it was written for)
+    bad0 = bad
+    sets = []
+    for k in range(2):
+        sets.append(dict(A=_lib.from_numpy((rng.standard_normal((M, K)) * (1 + k)).astype(np.float16)), R=_lib.from_numpy((rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)),
+                         C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
     dW = _lib.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
-    dR = _lib.from_numpy((rng.standard_normal((M, N)) * 3 + 1).astype(np.float32))
-    dC, dY = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
     dG, dB = _lib.from_numpy((1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
-    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 1024)
-    a = kernels.GemmArgs(A=dA.ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K, C32=dC.ptr, ldc32=N, tile_variant=31,
-                         ln_y16=dY.ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dB.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
-    if res: a.resid, a.ldr = dR.ptr, N
-    name = kernels.gemm_variant(a)
-    assert "128x160x64tt" in name and "layernorm" in name, name
-    kernels.gemm(a)
-    get = lambda: (dC.download((M * N,), np.uint32), dY.download((M * N // 2,), np.uint32))
-    first = get()
+    def mk(d):
+        a = kernels.GemmArgs(A=d["A"].ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K, C32=d["C"].ptr, ldc32=N, tile_variant=VARIANT,
+                             ln_y16=d["Y"].ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dB.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+        if res: a.resid, a.ldr = d["R"].ptr, N
+        return a
+    args = [mk(d) for d in sets]
+    name = kernels.gemm_variant(args[0])
+    assert TAG in name and "layernorm" in name, name
+    get = lambda d: (d["C"].download((M * N,), np.uint32), d["Y"].download((M * N // 2,), np.uint32))
+    first = []
+    for k in range(2):
+        kernels.gemm(args[k]); first.append(get(sets[k]))
     for r in range(reps):
-        kernels.gemm(a)
-        if r % 500 == 499 or r == reps - 1:
-            now = get()
-            if not (np.array_equal(now[0], first[0]) and np.array_equal(now[1], first[1])):
-                bad += 1; print("MISMATCH", name, M, N, K, "at launch", r)
+        kernels.gemm(args[r & 1])
+        if r % 10 >= 8 or r >= reps - 2:
+            now = get(sets[r & 1])
+            if not (np.array_equal(now[0], first[r & 1][0]) and np.array_equal(now[1], first[r & 1][1])):
+                bad += 1; print("MISMATCH", name, M, N, K, "at launch", r, "operand set", r & 1)
     if cnt.download((8192,), np.uint32).any():
         bad += 1; print("COUNTERS LEFT", name, M, N, K)
-    print(f"{name} {M}x{N}x{K} ({N // 160} partner tiles, {(M // 128) * (N // 160)} blocks): {reps} launches ok", flush=True)
+    print(f"{name} {M}x{N}x{K} ({N // (160 if VARIANT == 31 else 320)} partner tiles, {(M // 128) * (N // (160 if VARIANT == 31 else 320))} tiles): {reps} launches on two alternating operand sets, every fifth checked: {'MISMATCHES (above)' if bad > bad0 else 'ok'}", flush=True)
 Lh = engine._proto2()
 Lh.mlctx_handoff_retries.restype = ctypes.c_int
 st = vp(); L.mlsd_stream_create(ctypes.byref(st))        # (a hipGraph plan captures its launches: not on the NULL stream)
-for (model, lat, n, flags, label) in [("sd1", 64, 2, 8, "SD1.5 b1 (hipGraph)"), ("sdxl", 128, 4, 0, "SDXL b2"), ("sdxl", 128, 2, 0, "SDXL b1")]:
+for (model, lat, n, flags, label) in [("sd1", 64, 2, 8, "SD1.5 b1 (hipGraph)"), ("sdxl", 128, 4, 0, "SDXL b2"), ("sdxl", 128, 2, 0, "SDXL b1"), ("sdxl", 128, 8, 0, "SDXL b4")]:
     un = engine.Unet(model, lat, lat, n, flags=flags, stream=st.value)
     ntt = sum(1 for l, _ in un.ctx.op_list() if "128x160x64tt" in l)
     P = un.P
