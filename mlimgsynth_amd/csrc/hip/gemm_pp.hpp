@@ -562,8 +562,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 #pragma unroll
                 for (int r = 0; r < NR; ++r) red[(wr * 64 + row_of(r) + l15) * 4 + wc] = f32x2{mean_w[r], m2_w[r]};
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the ds_writes above have landed before the barrier lets the readers through (gemm_tt.hip: the same
+                                                                             // exchange with two blocks on the CU read a stale pair once in ~100 launches when the wait stood BEHIND the barrier)
             __builtin_amdgcn_s_barrier();                                    // (the groups run their epilogues side by side: an ordinary block barrier)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             auto chan = [&](float& n, float& mu, float& m2, float nb, float mub, float m2b) __attribute__((always_inline)) {
                 const float d = mub - mu, nn = n + nb;
                 mu += d * (nb / nn); m2 += m2b + d * d * (n * nb / nn); n = nn;

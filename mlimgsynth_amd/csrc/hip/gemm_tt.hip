@@ -233,8 +233,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
 #pragma unroll
             for (int i = 0; i < NI; ++i) red[(wr * 64 + i * 16 + l15) * 2 + wc] = f32x2{mean_w[i], m2_w[i]};
         }
-        __builtin_amdgcn_s_barrier();
+        // the ds_writes above must have LANDED before this wave lets the others through (a raw s_barrier waits for nothing): with a second block hammering the CU's LDS port a
+        // reader behind the barrier could overtake them and combine a stale pair -- one (tile, wave row)'s partial wrong, hence the LayerNorm of 64 rows wrong in ALL partner tiles
+        // (round 5, tools/tt_ln_diag.py; it showed once in 30 .. 300 launches on grids of more than one block per CU, never with one)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         auto chan = [&](float& n, float& mu, float& m2, float nb, float mub, float m2b) __attribute__((always_inline)) {
             const float d = mub - mu, nn = n + nb;
             mu += d * (nb / nn); m2 += m2b + d * d * (n * nb / nn); n = nn;
@@ -338,15 +341,13 @@ extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu)
         if (a->resid && ((a->ldr & 3) || ((uintptr_t)a->resid & 15))) return 0;
         if (a->ln_y16) {
             if (!a->ln_gamma || !a->ln_beta || !a->ln_ws || !a->ln_cnt || (a->ldln & 7) || ((uintptr_t)a->ln_y16 & 15) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return 0;
-            // The N / 160 tiles of a row block exchange their statistics through ONE XCD's L2 (write-through partials, agent-scope loads): they must sit on one XCD, which holds for the
-            // workgroups the dispatcher places up front -- id % 8 is the XCD -- and that is only certain for grids of at most ONE block per CU (what the ping-pong kernels' exchange
-            // runs on).  Round 5's first version took any grid and, on 1024-block grids about once in fifty launches, a tile read a partner's partials of the PREVIOUS launch from a
-            // stale line of its own XCD's L2 -- near-identical statistics, an error in the last bits of one image that no soak on fixed operands could see (the stale values ARE the
-            // fresh ones); tests/test_determinism_gpu.py did.  512-block grids (exactly two per CU) still showed it once in a few hundred launches (tools/soak_r5.py on alternating
-            // operand sets): later blocks go wherever a slot frees up.  Counters: 16 words per (row block, wave row) in 8192 words.
-            static int anygrid = -1;      // MLSD_TT_LN_ANYGRID=1: reproduce the hazard (tools/soak_r5.py anygrid)
+            // The N / 160 tiles of a row block wait for each other inside the launch: all of them must be resident together, which a grid of at most 2 blocks per CU guarantees
+            // without any assumption on the dispatch order (larger grids work while blocks are dispatched in id order -- the soak runs them with MLSD_TT_LN_ANYGRID=1 -- but are
+            // not taken).  Partner tiles are blocks 8 apart: one XCD (checked: XCC_ID == id % 8 for every block of 256 .. 1024-block grids, tools/gemm_tt_xcd_check.py), so the
+            // write-through partials and agent-scope loads meet in that XCD's L2.  Counters: 16 words per (row block, wave row) in 8192 words.
+            static int anygrid = -1;      // MLSD_TT_LN_ANYGRID=1: also grids of more than 2 blocks per CU (tools/soak_r5.py)
             if (anygrid < 0) { const char* e = getenv("MLSD_TT_LN_ANYGRID"); anygrid = (e && *e == '1') ? 1 : 0; }
-            if (a->M / 128 > 256 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > (long)ncu)) return 0;
+            if (a->M / 128 > 256 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > 2L * ncu)) return 0;
             return a->resid ? TT_F32_RES_LN : TT_F32_LN;
         }
         return a->resid ? TT_F32_RES : TT_F32;

@@ -1172,12 +1172,12 @@ static void wire_ln_fold(MLCtx* C)
 			 * MLSD_TT_LN=0 keeps the table's tile and the separate LayerNorm. */
 			if (!pass && tt_ln_on() && g->tile_variant != VARIANT_TT && !(g->ksplit > 1) && !(g->tile_variant == 19 && !(g->N % 320)) && g->N <= 640 &&
 			    !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m && !g->colstats && !g->C16 &&
-			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && (long)(g->M / 128) * (g->N / 160) <= 256) {
+			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && (long)(g->M / 128) * (g->N / 160) <= 512) {
 				o->saved_variant = g->tile_variant ? g->tile_variant : -1;
 				g->tile_variant = VARIANT_TT;
 			}
 			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1) &&
-			                    (long)(g->M / 128) * (g->N / 160) <= 256;      /* (N / 160 partner tiles per row block; at most one block per CU: all placed up front, gemm_tt.hip) */
+			                    (long)(g->M / 128) * (g->N / 160) <= 512;      /* (N / 160 partner tiles per row block; at most two blocks per CU: all resident together, gemm_tt.hip) */
 			const int pp_form = tt_form || (g->tile_variant != VARIANT_TT && !(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
 			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 8 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
 			if (!pass) { if (need > need_max) need_max = need; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }

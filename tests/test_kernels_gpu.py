@@ -946,21 +946,52 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         kernels.gemm(a2)
 
 
-def test_gemm_two_tiles_per_cu_layernorm_only_on_grids_placed_up_front(K):
-    """The partner tiles of a row block exchange their statistics through ONE XCD's L2: they must be blocks the dispatcher places up front (id % 8 = XCD), i.e. the grid may hold
-    at most ONE block per CU (the ping-pong kernels' condition).  Larger grids must REFUSE the LayerNorm ending: round 5's first version took them and read a partner's stale
-    statistics from another XCD's L2 once in ~50 launches at 1024 blocks, once in a few hundred at 512 (tools/soak_r5.py with MLSD_TT_LN_ANYGRID=1 reproduces it)."""
+def test_gemm_two_tiles_per_cu_layernorm_only_on_grids_resident_together(K):
+    """The partner tiles of a row block wait for each other inside the launch: the LayerNorm ending is taken by grids of at most 2 blocks per CU (all resident together whatever the
+    dispatch order) and refused beyond."""
     kernels, _lib = K
     L = _lib.lib()
     L.mlsd_gemm_ln_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
     d = _lib.DeviceBuffer(1 << 20)
     mk = lambda M, N: kernels.GemmArgs(A=d.ptr, lda=640, W_=d.ptr, ldb=640, M=M, N=N, K=640, C32=d.ptr, ldc32=N, tile_variant=31, ln_y16=d.ptr, ldln=N, ln_gamma=d.ptr, ln_beta=d.ptr,
                                        ln_eps=1e-5, ln_ws=d.ptr, ln_cnt=d.ptr)
-    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(32768, 640))) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(16384, 640))) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(8192, 1280))) == 0
-    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(8192, 640))) == 1 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(4096, 1280))) == 1
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(32768, 640))) == 0 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(16384, 1280))) == 0
+    assert L.mlsd_gemm_ln_fused(ctypes.byref(mk(16384, 640))) == 1 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(8192, 1280))) == 1 and L.mlsd_gemm_ln_fused(ctypes.byref(mk(4096, 1280))) == 1
 
 
-@pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 640, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 320, 640, 1), (1024, 320, 2560, 0)])
+@pytest.mark.parametrize("alt", [0])
+def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
+    """Round 5's lesson: a hand-off screened on FIXED operands cannot show stale data (the previous launch's values are the fresh ones).  Both LayerNorm-ending kernels (ping-pong
+    128x320, two-blocks-per-CU 128x160 at 1 and 2 blocks per CU) on TWO operand sets launched alternately over one scratch block and one counter block: every launch bit-identical
+    to its set's first.  (The bug this would have caught: the block-internal exchange of the wave columns' statistics through LDS had its s_waitcnt lgkmcnt(0) BEHIND the raw
+    s_barrier; with a second block loading the CU's LDS port a reader overtook the ds_write once in 30 .. 300 launches and 64 rows of ALL partner tiles were normalised with a
+    stale pair -- tests/test_determinism_gpu.py saw it as one image in a few generations differing in the last bits.)"""
+    kernels, _lib = K
+    rng = np.random.default_rng(5)
+    ws = _lib.DeviceBuffer(2 << 20); cnt = dev(_lib, np.zeros(8192, np.uint32))
+    for (variant, M, N, Kd) in [(30, 8192, 1280, 2560), (30, 16384, 640, 640), (30, 4096, 1280, 1280), (18, 8192, 1280, 1280), (18, 32768, 640, 640)]:
+        sets = []
+        for k in range(2):
+            sets.append(dict(A=dev(_lib, (rng.standard_normal((M, Kd)) * (1 + k)).astype(np.float16)), R=dev(_lib, (rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)),
+                             C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
+        dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+        dG, dB = dev(_lib, (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+        args = [kernels.GemmArgs(A=d["A"].ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=d["C"].ptr, ldc32=N, resid=d["R"].ptr, ldr=N, tile_variant=variant + 1,
+                                 ln_y16=d["Y"].ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dB.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr) for d in sets]
+        assert "layernorm" in kernels.gemm_variant(args[0])
+        first = []
+        for k in range(2):
+            kernels.gemm(args[k]); first.append((sets[k]["C"].download((M * N,), np.uint32), sets[k]["Y"].download((M * N // 2,), np.uint32)))
+        for r in range(400):
+            kernels.gemm(args[r & 1])
+            if r % 4 >= 2:
+                assert np.array_equal(sets[r & 1]["Y"].download((M * N // 2,), np.uint32), first[r & 1][1]), (variant, M, N, Kd, r)
+        for k in range(2):
+            assert np.array_equal(sets[k]["C"].download((M * N,), np.uint32), first[k][0])
+    assert not cnt.download((8192,), np.uint32).any()
+
+
+@pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 640, 640, 1), (1024, 320, 2560, 0)])
 def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
     """Tile variant 30 (gemm_tt.hip, round 5): 128x160 tiles on 4-wave blocks, two resident per CU, so that one tile's residual read / output burst runs under the other
     tile's K loop; chosen by the plan where the 128x320 ping-pong tiles would fill at most half of the CUs (SDXL batch 1 / 2, SD1.5).  Every epilogue it has -- fp16,

@@ -1,0 +1,38 @@
+"""Diagnosis of the 128x160 kernel's LayerNorm ending on grids of more than one block per CU (MLSD_TT_LN_ANYGRID=1): in a failing launch, what differs -- the fp32 output, the fp16
+rows, which row blocks / tile columns, and by how much?"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, ".")
+from mlimgsynth_amd import _lib, kernels
+L = _lib.lib()
+rng = np.random.default_rng(0)
+M, N, K = 8192, 1280, 5120
+sets = []
+for k in range(2):
+    sets.append(dict(A=_lib.from_numpy((rng.standard_normal((M, K)) * (1 + k)).astype(np.float16)), R=_lib.from_numpy((rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)),
+                     C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
+dW = _lib.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
+dG, dB = _lib.from_numpy((1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
+ws = _lib.DeviceBuffer(2 << 20); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+prio = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+L.mlsd_gemm_tt_set_prio(prio)
+def mk(d):
+    return kernels.GemmArgs(A=d["A"].ptr, lda=K, W_=dW.ptr, ldb=K, M=M, N=N, K=K, C32=d["C"].ptr, ldc32=N, resid=d["R"].ptr, ldr=N, tile_variant=31,
+                            ln_y16=d["Y"].ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dB.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+args = [mk(d) for d in sets]
+first = []
+for k in range(2):
+    kernels.gemm(args[k]); first.append((sets[k]["C"].download((M, N), np.uint32), sets[k]["Y"].download((M, N), np.float16)))
+nbad = 0
+for r in range(1500):
+    k = r & 1
+    kernels.gemm(args[k])
+    c = sets[k]["C"].download((M, N), np.uint32); y = sets[k]["Y"].download((M, N), np.float16)
+    dc = c != first[k][0]; dy = y != first[k][1]
+    if dc.any() or dy.any():
+        nbad += 1
+        rows = np.unique(np.nonzero(dy)[0]); cols = np.unique(np.nonzero(dy)[1])
+        print(f"launch {r} set {k}: fp32 differs in {int(dc.sum())} values; fp16 rows differ in {int(dy.sum())} values: row blocks {sorted(set((rows // 128).tolist()))}, rows-in-block {sorted(set((rows % 128).tolist()))[:10]}.., "
+              f"tile columns {sorted(set((cols // 160).tolist()))}, max |diff| {np.abs(y.astype(np.float32) - first[k][1].astype(np.float32)).max():.3e}, sticky {cnt.download((8192,), np.uint32)[8191]}", flush=True)
+        if nbad >= 6: break
+print("prio", prio, "bad launches:", nbad)
