@@ -96,6 +96,12 @@ static const OParam* par(Ctx* C, const char* name, int type, int64_t n0, int64_t
 	return p;
 }
 
+/* Linear weight type of every model built from here on: the reference takes it from the checkpoint unless WEIGHT_TYPE is set (src/mlimgsynth.c:1235-1236, default F16 :473).
+ * ORC_F32 = an fp32 checkpoint (BASELINE configs[0]): ggml's mul_mat then multiplies fp32 weights with fp32 activations, nothing is rounded to F16 (orc_linear). */
+static int g_linear_wtype = ORC_F16;
+ORACLE_API void orc_set_linear_wtype(int type) { g_linear_wtype = type == ORC_F32 ? ORC_F32 : ORC_F16; }
+ORACLE_API int orc_get_linear_wtype(void) { return g_linear_wtype; }
+
 /* ------------------------------------------------------------------ NN blocks (src/mlblock_nn.c) */
 static OT* nn_linear(Ctx* C, const char* name, const OT* x, int n_out, int bias)
 {	/* :16-28 */
@@ -275,7 +281,7 @@ static OT* spatial_transf(Ctx* C, const char* name, const OT* x0, const OT* ctx,
 OT* orc_unet_graph(OParams* P, const char* prefix, const OrcUnetParams* U,
 	const OT* x_in, float time, const OT* ctx, const OT* label)
 {
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	push(C, prefix);
 	char name[64];
@@ -377,7 +383,7 @@ static OT* attn_2d_self(Ctx* C, const char* name, const OT* x0)
 
 OT* orc_vae_decode(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* latent)
 {
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	push(C, prefix);
 	char name[64];
@@ -417,7 +423,7 @@ OT* orc_vae_decode(OParams* P, const char* prefix, const OrcVaeParams* V, const 
  * (mean | logvar) after quant_conv; no sampling (orc_latent_sample) */
 OT* orc_vae_encode_moments(OParams* P, const char* prefix, const OrcVaeParams* V, const OT* img)
 {
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	push(C, prefix);
 	char name[64];
@@ -543,7 +549,7 @@ static OT* tae_block(Ctx* C, int idx, const OT* x0, int ch_out);
 OT* orc_tae_encode(OParams* P, const char* prefix, const OT* img)
 {	/* mlb_sdtae_encoder :43-63 (the image is used as given: sdtae_encode applies no pre-scaling, :96-115) */
 	const int ch_inner=64, ch_z=4, n_blk=3;
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	push(C, prefix); push(C, "encoder.layers");
 	char name[16];
@@ -579,7 +585,7 @@ static OT* tae_block(Ctx* C, int idx, const OT* x0, int ch_out)
 OT* orc_tae_decode(OParams* P, const char* prefix, const OT* latent)
 {	/* mlb_sdtae_decoder :65-92; params g_sdtae_sd1 :17-22 */
 	const int ch_inner=64, ch_x=3, n_blk=3;
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	push(C, prefix); push(C, "decoder.layers");
 	char name[16];
@@ -605,7 +611,7 @@ OT* orc_tae_decode(OParams* P, const char* prefix, const OT* latent)
 OT* orc_clip_text_encode(OParams* P, const char* prefix, const OrcClipParams* K,
 	const int32_t* tokens, int clip_skip, int norm, int want_feat, int i_tok_end)
 {
-	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = ORC_F16;
+	Ctx Cs; memset(&Cs, 0, sizeof(Cs)); Cs.P = P; Cs.wtype = g_linear_wtype;
 	Ctx *C = &Cs;
 	if (want_feat) { clip_skip = -1; norm = 1; }   /* clip.c:446 */
 	push(C, prefix); push(C, "text");
