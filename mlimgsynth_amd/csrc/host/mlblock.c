@@ -176,6 +176,7 @@ MLB_API int mlctx_handoffs_off(MLCtx* C)
 			g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL;
 			if (i + 1 < C->n_ops && C->ops[i+1].kind == OP_LN && C->ops[i+1].fused) { C->ops[i+1].fused = 0; C->n_ln_fused--; }
 			++n;
+			if (o->folded_from) { g->tile_variant = o->folded_from < 0 ? 0 : o->folded_from; o->folded_from = 0; }      /* moved to the 128 x 160 kernel only for this LayerNorm: back to its own tile */
 		}
 		if ((IS_STREAMK(g->tile_variant) || g->ksplit > 1) && g->sk_flags) { g->sk_flags = NULL; ++n; }     /* (split-K: back to the two-launch form) */
 	}
@@ -1199,7 +1200,7 @@ static void wire_ln_fold(MLCtx* C)
 				               !((const char*)g->W_ < y1 && y0 < (const char*)g->W_ + rd[2].n))) { C->n_ln_alias++; continue; }
 			}
 			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
-			if (mlsd_gemm_ln_fused(g) >= 1) { l->fused = 1; C->n_ln_fused++; o->saved_variant = 0; }
+			if (mlsd_gemm_ln_fused(g) >= 1) { l->fused = 1; C->n_ln_fused++; o->folded_from = o->saved_variant; o->saved_variant = 0; }
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
 		if (!pass) {

@@ -22,6 +22,7 @@ typedef struct MLOp {
 	int gn_src[2];          /* OP_GN: index of the op that PRODUCES each fp32 source (MLTensor.prod), -1 = not a GEMM/conv output */
 	int fused;              /* OP_LN: the producer's launch ends with this LayerNorm (wire_ln_fold): the op itself does nothing */
 	int saved_variant;      /* OP_GEMM, during wire_ln_fold: the table's tile of a producer that was moved to the 128 x 160 kernel for its LayerNorm (-1: the static rule); 0 = not moved / fold done */
+	int folded_from;        /* OP_GEMM: the tile such a producer had before it was moved AND its LayerNorm was handed over: mlctx_handoffs_off returns it there (-1: the static rule; 0: not moved) */
 	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
 	                         * re-runs it only after such an input was written (mlctx_input_set / mlctx_input_device_ptr) */
 	union {
