@@ -1147,10 +1147,15 @@ int device_cus()
 // problems the ping-pong kernels take (gemm_pp.hpp); everything else asked of variants 17 / 18 runs on the LDS-transposing
 // tile of the same shape (9 / 16)
 int g_gemm_korder = 0;     // experiment (EXPERIMENTS builds): slab-ordered K for the ping-pong convolutions, timing only -- see mlsd_gemm_set_korder
+int pp_epilogue_kind(const mlsd_gemm_args* a, int BN);
 bool pp_eligible(const mlsd_gemm_args* a, int BM, int BN)
 {
     if ((a->K & 63) || a->K < 192 || (a->M % (BM / 2)) || (a->N % (BN / 4))) return false;
-    if (a->conv && (a->upsample || (a->Cin & 63) || a->KH * a->KW > 9)) return false;   // a K tile must lie inside one filter tap
+    if (a->conv && ((a->Cin & 63) || a->KH * a->KW > 9)) return false;   // a K tile must lie inside one filter tap
+    if (a->conv && a->upsample) {       // nearest-2x upsampled source (round 5): stride 1, and the two epilogues the upsampling convolutions of the UNets / decoders use
+        const int e = pp_epilogue_kind(a, BN);
+        if (a->stride != 1 || a->pad > 16 || a->H > 16000 || a->W > 16000 || (e != 2 /* PP_EPI_F32 */ && e != 5 /* PP_EPI_F32_STATS */)) return false;
+    }
     if (a->rowbias && ((a->rows_per_batch > 0 ? a->rows_per_batch : 1) % BM)) return false;
     if (a->act == MLSD_ACT_GEGLU && BN != 256) return false;
     const int nout = a->act == MLSD_ACT_GEGLU ? a->N / 2 : a->N;
@@ -1205,7 +1210,7 @@ int sk_share(long ntiles, int nkt, int ncu)
 
 bool sk_eligible(const mlsd_gemm_args* a, int BM, int BN, bool ignore_stats = false)
 {
-    if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15) || device_cus() < g_gemm_ncu) return false;
+    if (!pp_eligible(a, BM, BN) || !a->ws || !a->sk_flags || ((uintptr_t)a->ws & 15) || device_cus() < g_gemm_ncu || (a->conv && a->upsample)) return false;
     if (a->conv && a->colstats && !ignore_stats) return false;      // (the conv builds with the statistics epilogue do not fit the register budget beside the hand-off code)
     const long tiles = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN), nkt = a->K / 64;
     const long L = sk_share(tiles, (int)nkt, g_gemm_ncu);
@@ -1266,6 +1271,11 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         case PP_EPI_F32_RES: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_F32_RES, true>);
         default: return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, true>);
         }
+    }
+    if (a->conv && a->upsample) {       // (pp_eligible admits these two epilogues only)
+        if (epi == PP_EPI_F32_STATS) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, 2, PP_EPI_F32_STATS, false, NPH, SCH>);
+        if (epi == PP_EPI_F32) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, 2, PP_EPI_F32, false, NPH, SCH>);
+        return mlsd_set_error(-1, "mlsd_gemm: ping-pong tile: upsampled convolution with epilogue %d", epi);
     }
     if (a->conv) {
         switch (epi) {

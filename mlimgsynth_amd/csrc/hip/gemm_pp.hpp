@@ -126,7 +126,7 @@ enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, P
 //   counted waits (what may stay in flight):   P4: NU1+NU2+NU3+NU4 (retires U1, U2 of the next tile)    P1: NU1+NU2+NU4 (retires U4, U3 of this tile)
 //   RAW: P1 reads U1/U2 retired in the previous P4; P2 reads U3 retired in P1; P3 reads U4, older than U3, retired with it.  WAR: every
 //   unit is restaged >= 3 phases after the phase that read its rows.
-template <int BM, int BN, int CB0, int CB1, bool RESBATCH, bool CONV, int EPI, bool SK = false, int NPH = 4, int SCH = 0>
+template <int BM, int BN, int CB0, int CB1, bool RESBATCH, int CONV, int EPI, bool SK = false, int NPH = 4, int SCH = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
 {
     constexpr int BK = 64, RB = BK * 2;            // bytes per tile row
@@ -185,7 +185,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     // CONV (3x3 / 1x1, stride 1 / 2, no upsample, Cin % 64 == 0): a K tile lies inside ONE filter tap, so the tap and the
     // channel offset are block-uniform (scalar); a row keeps the address of its output pixel's top-left input pixel
     // and a 9-bit mask of the taps that fall inside the image; padded taps read the zero page.
-    struct SeqA { int kt, par; const _Float16* ptr[NU1]; int mask[CONV ? NU1 : 1]; int kh, kw, cin; };
+    // CONV == 2 (round 5): the source is read through a nearest-2x upsample (ggml_upscale + conv, src/mlblock_nn.c:122; stride 1): tap (kh, kw) of output pixel (oh, ow) is
+    // source pixel ((oh - pad + kh) >> 1, (ow - pad + kw) >> 1), so the tap offset depends on the parity of the row's pixel: the row keeps its image base and its
+    // (oh - pad, ow - pad) pair, and the source address is formed per row and K tile (a handful of VALU operations per LDS-DMA instruction) instead of once per tile.
+    constexpr bool UPS = CONV == 2;
+    struct SeqA { int kt, par; const _Float16* ptr[NU1]; int mask[CONV ? NU1 : 1]; int pos[UPS ? NU1 : 1]; int kh, kw, cin; };
     struct SeqB2 { int kt, par; const _Float16* ptr[NU2]; };
     struct SeqB3 { int kt, par; const _Float16* ptr[NU3]; };
     SeqA sa[2];    // [0] = U1, [1] = U4
@@ -215,11 +219,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 const int img = m / ohw, rem = m - img * ohw;
                 const int oh = rem / p.OW, ow = rem - oh * p.OW;
                 const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+                const int He = UPS ? 2 * p.H : p.H, We = UPS ? 2 * p.W : p.W;
                 int mk = 0;
                 for (int kh = 0; kh < p.KH; ++kh)
                     for (int kw = 0; kw < p.KW; ++kw)
-                        if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= 1 << (kh * p.KW + kw);
+                        if ((unsigned)(ih0 + kh) < (unsigned)He && (unsigned)(iw0 + kw) < (unsigned)We) mk |= 1 << (kh * p.KW + kw);
                 s.mask[it] = mk;
+                if constexpr (UPS) {
+                    s.pos[it] = ((ih0 + 16) << 16) | (iw0 + 16);                  // (pad <= 16: both halves stay non-negative)
+                    s.ptr[it] = p.A + (long)img * p.H * p.W * p.lda + chunk_of(r);
+                } else
                 s.ptr[it] = p.A + ((long)img * p.H * p.W + (long)ih0 * p.W + iw0) * p.lda + chunk_of(r);
             } else {
                 s.ptr[it] = p.A + (long)m * p.lda + chunk_of(r) + kenter * BK;
@@ -250,6 +259,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         for (int it = 0; it < NU1; ++it) {
             unsigned char* dst = stage + a_row0(it, second) * RB;                  // wave-uniform: 8 rows, lane-linear
             const _Float16* src = s.ptr[it];
+            if constexpr (UPS) {
+                const int ih = (s.pos[it] >> 16) - 16 + s.kh, iw = (s.pos[it] & 0xffff) - 16 + s.kw;
+                src = (s.mask[it] & tbit) ? s.ptr[it] + ((long)(ih >> 1) * p.W + (iw >> 1)) * p.lda + s.cin : zsrc;
+            } else
             if constexpr (CONV) src = (s.mask[it] & tbit) ? s.ptr[it] + toff : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);

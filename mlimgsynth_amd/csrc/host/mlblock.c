@@ -868,18 +868,18 @@ static int gemm_candidates(MLCtx* C, mlsd_gemm_args* g, int cv[32], int cs[32])
 	else {
 		/* persistent ping-pong tiles (gemm_pp.hpp): problems made of whole wave blocks; convs whose K tiles lie inside
 		 * one filter tap (anything else they would hand to the LDS-transposing tile of the same shape anyway) */
-		const int pp_ok = !(g->K & 63) && g->K >= 192 && (!g->conv || (!g->upsample && !(g->Cin & 63)));
+		const int pp_ok = !(g->K & 63) && g->K >= 192 && (!g->conv || (!(g->Cin & 63) && (!g->upsample || (g->stride == 1 && g->C32 && !g->C16 && !g->resid && g->act == MLSD_ACT_NONE))));      /* (upsampled sources: round 5, gemm_pp.hpp CONV == 2) */
 		if (pp_ok && g->M >= 256 && g->N >= 256 && !(g->M & 127) && !(g->N & 63)) {
 			cv[nc]=17; cs[nc++]=1; cv[nc]=21; cs[nc++]=1;
 			/* stream-K on the same tile where the tiles do not fill whole rounds of the 256 blocks */
 			const long t256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256);
-			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
+			if (t256 % 256 && t256 * (g->K / 64) >= 256 * 4 && g->act != MLSD_ACT_GEGLU && !(g->conv && g->upsample) && !streamk_get(C, g)) { cv[nc]=19; cs[nc++]=1; }
 		}
 		if (pp_ok && g->M >= 128 && !(g->M & 63) && !(g->N % 80) && g->act != MLSD_ACT_GEGLU) {
 			cv[nc]=18; cs[nc++]=1; cv[nc]=20; cs[nc++]=1;   /* four / two phases per K tile */
 			/* stream-K on that tile: few tiles (not whole rounds of the 256 blocks) and K long enough to deal out */
 			const long t320 = (long)((g->M + 127) / 128) * ((g->N + 319) / 320);
-			if (t320 % 256 && t320 < 256 && t320 * (g->K / 64) >= 256 * 4 && !streamk_get(C, g)) { cv[nc]=28; cs[nc++]=1; }
+			if (t320 % 256 && t320 < 256 && t320 * (g->K / 64) >= 256 * 4 && !(g->conv && g->upsample) && !streamk_get(C, g)) { cv[nc]=28; cs[nc++]=1; }
 		}
 		/* two tiles in flight per CU (gemm_tt.hip, round 5): linear / 1x1 problems made of whole 128 x 160 tiles */
 		if (!(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m &&

@@ -720,6 +720,44 @@ def test_conv2d_pingpong(K, pp, n, h, w, cin, cout, k, s):
         assert rel(got, ref) < 2e-5, rep
 
 
+@pytest.mark.parametrize("pp", [17, 18, 20, 21])
+@pytest.mark.parametrize("n,h,w,cin,cout,stats", [(2, 16, 16, 64, 320, 0), (1, 16, 32, 128, 640, 1), (3, 8, 8, 192, 1280, 0), (2, 32, 32, 64, 256, 1)])
+def test_conv2d_pingpong_upsampled_source(K, pp, n, h, w, cin, cout, stats):
+    """The upsampling convolutions of the UNets / decoders (ggml_upscale nearest 2x + 3x3 conv, src/mlblock_nn.c:122) on the ping-pong tiles (round 5: gemm_pp.hpp CONV == 2, the
+    tap offset formed per row from the parity of its pixel): against the oracle's upscale + conv, borders included (taps outside the UPSAMPLED image read zeros); with the
+    column statistics a consuming GroupNorm takes from its producer; bit-identical to the general tile's sums is not asked for (another summation order)."""
+    kernels, _lib = K
+    rng = np.random.default_rng(cin + cout + n)
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    P = O.Params()
+    pw, pb = P.set("w", wt, f16=True), P.set("b", bias)
+    ref = np.stack([O.from_ot(O.L().orc_conv2d(O.L().orc_upscale2(O.to_ot(x[i:i + 1])), pw, pb, 1, 1))[0] for i in range(n)])
+    oh, ow = 2 * h, 2 * w
+    assert ref.shape == (n, cout, oh, ow)
+    M = n * oh * ow
+    dX = dev(_lib, np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    dW, dB = dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias)
+    dC = _lib.DeviceBuffer(M * cout * 4)
+    BMh = 128 if pp in (17, 21) else 64
+    nrb = (M + BMh - 1) // BMh
+    dS = _lib.DeviceBuffer(nrb * 2 * cout * 4)
+    a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=oh, OW=ow, KH=3, KW=3, stride=1, pad=1, upsample=1,
+                         W_=dW.ptr, ldb=9 * cin, M=M, N=cout, K=9 * cin, bias=dB.ptr, C32=dC.ptr, ldc32=cout, colstats=dS.ptr if stats else None, tile_variant=pp + 1)
+    if (M % BMh) or (cout % (64 if pp in (17, 21) else 80)):
+        pytest.skip("not made of whole wave blocks for this tile")
+    assert "pp" in kernels.gemm_variant(a), kernels.gemm_variant(a)
+    for rep in range(2):
+        kernels.gemm(a)
+        got = dC.download((n, oh, ow, cout), np.float32).transpose(0, 3, 1, 2)
+        assert rel(got, ref) < 2e-5, rep
+    if stats:
+        st = dS.download((nrb, 2, cout), np.float32).astype(np.float64)
+        flat = got.transpose(0, 2, 3, 1).reshape(M, cout).astype(np.float64)
+        assert np.allclose(st[:, 0].sum(0), flat.sum(0), rtol=1e-4, atol=1e-2) and np.allclose(st[:, 1].sum(0), (flat ** 2).sum(0), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("pp,M,N,Kd", [(17, 4096, 2560, 1280), (18, 8192, 1280, 1280), (17, 8192, 5120, 320), (18, 32768, 640, 640),
                                        (20, 8192, 1280, 1280), (20, 32768, 640, 640), (21, 4096, 2560, 1280), (20, 131072, 320, 192)])
 def test_gemm_pingpong_is_bit_repeatable(K, pp, M, N, Kd):
