@@ -11,6 +11,12 @@ ARGS="--workload $WL --batch-per-gpu $B --steps 1 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -- python3 $R/bench.py $ARGS > $OUT/kt_$WL.log 2>&1 < /dev/null
 for f in $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1); do cp $f $OUT/${TAG}_${WL}_b${B}_rocprofv3_kernel_stats.csv; done
 find $OUT/kt_$WL -name "*kernel_trace.csv" -delete
+# the same statistics for the UNet plan ALONE (tools/unet_eval.py: 10 evaluations of the plan bench.py times, nothing else in the process): the per-kernel averages that
+# bench.py's roofline.avg_launch_us must agree with (the 140 launches of 'gemm<256x256x64pp,linear>' are TWO instantiations here: GEGLU epilogue (60 per evaluation) and fp16 (80))
+case $WL in sdxl) UA0="sdxl 128 $((2*B)) 10";; sd15) UA0="sd1 64 $((2*B)) 10";; *) UA0="$WL 8 $((2*B)) 10";; esac
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktu_$WL -- python3 $R/tools/unet_eval.py $UA0 > $OUT/ktu_$WL.log 2>&1 < /dev/null
+for f in $(find $OUT/ktu_$WL -name "*kernel_stats.csv" | head -1); do cp $f $OUT/${TAG}_${WL}_b${B}_unet_eval_rocprofv3_kernel_stats.csv; done
+find $OUT/ktu_$WL -name "*kernel_trace.csv" -delete
 # HBM-side counters: one pass each, with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 # Target: tools/unet_eval.py = the same UNet plan (same shapes, same tuned kernels) evaluated 10x on the NULL stream;
 # (a WRITE_SIZE pass occasionally hangs at start-up on this pool: hence the short timeout -- re-run the pass, the summary
