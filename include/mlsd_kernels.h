@@ -154,6 +154,13 @@ typedef struct mlsd_gemm_args {
 	const float *gn_gamma, *gn_beta;
 	float gn_eps;
 	int gn_groups, gn_hw, gn_silu;
+	/* A SECOND GEMM in the same launch (round 5; the 128 x 160 kernel, tile variant 30, on launches that end with a LayerNorm): the Linear that consumes that LayerNorm --
+	 * chain_C16[m][n] = fp16(sum_k ln_y16[m][k] chain_W[n][k] + chain_bias[n]), N columns, K = N (src/mlblock_nn.c:200-203: the cross-attention q projection behind norm2).
+	 * Honoured when mlsd_gemm_chained(args) == 1 (M % 128 == 0, N % 320 == 0, at most two 128 x 160 tiles per CU; EXPERIMENTS builds only: measured, correct, not faster in
+	 * the plan -- profiles/NOTES.md "Round 5"); mlsd_gemm FAILS when chain_W is set and it is not. */
+	const void* chain_W; int64_t chain_ldb;
+	const float* chain_bias;
+	void* chain_C16; int64_t chain_ldc16;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -162,6 +169,8 @@ int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
 /* != 0 if this launch (ln_* fields set) ends with the LayerNorm of its output (see mlsd_gemm_args.ln_y16): 1 = inside the launch, the tiles of a row block exchanging their
  * row statistics (128x320 ping-pong tile; an in-launch hand-off); 2 = in the reduce pass of a split-K launch (one block per finished row: no hand-off; ln_ws / ln_cnt unused) */
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
+/* 1 if this launch (chain_* fields set) also runs the Linear that consumes its LayerNorm: see mlsd_gemm_args.chain_W */
+int mlsd_gemm_chained(const mlsd_gemm_args* a);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 /* 1 if this launch (gn_* fields set) ends its split-K reduce pass with the GroupNorm of its output (see mlsd_gemm_args.gn_y16) */
 int mlsd_gemm_gn_fused(const mlsd_gemm_args* a);

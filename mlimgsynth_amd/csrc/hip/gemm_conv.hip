@@ -1465,6 +1465,8 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
                               "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
     if (a->gn_y16 && !mlsd_gemm_gn_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a GroupNorm for this launch's reduce pass but the launch would not run it (tile or K-split settings changed after planning)");
+    if (a->chain_W && !mlsd_gemm_chained(a))
+        return mlsd_set_error(-1, "mlsd_gemm: the plan dropped the launch of a consuming Linear for this launch's second GEMM but the launch would not run it (tile settings changed after planning)");
     if (a->ln_y16 && !mlsd_gemm_ln_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a LayerNorm for this launch's *_LN epilogue but the launch would not run it (tile or epilogue settings changed after planning)");
     hipStream_t st = (hipStream_t)stream;
@@ -1640,7 +1642,7 @@ MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
         if (vec && splitk_slices(a, 64, nullptr) > 1 && !splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)))
             return 2;
     }
-    if (v == 30) { const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu); return (e == 4 || e == 5) ? 1 : 0; }      // (TT_F32_LN / TT_F32_RES_LN)
+    if (v == 30) { const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu); return (e >= 4 && e <= 7) ? 1 : 0; }      // (TT_F32_LN / TT_F32_RES_LN / TT_CHAIN_*)
     if (v != 18 || !ln_eligible(a)) return 0;
     const int e = pp_epilogue_kind(a, 320);
     return (e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN) ? 1 : 0;
@@ -1668,6 +1670,14 @@ MLSD_API int mlsd_gemm_gn_fused(const mlsd_gemm_args* a)
 #endif
 }
 
+/* 1 if this launch (chain_* fields set) also runs the GEMM that consumes its LayerNorm (mlsd_gemm_args.chain_W): the plan builder then drops that launch */
+MLSD_API int mlsd_gemm_chained(const mlsd_gemm_args* a)
+{
+    if (!a || !a->chain_W || !a->ln_y16 || pick_variant(a) != 30) return 0;
+    const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu);
+    return (e == 6 || e == 7) ? 1 : 0;
+}
+
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
@@ -1693,7 +1703,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : (mlsd_gemm_gn_fused(a) ? "+groupnorm" : ""), ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
-    else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
+    else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm%s>", kVariants[v].name, mlsd_gemm_chained(a) ? "+linear" : "");      /* the launch ends with the LayerNorm of its output (and runs the Linear that consumes it) */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;
 }

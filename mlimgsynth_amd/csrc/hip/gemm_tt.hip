@@ -36,9 +36,11 @@ struct TTP {
     int nbm, nbn, prio;
     const float *ln_g, *ln_b; float ln_eps; _Float16* ln_y; long ldln; float* ln_ws; unsigned* ln_cnt;
     unsigned long long* tbuf;      // diagnostics: 4 words per block {start, loop end, exit (100 MHz), HW_ID | XCC_ID << 32}
+    // TT_CHAIN_*: the SECOND GEMM of the launch, C16b = fp16(ln_y . B2^T + bias2): same M, N columns, K = N (see the kernel)
+    const _Float16* B2; long ldb2; const float* bias2; _Float16* C16b; long ldc16b;
 };
 
-enum { TT_F16 = 1, TT_F32 = 2, TT_F32_RES = 3, TT_F32_LN = 4, TT_F32_RES_LN = 5 };
+enum { TT_F16 = 1, TT_F32 = 2, TT_F32_RES = 3, TT_F32_LN = 4, TT_F32_RES_LN = 5, TT_CHAIN_LN = 6, TT_CHAIN_RES_LN = 7 };
 
 template <int N>
 __device__ __forceinline__ void tt_wait_vmcnt()
@@ -71,6 +73,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     const int m0 = bmi * BM, n0 = bni * BN;
     // priority class: blocks 0..255 (the first one on every CU), 512..767, ... run ahead of the others
     if (p.prio && !((v >> 8) & 1)) __builtin_amdgcn_s_setprio(2);
+    if constexpr (EPI == TT_CHAIN_LN || EPI == TT_CHAIN_RES_LN) {
+        // the second GEMM reads its partners' rows from the XCD's L2: the partner tiles (blocks 8 apart) must sit on this block's XCD.  They do (block id % 8, measured on
+        // every grid size: tools/gemm_tt_xcd_check.py); should a driver ever place them otherwise the launch says so through the sticky give-up word and the plan retries
+        // on separate launches
+        if (tid == 0 && (int)(__builtin_amdgcn_s_getreg(63508) & 0xf) != (v & 7)) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (p.tbuf && tid == 0) {
         p.tbuf[(long)v * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         p.tbuf[(long)v * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -81,12 +89,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     const int schunk = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;   // halfs
     const _Float16* pa = p.A + (long)(m0 + srow) * p.lda + schunk;
     const _Float16* pb = p.B + (long)(n0 + srow) * p.ldb + schunk;
-    const long a32 = 32 * p.lda, b32 = 32 * p.ldb;
+    long a32 = 32 * p.lda, b32 = 32 * p.ldb;
+    constexpr bool CHAIN = EPI == TT_CHAIN_LN || EPI == TT_CHAIN_RES_LN;
+    bool second = false;                                                          // CHAIN: staging for the second GEMM (block-uniform)
     auto issue_one = [&](int g, int st) __attribute__((always_inline)) {          // g 0..NI-1: A row groups, NI..NS-1: B row groups; K tile = where pa / pb stand
-        if (g < NI)
+        if (g < NI) {
+            // the A operand of the second GEMM was written by the partner tiles a moment ago and sits at addresses this CU may have read in the first GEMM (the LayerNorm rows
+            // often land on the first A operand): agent-scope loads go past the vector L1 to the XCD's L2, where the partners' rows are
+            if (CHAIN && second)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + g * a32),
+                                                 (__attribute__((address_space(3))) void*)(smem + st * A_ST + wave * 1024 + g * 4096), 16, 0, 16);
+            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + g * a32),
                                              (__attribute__((address_space(3))) void*)(smem + st * A_ST + wave * 1024 + g * 4096), 16, 0, 0);
-        else
+        } else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + (g - NI) * b32),
                                              (__attribute__((address_space(3))) void*)(smem + BBASE + st * B_ST + wave * 1024 + (g - NI) * 4096), 16, 0, 0);
     };
@@ -142,15 +158,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
         half(1, NEXT_, 0, s ^ 1, ISSUE_, s);
     };
 
-    issue_tile(0); issue_tile(1);
-    tt_wait_vmcnt<NS>();
-    __builtin_amdgcn_s_barrier();
+    auto mainloop = [&](int nk) __attribute__((always_inline)) {
+        issue_tile(0); issue_tile(1);
+        tt_wait_vmcnt<NS>();
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int g = 0; g < NS; ++g) read_one(0, g, 0);
-    int t = 0;
-    for (; t + 2 < nkt; ++t) body(t & 1, std::true_type{}, std::true_type{});
-    body(t & 1, std::true_type{}, std::false_type{}); ++t;
-    body(t & 1, std::false_type{}, std::false_type{});
+        for (int g = 0; g < NS; ++g) read_one(0, g, 0);
+        int t = 0;
+        for (; t + 2 < nk; ++t) body(t & 1, std::true_type{}, std::true_type{});
+        body(t & 1, std::true_type{}, std::false_type{}); ++t;
+        body(t & 1, std::false_type{}, std::false_type{});
+    };
+    mainloop(nkt);
 
     if (p.tbuf && tid == 0) p.tbuf[(long)v * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue: acc[i][c][e] = C[wrow0 + 16 i + l15][wcol0 + 16 c + 4 lg + e]
@@ -158,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     f32x4 cb[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) cb[c] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wcol0 + c * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == TT_F16) {
-        _Float16* rowp = p.C16 + (long)(wrow0 + l15) * p.ldc16 + wcol0 + 8 * (lg >> 1) + 16 * (lg & 1);
+    auto epi_f16 = [&](_Float16* C16, long ldc16) __attribute__((always_inline)) {
+        _Float16* rowp = C16 + (long)(wrow0 + l15) * ldc16 + wcol0 + 8 * (lg >> 1) + 16 * (lg & 1);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -170,12 +189,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1);
                 const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                *reinterpret_cast<u32x4*>(rowp + (long)i * 16 * p.ldc16 + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                *reinterpret_cast<u32x4*>(rowp + (long)i * 16 * ldc16 + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
             }
             const f32x4 vl = acc[i][NC - 1] + cb[NC - 1];      // odd block count: the last block keeps its 8-byte pieces
             const f16x4 hl = {(_Float16)vl[0], (_Float16)vl[1], (_Float16)vl[2], (_Float16)vl[3]};
-            *reinterpret_cast<f16x4*>(p.C16 + (long)(wrow0 + l15 + i * 16) * p.ldc16 + wcol0 + (NC - 1) * 16 + 4 * lg) = hl;
+            *reinterpret_cast<f16x4*>(C16 + (long)(wrow0 + l15 + i * 16) * ldc16 + wcol0 + (NC - 1) * 16 + 4 * lg) = hl;
         }
+    };
+    if constexpr (EPI == TT_F16) {
+        epi_f16(p.C16, p.ldc16);
     } else if constexpr (EPI == TT_F32 || EPI == TT_F32_RES) {
         constexpr bool RES = EPI == TT_F32_RES;
         float* rowp = p.C32 + (long)(wrow0 + l15) * p.ldc32 + wcol0 + 4 * lg;
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             }
     } else {
         // *_LN: fp32 output (+ residual) AND the LayerNorm of the finished rows as fp16 (gemm_pp.hpp epi_ln with nbn = N / 160 partner tiles and 2 wave columns)
-        constexpr bool RES = EPI == TT_F32_RES_LN;
+        constexpr bool RES = EPI == TT_F32_RES_LN || EPI == TT_CHAIN_RES_LN;
         f32x4 rr[RES ? NI : 1][RES ? NC : 1];
         if constexpr (RES) {
             const float* resp = p.resid + (long)(wrow0 + l15) * p.ldr + wcol0 + 4 * lg;
@@ -266,10 +288,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         float* c32b = p.C32 + (long)(wrow0 + l15) * p.ldc32 + wcol0 + 4 * lg;
+        auto store_c32 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(c32b + (long)i * 16 * p.ldc32 + c * 16) = acc[i][c];
+                for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(c32b + (long)i * 16 * p.ldc32 + c * 16) = acc[i][c];
+        };
+        if constexpr (!CHAIN) store_c32();      // (CHAIN: after the fp16 rows, see below -- the second GEMM waits for the rows, the fp32 output can drain under it)
         if (wc == 0) {
             unsigned spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
@@ -318,6 +343,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }        if constexpr (CHAIN) {
+            // ---- the SECOND GEMM of the launch (round 5): C16b = fp16(ln_y . B2^T + bias2) for the same tile coordinates -- the projection that consumes this LayerNorm
+            // (the cross-attention q projection behind the self-attention output projection).  Its A rows [m0, m0 + 128) x N are the fp16 rows the nbn partner tiles of
+            // this row block have just written: every tile counts itself in once its rows are acknowledged (vmcnt(0) of all four waves, then one ticket), one wave polls,
+            // and the K loop runs again on the new operands.  What it buys: no dispatch boundary, no cold prologue, and the fp32 output of the first GEMM (80 KB per tile,
+            // issued after the ticket) drains to memory under the second K loop instead of in front of a kernel end.
+            unsigned* cnt2 = p.ln_cnt + (bmi * 2) * 16 + 2;                                  // {arrivals, departures} of the row block's finished tiles (words 2, 3 of its first group)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // this wave's fp16 rows are in the XCD's L2
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) __hip_atomic_fetch_add(cnt2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            store_c32();
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            second = true;
+            pa = p.ln_y + (long)(m0 + srow) * p.ldln + schunk; a32 = 32 * p.ldln;
+            pb = p.B2 + (long)(n0 + srow) * p.ldb2 + schunk; b32 = 32 * p.ldb2;
+            if (wave == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
+                if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(cnt2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)(nbn - 1)) {
+                    __hip_atomic_store(cnt2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt2 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            mainloop(p.N / BK);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cb[c] = p.bias2 ? *reinterpret_cast<const f32x4*>(p.bias2 + wcol0 + c * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
+            epi_f16(p.C16b, p.ldc16b);
         }
     }
     if (p.tbuf && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.tbuf[(long)v * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
@@ -348,6 +408,18 @@ extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu)
             static int anygrid = -1;      // MLSD_TT_LN_ANYGRID=1: also grids of more than 2 blocks per CU (tools/soak_r5.py)
             if (anygrid < 0) { const char* e = getenv("MLSD_TT_LN_ANYGRID"); anygrid = (e && *e == '1') ? 1 : 0; }
             if (a->M / 128 > 256 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > 2L * ncu)) return 0;
+            // MEASURED AND NOT ADOPTED (profiles/NOTES.md "Round 5", tools/gemm_chain_bench.py, profiles/r5_ab_chain.txt): bit-identical to the separate launches, 86 -> 81 us on the
+            // pair of 8192x1280x1280 launches against 80.5 for the plan's ping-pong + 128x160 pair; in the plan SDXL b4 +1.5 %, b2 +0.7 %, SD1.5 b1 -0.3 %.  EXPERIMENTS builds only.
+#ifdef MLSD_GEMM_EXPERIMENTS
+            if (a->chain_W) {      // + the GEMM that consumes the LayerNorm, in the same launch (TT_CHAIN_*): fp16(ln_y16 . chain_W^T + chain_bias) -> chain_C16, N columns, K = N
+                if (!a->chain_C16 || (a->N & 63) || a->N < 128 || a->ldln < a->N || (a->chain_ldb & 7) || a->chain_ldb < a->N || (a->chain_ldc16 & 7) || a->chain_ldc16 < a->N ||
+                    ((uintptr_t)a->chain_W & 15) || ((uintptr_t)a->chain_C16 & 15) || (a->chain_bias && ((uintptr_t)a->chain_bias & 15)) ||
+                    (long)(a->M / 128) * (a->N / 160) > 2L * ncu) return 0;      // (all tiles resident together: the second GEMM waits for its partners' rows)
+                return a->resid ? TT_CHAIN_RES_LN : TT_CHAIN_LN;
+            }
+#else
+            if (a->chain_W) return 0;
+#endif
             return a->resid ? TT_F32_RES_LN : TT_F32_LN;
         }
         return a->resid ? TT_F32_RES : TT_F32;
@@ -364,7 +436,8 @@ extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu)
     p.bias = a->bias; p.resid = a->resid; p.ldr = a->ldr; p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = a->M / 128; p.nbn = a->N / 160; p.prio = g_tt_prio;
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt; p.tbuf = g_tt_tbuf;
-    const bool ln = epi == TT_F32_LN || epi == TT_F32_RES_LN;
+    p.B2 = (const _Float16*)a->chain_W; p.ldb2 = a->chain_ldb; p.bias2 = a->chain_bias; p.C16b = (_Float16*)a->chain_C16; p.ldc16b = a->chain_ldc16;
+    const bool ln = epi >= TT_F32_LN;
     const size_t LDS = 2 * (size_t)(128 + 160) * 128 + (ln ? 2048 : 0);
     const dim3 grid(p.nbm * p.nbn), block(256);
     auto go = [&](auto kfn) -> int {
@@ -383,6 +456,10 @@ extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu)
     case TT_F32: return go(gemm_tt_kernel<TT_F32>);
     case TT_F32_RES: return go(gemm_tt_kernel<TT_F32_RES>);
     case TT_F32_LN: return go(gemm_tt_kernel<TT_F32_LN>);
+#ifdef MLSD_GEMM_EXPERIMENTS
+    case TT_CHAIN_LN: return go(gemm_tt_kernel<TT_CHAIN_LN>);
+    case TT_CHAIN_RES_LN: return go(gemm_tt_kernel<TT_CHAIN_RES_LN>);
+#endif
     default: return go(gemm_tt_kernel<TT_F32_RES_LN>);
     }
 }

@@ -20,7 +20,7 @@ typedef struct MLOp {
 	double flops;
 	char label[56];
 	int gn_src[2];          /* OP_GN: index of the op that PRODUCES each fp32 source (MLTensor.prod), -1 = not a GEMM/conv output */
-	int fused;              /* OP_LN: the producer's launch ends with this LayerNorm (wire_ln_fold): the op itself does nothing */
+	int fused;              /* OP_LN: the producer's launch ends with this LayerNorm (wire_ln_fold): the op itself does nothing; OP_GEMM: the Linear runs as the second GEMM of its producer's launch */
 	int saved_variant;      /* OP_GEMM, during wire_ln_fold: the table's tile of a producer that was moved to the 128 x 160 kernel for its LayerNorm (-1: the static rule); 0 = not moved / fold done */
 	int folded_from;        /* OP_GEMM: the tile such a producer had before it was moved AND its LayerNorm was handed over: mlctx_handoffs_off returns it there (-1: the static rule; 0: not moved) */
 	int once;               /* step-invariant: depends only on inputs marked static_src (the text conditioning); mlctx_compute
@@ -109,6 +109,7 @@ struct MLCtx {
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums / stream-K slabs (one buffer: ops run in order on one stream) */
 	unsigned* sk_flags;                        /* stream-K: one flag per persistent block, zeroed once (consumers clear them) */
 	unsigned* ln_cnt; float* ln_ws; size_t ln_ws_bytes; int n_ln_fused;   /* LayerNorms ended in their producers (wire_ln_fold): counters, scratch, count */
+	int n_chained;          /* Linears that run as the second GEMM of their producer's launch */
 	int n_gn_fused;            /* GroupNorms ended in their producers' split-K reduce pass (wire_gn_fold) */
 	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
 	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy

@@ -1029,6 +1029,64 @@ def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
     assert not cnt.download((8192,), np.uint32).any()
 
 
+@pytest.mark.skipif(not HAS_EXP, reason="the chained launch is an EXPERIMENTS build variant (measured, bit-identical, not faster in the plan)")
+@pytest.mark.parametrize("M,N,Kd,res,alias", [(8192, 1280, 1280, 1, 1), (8192, 1280, 1280, 1, 0), (4096, 1280, 640, 0, 0), (8192, 320, 320, 1, 1), (2048, 640, 640, 1, 0), (16384, 640, 1920, 1, 0)])
+def test_gemm_second_gemm_of_the_launch(K, M, N, Kd, res, alias):
+    """mlsd_gemm_args.chain_W (round 5): a launch of the 128x160 kernel that ends with a LayerNorm goes on to run the Linear that consumes it -- fp16(ln_y16 . W2^T + b2), the
+    cross-attention q projection behind the self-attention output projection (src/mlblock_nn.c:200-203 behind :224-229) -- on the rows its partner tiles have just written.
+    Against the same three results from separate launches (output projection + LayerNorm; projection of the LayerNorm rows on the same kernel): bit-identical, also when the
+    LayerNorm rows land on the first GEMM's A operand (the common case in the plan), and on TWO operand sets launched alternately over one scratch / counter block (stale rows
+    of the previous launch -- another layer's in the plan -- must never be read: the second GEMM's A loads go past the vector L1)."""
+    kernels, _lib = K
+    L = _lib.lib()
+    L.mlsd_gemm_chained.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    rng = np.random.default_rng(M + N + Kd)
+    ws = _lib.DeviceBuffer(2 << 20); cnt = dev(_lib, np.zeros(8192, np.uint32))
+    dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
+    dW2 = dev(_lib, (rng.standard_normal((N, N)) / np.sqrt(N)).astype(np.float16))
+    dB, dB2 = dev(_lib, rng.standard_normal(N).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    dG, dBt = dev(_lib, (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
+    assert not alias or Kd == N
+    sets, ref = [], []
+    for k in range(2):
+        A = (rng.standard_normal((M, Kd)) * (1 + k)).astype(np.float16)
+        d = dict(A0=A, A=dev(_lib, A), R=dev(_lib, (rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)), C=_lib.DeviceBuffer(M * N * 4), Q=_lib.DeviceBuffer(M * N * 2))
+        d["Y"] = d["A"] if alias else _lib.DeviceBuffer(M * N * 2)
+        sets.append(d)
+
+    def args(d, chain):
+        a = kernels.GemmArgs(A=d["A"].ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=d["C"].ptr, ldc32=N, tile_variant=31,
+                             ln_y16=d["Y"].ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dBt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+        if res:
+            a.resid, a.ldr = d["R"].ptr, N
+        if chain:
+            a.chain_W, a.chain_ldb, a.chain_bias, a.chain_C16, a.chain_ldc16 = dW2.ptr, N, dB2.ptr, d["Q"].ptr, N
+        return a
+    # separate launches first (the LayerNorm rows may overwrite A: restore it afterwards)
+    for d in sets:
+        a1 = args(d, False)
+        assert L.mlsd_gemm_chained(ctypes.byref(a1)) == 0 and "layernorm" in kernels.gemm_variant(a1)
+        kernels.gemm(a1)
+        a2 = kernels.GemmArgs(A=d["Y"].ptr, lda=N, W_=dW2.ptr, ldb=N, M=M, N=N, K=N, bias=dB2.ptr, C16=d["Q"].ptr, ldc16=N, tile_variant=31)
+        assert "tt" in kernels.gemm_variant(a2)
+        kernels.gemm(a2)
+        ref.append((d["C"].download((M * N,), np.uint32), d["Y"].download((M * N // 2,), np.uint32), d["Q"].download((M * N // 2,), np.uint32)))
+        assert np.isfinite(d["Q"].download((M, N), np.float16).astype(np.float32)).all()
+    chained = [args(d, True) for d in sets]
+    assert L.mlsd_gemm_chained(ctypes.byref(chained[0])) == 1 and kernels.gemm_variant(chained[0]).endswith("+layernorm+linear>")
+    for r in range(300):
+        d = sets[r & 1]
+        if alias:
+            d["A"].upload(d["A0"])
+        _lib.check(L.mlsd_memset(_lib.vp(d["Q"].ptr), 0xFF, ctypes.c_size_t(M * N * 2), None))
+        kernels.gemm(chained[r & 1])
+        if r < 4 or r % 10 < 2:
+            got = (d["C"].download((M * N,), np.uint32), d["Y"].download((M * N // 2,), np.uint32), d["Q"].download((M * N // 2,), np.uint32))
+            for name, g_, e_ in zip(("fp32 output", "LayerNorm rows", "second GEMM"), got, ref[r & 1]):
+                assert np.array_equal(g_, e_), (name, r, int((g_ != e_).sum()))
+    assert not cnt.download((8192,), np.uint32).any()
+
+
 @pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 640, 640, 1), (1024, 320, 2560, 0)])
 def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
     """Tile variant 30 (gemm_tt.hip, round 5): 128x160 tiles on 4-wave blocks, two resident per CU, so that one tile's residual read / output burst runs under the other
