@@ -1386,6 +1386,9 @@ static int mlsd_gemm_w4(const mlsd_gemm_args*, int, void*, int) { return -1; }
 
 extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu);     // gemm_tt.hip: 128 x 160 tile, 4 waves, two blocks per CU (variant 30)
 extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu);
+// CUs the 128 x 160 kernel may count on for launches whose tiles wait for each other (LayerNorm endings: all partner tiles resident together): the stream's budget, and not
+// more than the device has (a partitioned device); the dry runtime has no device and plans for the full part
+static int tt_ncu() { if (mlsd_runtime_is_dry()) return g_gemm_ncu; const int c = device_cus(); return c < g_gemm_ncu ? c : g_gemm_ncu; }
 
 struct Variant { const char* name; int bm, bn, slots; };
 const Variant kVariants[] = {
@@ -1491,7 +1494,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (skinny_eligible(a)) return launch_skinny(a, st);
         return launch<64, 128, 64, 2, 2, 2>(a, st);
     case 30:
-        if (mlsd_gemm_tt_eligible(a, g_gemm_ncu)) return mlsd_gemm_tt(a, st, g_gemm_ncu);
+        if (mlsd_gemm_tt_eligible(a, tt_ncu())) return mlsd_gemm_tt(a, st, tt_ncu());
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);      // anything else: the ping-pong tile nearest in shape
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
@@ -1642,7 +1645,7 @@ MLSD_API int mlsd_gemm_ln_fused(const mlsd_gemm_args* a)
         if (vec && splitk_slices(a, 64, nullptr) > 1 && !splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)))
             return 2;
     }
-    if (v == 30) { const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu); return (e >= 4 && e <= 7) ? 1 : 0; }      // (TT_F32_LN / TT_F32_RES_LN / TT_CHAIN_*)
+    if (v == 30) { const int e = mlsd_gemm_tt_eligible(a, tt_ncu()); return (e >= 4 && e <= 7) ? 1 : 0; }      // (TT_F32_LN / TT_F32_RES_LN / TT_CHAIN_*)
     if (v != 18 || !ln_eligible(a)) return 0;
     const int e = pp_epilogue_kind(a, 320);
     return (e == PP_EPI_F32_LN || e == PP_EPI_F32_RES_LN) ? 1 : 0;
@@ -1674,7 +1677,7 @@ MLSD_API int mlsd_gemm_gn_fused(const mlsd_gemm_args* a)
 MLSD_API int mlsd_gemm_chained(const mlsd_gemm_args* a)
 {
     if (!a || !a->chain_W || !a->ln_y16 || pick_variant(a) != 30) return 0;
-    const int e = mlsd_gemm_tt_eligible(a, g_gemm_ncu);
+    const int e = mlsd_gemm_tt_eligible(a, tt_ncu());
     return (e == 6 || e == 7) ? 1 : 0;
 }
 
@@ -1689,7 +1692,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
         snprintf(buf, sizeof(buf), "gemm<%s,%s,k/%d>", kVariants[v].name, a->conv ? "conv" : "linear", skinny_slices(a, nullptr));
         return buf;
     }
-    if (v == 30 && !mlsd_gemm_tt_eligible(a, g_gemm_ncu)) v = 18;
+    if (v == 30 && !mlsd_gemm_tt_eligible(a, tt_ncu())) v = 18;
     if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
