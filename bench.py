@@ -55,7 +55,30 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (sd15, sdxl + TAESD) reported beside the headline")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--extras", action="store_true", help="run the secondary workloads also when the headline workload is not sdxl (tests)")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "host"),
+                    help="N > 1 exchange steps: rccl = device buffers over RCCL / xGMI (the product path); host = the library's communicator over a host transport "
+                         "(torch.distributed gloo), so that the world > 1 branch runs where RCCL cannot (several ranks sharing one GPU)")
     return ap.parse_args()
+
+
+def pmc_files(workload, B, kind):
+    """Committed rocprofv3 --pmc summaries of this plan, newest round first (profiles/r<N>_<workload>_b<B>_pmc_<kind>.json)."""
+    import glob
+    fs = glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_b{B}_pmc_{kind}.json"))
+    rnd = lambda p_: int(re.match(r"r(\d+)_", os.path.basename(p_)).group(1)) if re.match(r"r(\d+)_", os.path.basename(p_)) else -1
+    return sorted(fs, key=rnd, reverse=True)
+
+
+def pmc_entry(workload, B, kind, lab):
+    """(entry, file) of kernel label `lab` in the NEWEST committed summary; (None, file) when that file does not know the label --
+    never an older round's number for a kernel that has changed since (tests/test_profile_labels_cpu.py keeps the newest file keyed by plan labels)."""
+    for pmc in pmc_files(workload, B, kind)[:1]:
+        try:
+            with open(pmc) as fh:
+                return json.load(fh)["kernels"].get(lab), pmc
+        except Exception:
+            return None, pmc
+    return None, None
 
 
 def kernel_roofline(g, workload, B):
@@ -85,18 +108,11 @@ def kernel_roofline(g, workload, B):
     # (counters cannot be read from inside the process), summarised by tools/pmc_summary.py and committed under profiles/
     traffic, traffic_src, mfma_busy = None, None, None
     for kind in ("traffic", "mfma"):
-        pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_{workload}_b{B}_pmc_{kind}.json") for r_ in ("r5", "r4", "r3", "r2", "r1")) if os.path.exists(p_)), "")
-        if not pmc:
-            continue
-        try:
-            with open(pmc) as fh:
-                k = json.load(fh)["kernels"].get(lab)
-            if k and kind == "traffic":
-                traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
-            elif k:
-                mfma_busy = k["mfma_busy_frac"]      # matrix-pipe utilisation from a SQ counter pass (tools/pmc_mfma_summary.py)
-        except Exception:
-            pass
+        k, pmc = pmc_entry(workload, B, kind, lab)
+        if k and kind == "traffic":
+            traffic, traffic_src = k["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
+        elif k:
+            mfma_busy = k["mfma_busy_frac"]      # matrix-pipe utilisation from a SQ counter pass (tools/pmc_mfma_summary.py)
     roof = {**roof, "kernel": lab, "launches_per_eval": cnt, "avg_launch_us": round(tms / cnt * 1e3, 2),
             "algorithmic_gb_per_eval": round(nb / 1e9, 3), "algorithmic_tflop_per_eval": round(fl / 1e12, 3),
             "algorithmic_bytes_per_launch": round(nb / cnt), "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_frac_pmc": mfma_busy,
@@ -237,7 +253,7 @@ def host_threads(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s, decode_flops_1):
+def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s, decode_flops_1, wtype="f16"):
     """CHILD PROCESS of the CPU-baseline leg (python bench.py --cpu-child ...): never touches the GPU (the plan that names the weights is built in the dry runtime).
     BASELINE.md section 3 as a bounded sample: the text towers of one prompt pair, ONE sampler step = 2 batch-1 UNet evaluations (cond + uncond) and ONE
     full-size VAE decode of the oracle (CPU restatement of the reference path), each timed and printed as soon as it is known (the parent uses what arrived before its
@@ -250,6 +266,9 @@ def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s
     _lib.lib().mlsd_runtime_dry(1)
     Lo = O.L()
     Lo.orc_set_threads(threads)
+    # BASELINE configs[0] is SD1.5 **fp32**: with an fp32 checkpoint the reference keeps fp32 linear weights and ggml multiplies fp32 x fp32
+    # (src/mlimgsynth.c:1235-1236, src/mlblock_nn.c:20-22) -- no F16 rounding passes over the activations in the timed sample
+    Lo.orc_set_linear_wtype(0 if wtype == "f32" else 1)        # ORC_F32 = 0, ORC_F16 = 1 (oracle/oracle.h)
     U = O.unet_params(model)
     V = O.vae_params("sdxl" if model == "sdxl" else "sd1")
     OP = O.Params(1234)
@@ -259,7 +278,7 @@ def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s
     unet_flops_1 = un.ctx.info().flops / 2
     plist = un.ctx.param_list()
     emit = lambda **kw: print("CPU " + json.dumps(kw), flush=True)
-    emit(threads=threads, unet_flops=unet_flops_1, decode_flops=decode_flops_1)
+    emit(threads=threads, unet_flops=unet_flops_1, decode_flops=decode_flops_1, linear_wtype=wtype)
     # ---- weights first (same (seed, name, shape) rule as the engine): the UNet's from the plan's parameter list, the VAE's / towers' by one run at 8 x 8 / as is
     for key, typ, ne in plist:
         OP.get(key, typ == 1, [d for d in ne[::-1]])
@@ -298,12 +317,12 @@ def cpu_child(model, width, height, cfg, denoise_steps, threads, decode_budget_s
     emit(decode_s=time.perf_counter() - t0, decode="measured")
 
 
-def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_s, timeout_s, flop_img, decode_flops_1, name):
+def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_s, timeout_s, flop_img, decode_flops_1, name, wtype="f16"):
     nfe = denoise_steps * (2 if cfg > 1 else 1)          # UNet evaluations per image (mlis_denoise_dxdt, src/mlimgsynth.c:1565-1587: cond + uncond)
     """Runs cpu_child in its own process (its OpenMP settings and a hard timeout never touch the product process) and composes the record from what it printed."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="PASSIVE", OMP_PROC_BIND="false", OMP_DYNAMIC="false")
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", model, str(width), str(height), str(cfg), str(denoise_steps), str(threads), str(decode_budget_s), str(decode_flops_1)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", model, str(width), str(height), str(cfg), str(denoise_steps), str(threads), str(decode_budget_s), str(decode_flops_1), wtype]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     timed_out = False
     try:
@@ -323,16 +342,16 @@ def cpu_record(model, width, height, cfg, denoise_steps, threads, decode_budget_
     s_img = rec["clip_s"] + nfe * rec["unet_eval_s"] + rec["decode_s"]
     return {"value": round(1.0 / s_img, 6), "unit": "images/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "s_per_unet_eval": round(rec["unet_eval_s"], 3), "s_text_towers": round(rec["clip_s"], 3), "s_vae_decode": round(rec["decode_s"], 3),
-            "decode": rec["decode"], "unet_gflops": round(rec["unet_flops"] / rec["unet_eval_s"] / 1e9, 1), "job_gflops": round(flop_img / s_img / 1e9, 1),
+            "linear_weights": rec.get("linear_wtype", wtype), "decode": rec["decode"], "unet_gflops": round(rec["unet_flops"] / rec["unet_eval_s"] / 1e9, 1), "job_gflops": round(flop_img / s_img / 1e9, 1),
             "sample": f"{name}: text towers of a prompt pair + {rec['unet_evals_timed']} of {nfe} batch-1 UNet evaluations (one sampler step) + one VAE decode "
-                      f"({rec['decode']}); oracle/ = fp32 CPU restatement of the reference path, AVX-512 / AVX2 SGEMM, OpenMP {threads} threads of {os.cpu_count()} host CPUs "
+                      f"({rec['decode']}); linear weights {rec.get('linear_wtype', wtype)}; oracle/ = fp32 CPU restatement of the reference path, AVX-512 / AVX2 SGEMM, OpenMP {threads} threads of {os.cpu_count()} host CPUs "
                       f"(those the box grants -- cgroup quota / affinity -- capped at 64); s per image = towers + {nfe} x evaluation + decode"}
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-child":
         m, w, h, cfg, ds, th, bud, dfl = sys.argv[2:10]
-        return cpu_child(m, int(w), int(h), float(cfg), int(ds), int(th), float(bud), float(dfl))
+        return cpu_child(m, int(w), int(h), float(cfg), int(ds), int(th), float(bud), float(dfl), sys.argv[10] if len(sys.argv) > 10 else "f16")
     a = parse()
     import numpy as np
     import torch
@@ -346,10 +365,33 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if a.transport == "host":
+        local_rank %= torch.cuda.device_count()        # ranks may share a GPU on the host transport (1-GPU boxes: both on cuda:0)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if a.transport == "rccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    try:
+        return run(a, world, rank, local_rank)
+    except BaseException:
+        # a rank that fails leaves the group and exits non-zero (never re-exec: the process has initialised the GPU); the launcher ends the other ranks
+        import traceback
+        traceback.print_exc()
+        if world > 1 and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(1)
+
+
+def run(a, world, rank, local_rank):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     from mlimgsynth_amd import _lib, engine, text
     from mlimgsynth_amd import dist as mdist
@@ -376,7 +418,7 @@ def main():
     if world > 1:
         # the library owns the data-path collectives (RCCL over xGMI through its C entry points); torch.distributed only carries
         # the 128-byte unique id to the other ranks and provides the barrier / max-over-ranks of the timing contract
-        comm = mdist.rccl_comm(L, world, rank, dev)
+        comm = mdist.rccl_comm(L, world, rank, dev) if a.transport == "rccl" else mdist.host_comm(L, world, rank)
         d_gather = _lib.DeviceBuffer(world * B * 4 * (height // 8) * (width // 8) * 4)
     info = g.info()
     t_setup = time.time() - t_setup
@@ -390,6 +432,12 @@ def main():
             lambda: engine.check1(Lh.mlis_amd_textcond_apply(tc.h, g.h, pp, prompt.size, None, 0), "mlis_amd_textcond_apply"),
             lambda: g.generate(mdist.image_seeds(idx, world, rank, B), want_latents=False, want_images=want_images),   # syncs its stream
             _lib.vp(d_gather.ptr) if d_gather else None)
+
+    tdev = dev if a.transport == "rccl" else torch.device("cpu")      # where torch.distributed's own tensors live (gloo: host)
+    comm_ranks, comm_kind = ctypes.c_int(0), ctypes.c_int(-1)
+    if world > 1:
+        assert L.mlsd_comm_count(comm, ctypes.byref(comm_ranks), ctypes.byref(comm_kind)) == 0, _lib.last_error()
+        assert comm_ranks.value == world, f"the communicator reports {comm_ranks.value} ranks, the launcher {world}"
 
     def fence():
         torch.cuda.synchronize()
@@ -407,14 +455,14 @@ def main():
         unet_ms += g.last_unet_ms()
     fence()
     el = time.perf_counter() - t0
-    el = mdist.max_over_ranks(el, dev)
+    el = mdist.max_over_ranks(el, tdev)
     # PCIe-inclusive variant (the reference's mlis_generate ends with host pixels): one more step that also copies the fp32
     # images of this rank to host memory; reported beside `value`, never as `value`
     fence()
     t1 = time.perf_counter()
     one_step(a.steps + a.warmup, want_images=True)
     fence()
-    el_host = mdist.max_over_ranks(time.perf_counter() - t1, dev)
+    el_host = mdist.max_over_ranks(time.perf_counter() - t1, tdev)
 
     if rank != 0:
         if world > 1:
@@ -435,13 +483,17 @@ def main():
         "config": {"workload": f"{a.workload}-{width}x{height}-euler_a-{a.denoise_steps}-cfg{a.cfg:g}-b{B}-{'tae' if a.tae else 'vae'}",
                    "batch_per_gpu": B, "global_batch": B * world, "unet_evals_per_image": nfe_per_img,
                    "tflop_per_image": round(flop_per_img / 1e12, 3), "hipgraph": bool(hipgraph),
-                   "parallelism": f"image-sharded x{world}, RCCL bcast cond + gather latents" if world > 1 else "single GPU",
+                   "parallelism": (f"image-sharded x{world}, " + ("RCCL bcast cond + gather latents" if a.transport == "rccl" else "HOST transport (gloo) bcast cond + gather latents: not the product path")) if world > 1 else "single GPU",
                    "weights": "synthetic seed 1234", "setup_s": round(t_setup, 1)},
         "job_tflops": round(value * flop_per_img / 1e12, 1),
         "job_frac_of_mfma_peak": round(value * flop_per_img / 1e12 / (world * PEAK_MFMA_F16_TFLOPS), 4),
         "unet_eval_ms": round(unet_ms / (a.steps * a.denoise_steps), 3),
         "images_per_s_with_d2h_of_fp32_images": round(B * world / el_host, 4),
     }
+    if world > 1:
+        out["transport"] = a.transport
+        out["rccl_ranks" if comm_kind.value == 0 else "host_transport_ranks"] = comm_ranks.value      # the communicator's world as the transport reports it (ncclCommCount)
+        out["gpus_visible"] = torch.cuda.device_count()
 
     roof, agg, ms = kernel_roofline(g, a.workload, B)
     if rank == 0 and roof.get("bound") == "mfma":
@@ -492,7 +544,7 @@ def main():
         # BASELINE.md section 3 / configs[0] name SD1.5 fp32 512x512 on the CPU: the same sample of that path
         if aux15:
             try:
-                out["cpu_baseline"]["sd15"] = cpu_record("sd1", 512, 512, a.cfg, a.denoise_steps, threads, a.cpu_decode_budget, a.cpu_timeout, aux15["flop_per_img"], aux15["decode_flops_b1"], "one SD1.5 512x512 image")
+                out["cpu_baseline"]["sd15"] = cpu_record("sd1", 512, 512, a.cfg, a.denoise_steps, threads, a.cpu_decode_budget, a.cpu_timeout, aux15["flop_per_img"], aux15["decode_flops_b1"], "one SD1.5 fp32 512x512 image (BASELINE configs[0])", wtype="f32")
             except Exception as e:
                 out["cpu_baseline"]["sd15"] = {"value": None, "sample": f"failed: {e}"}
     print(json.dumps(out), flush=True)

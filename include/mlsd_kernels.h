@@ -72,6 +72,7 @@ int mlsd_rccl_destroy(void* comm);
 typedef int (*mlsd_host_bcast_fn)(void* user, void* buf, size_t nbytes, int root);
 typedef int (*mlsd_host_allgather_fn)(void* user, const void* send, void* recv, size_t nbytes_per_rank);
 int mlsd_comm_host(void** comm, int world, int rank, mlsd_host_bcast_fn bcast, mlsd_host_allgather_fn all_gather, void* user);
+int mlsd_comm_count(void* comm, int* count, int* kind);   /* ranks as the transport reports them (ncclCommCount); kind: 0 = RCCL, 1 = host transport */
 int mlsd_rccl_bcast(void* comm, void* buf, size_t nbytes, int root, void* stream);
 int mlsd_rccl_all_gather(void* comm, const void* send, void* recv, size_t nbytes_per_rank, void* stream);
 

@@ -620,7 +620,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __builtin_amdgcn_s_barrier();
-            // (no acquire fence: 2048 waves invalidating their caches cost 15 us per launch; the partials are read with agent-scope loads instead)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // program order only: the partials below must not be hoisted above the poll / barrier by the compiler
+            // (no AGENT acquire fence: 2048 waves invalidating their caches cost 15 us per launch; the partials are read with agent-scope loads instead)
             // 5. all tiles' partials in tile order -> mean, 1 / sqrt(var + eps)
             float mean_r[NR], rstd_r[NR];
 #pragma unroll

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // program order only: the partner tiles' partials below are relaxed agent-scope loads and must not be hoisted above the poll / barrier
         float mean_r[NI], rstd_r[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (as above: the second GEMM's loads of the finished rows stay behind the poll / barrier)
             if (tid == 0) {
                 const unsigned old = __hip_atomic_fetch_add(cnt2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == (unsigned)(nbn - 1)) {

@@ -18,8 +18,9 @@ typedef int (*fn_destroy)(void*);
 typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);      // ncclBroadcast(send, recv, count, dtype, root, comm, stream)
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);      // ncclAllGather(send, recv, sendcount, dtype, comm, stream)
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(const void*, int*);                                           // ncclCommCount(comm, &count)
 
-struct Rccl { void* h; fn_uid uid; fn_init init; fn_destroy destroy; fn_bcast bcast; fn_allgather allgather; fn_errstr errstr; } g = {};
+struct Rccl { void* h; fn_uid uid; fn_init init; fn_destroy destroy; fn_bcast bcast; fn_allgather allgather; fn_errstr errstr; fn_count count; } g = {};
 
 int rccl_load()
 {
@@ -30,6 +31,7 @@ int rccl_load()
     g.uid = (fn_uid)dlsym(g.h, "ncclGetUniqueId"); g.init = (fn_init)dlsym(g.h, "ncclCommInitRank");
     g.destroy = (fn_destroy)dlsym(g.h, "ncclCommDestroy"); g.bcast = (fn_bcast)dlsym(g.h, "ncclBroadcast");
     g.allgather = (fn_allgather)dlsym(g.h, "ncclAllGather"); g.errstr = (fn_errstr)dlsym(g.h, "ncclGetErrorString");
+    g.count = (fn_count)dlsym(g.h, "ncclCommCount");
     if (!g.uid || !g.init || !g.destroy || !g.bcast || !g.allgather) { g.h = nullptr; return mlsd_set_error(-1, "RCCL: missing symbols"); }
     return 0;
 }
@@ -96,6 +98,20 @@ MLSD_API int mlsd_rccl_destroy(void* comm)
     int r = (c->kind == 0 && c->nccl && g.destroy) ? chk(g.destroy(c->nccl), "ncclCommDestroy") : 0;
     free(c);
     return r;
+}
+
+/* ranks of the communicator AS THE TRANSPORT REPORTS THEM: ncclCommCount for RCCL (what the launcher prints as `rccl_ranks`), the stated world of a host transport */
+MLSD_API int mlsd_comm_count(void* comm, int* count, int* kind)
+{
+    Comm* c = (Comm*)comm;
+    if (!c || !count) return mlsd_set_error(-1, "mlsd_comm_count: bad arguments");
+    if (kind) *kind = c->kind;
+    if (c->kind == 0) {
+        if (!g.count) return mlsd_set_error(-1, "RCCL: ncclCommCount missing");
+        return chk(g.count(c->nccl, count), "ncclCommCount");
+    }
+    *count = c->world;
+    return 0;
 }
 
 MLSD_API int mlsd_rccl_bcast(void* comm, void* buf, size_t nbytes, int root, void* stream)

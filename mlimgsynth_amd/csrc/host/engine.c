@@ -15,10 +15,13 @@
  *   - weights stay resident in HBM (288 GB) for the lifetime of the context instead of being re-uploaded per
  *     generate (mlblock.c:266-292) or per half-graph (--unet-split, unet.c:390-458).
  */
+#define _GNU_SOURCE       /* sched_getaffinity, CPU_COUNT */
 #include "mlblock_int.h"
 #include "mlimgsynth_amd.h"
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <unistd.h>
 
 int unet_denoise_build(UnetState* S);
@@ -318,31 +321,94 @@ MLB_API int mlis_amd_set_lmask(MLIS_AmdCtx* S, const float* lmask)
  * B x 4 x hw values are cut into ranges over host threads -- bit-identical by construction (round 5: the single-threaded draw of the FIRST noise, 4 x 65 536 Box-Muller values
  * in fp64 before any GPU work, was 12 ms of every SDXL batch-4 step). */
 typedef struct { const RngPhilox* rng; unsigned i0, i1; float* out; } DrawJob;
-static void* draw_worker(void* arg)
+enum { DRAW_MAXT = 16, DRAW_MIN_CHUNK = 8192 };      /* (a range per 8192 values at least, 16 threads at most) */
+
+/* CPUs this process is GRANTED, not the ones the machine has: scheduler affinity and the cgroup CPU quota -- the GPU box shows 256 logical CPUs and grants 16;
+ * on a pod with a quota of 1-4 a thread per online CPU would oversubscribe the very thread that enqueues the GPU work. */
+static int granted_cpus(void)
 {
-	const DrawJob *j = arg;
-	rng_philox_randn_range(j->rng, j->i0, j->i1, j->out);
+	long n = sysconf(_SC_NPROCESSORS_ONLN);
+	if (n < 1) n = 1;
+	cpu_set_t set;
+	if (!sched_getaffinity(0, sizeof(set), &set)) { const int a = CPU_COUNT(&set); if (a >= 1 && a < n) n = a; }
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");                      /* cgroup v2: "<quota|max> <period>" */
+	if (f) {
+		char q[32]; long per = 0;
+		if (fscanf(f, "%31s %ld", q, &per) == 2 && per > 0 && q[0] != 'm') { const long c = atol(q) / per; if (c >= 1 && c < n) n = c; else if (c < 1) n = 1; }
+		fclose(f);
+	} else {
+		long q = -1, per = 0;                                             /* cgroup v1 */
+		if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) { if (fscanf(f, "%ld", &q) != 1) q = -1; fclose(f); }
+		if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) { if (fscanf(f, "%ld", &per) != 1) per = 0; fclose(f); }
+		if (q > 0 && per > 0) { const long c = q / per; if (c >= 1 && c < n) n = c; else if (c < 1) n = 1; }
+	}
+	return (int)n;
+}
+
+/* A small PERSISTENT pool (process-wide, started at the first multi-range draw, alive until exit): a draw used to create and join up to 15 threads each time.  The caller
+ * publishes the job array, works on it itself, and returns when every range is done; a pool of zero workers (one granted CPU, or pthread_create failing) degrades to the
+ * caller running every range.  One draw at a time (call_mu): engines of different threads share the workers. */
+static struct {
+	pthread_mutex_t call_mu, mu; pthread_cond_t cv_work, cv_done;
+	const DrawJob *jobs; int n_jobs, next, done, n_workers, started;
+} g_draw = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0, 0 };
+
+static void* draw_pool_worker(void* arg)
+{
+	(void)arg;
+	pthread_mutex_lock(&g_draw.mu);
+	for (;;) {
+		while (g_draw.next >= g_draw.n_jobs) pthread_cond_wait(&g_draw.cv_work, &g_draw.mu);
+		const DrawJob *j = &g_draw.jobs[g_draw.next++];
+		pthread_mutex_unlock(&g_draw.mu);
+		rng_philox_randn_range(j->rng, j->i0, j->i1, j->out);
+		pthread_mutex_lock(&g_draw.mu);
+		if (++g_draw.done == g_draw.n_jobs) pthread_cond_signal(&g_draw.cv_done);
+	}
 	return NULL;
 }
+
+static void draw_run(const DrawJob* jobs, int nj)
+{
+	if (nj <= 1) { for (int j=0;j<nj;++j) rng_philox_randn_range(jobs[j].rng, jobs[j].i0, jobs[j].i1, jobs[j].out); return; }
+	pthread_mutex_lock(&g_draw.call_mu);
+	pthread_mutex_lock(&g_draw.mu);
+	if (!g_draw.started) {
+		g_draw.started = 1;
+		int want = granted_cpus(); if (want > DRAW_MAXT) want = DRAW_MAXT;
+		pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+		for (int k=1;k<want;++k) { pthread_t t; if (pthread_create(&t, &at, draw_pool_worker, NULL)) break; g_draw.n_workers++; }      /* (the caller is thread 0) */
+		pthread_attr_destroy(&at);
+	}
+	g_draw.jobs = jobs; g_draw.n_jobs = nj; g_draw.next = 0; g_draw.done = 0;
+	pthread_cond_broadcast(&g_draw.cv_work);
+	while (g_draw.next < g_draw.n_jobs) {
+		const DrawJob *j = &g_draw.jobs[g_draw.next++];
+		pthread_mutex_unlock(&g_draw.mu);
+		rng_philox_randn_range(j->rng, j->i0, j->i1, j->out);
+		pthread_mutex_lock(&g_draw.mu);
+		g_draw.done++;
+	}
+	while (g_draw.done < g_draw.n_jobs) pthread_cond_wait(&g_draw.cv_done, &g_draw.mu);
+	g_draw.jobs = NULL; g_draw.n_jobs = 0; g_draw.next = 0; g_draw.done = 0;
+	pthread_mutex_unlock(&g_draw.mu);
+	pthread_mutex_unlock(&g_draw.call_mu);
+}
+
 static void draw_all(MLIS_AmdCtx* S, float* hn, size_t per)
 {
-	enum { MAXT = 16, MIN_CHUNK = 8192 };      /* (a thread per 8192 values at least, 16 at most: creating them costs ~20 us each) */
 	static int ncpu = 0;
-	if (!ncpu) { long n = sysconf(_SC_NPROCESSORS_ONLN); ncpu = n < 1 ? 1 : (n > MAXT ? MAXT : (int)n); }
+	if (!ncpu) { const int n = granted_cpus(); ncpu = n > DRAW_MAXT ? DRAW_MAXT : n; }
 	const size_t total = (size_t)S->B * per;
-	int nt = (int)(total / MIN_CHUNK); if (nt > ncpu) nt = ncpu; if (nt < 1) nt = 1;
+	int nt = (int)(total / DRAW_MIN_CHUNK); if (nt > ncpu) nt = ncpu; if (nt < 1) nt = 1;
 	int per_img = (nt + S->B - 1) / S->B; if (per_img < 1) per_img = 1;       /* ranges never straddle images */
-	DrawJob jobs[MAX_BATCH * MAXT]; pthread_t th[MAX_BATCH * MAXT];
+	DrawJob jobs[MAX_BATCH * DRAW_MAXT];
 	int nj = 0;
 	for (int b=0;b<S->B;++b) for (int q=0;q<per_img;++q) {
 		const unsigned i0 = (unsigned)(per * q / per_img), i1 = (unsigned)(per * (q + 1) / per_img);
 		jobs[nj++] = (DrawJob){ &S->rng[b], i0, i1, hn + (size_t)b*per + i0 };
 	}
-	int started = 0;
-	for (int j=1;j<nj;++j) { if (pthread_create(&th[j], NULL, draw_worker, &jobs[j])) break; started = j; }
-	draw_worker(&jobs[0]);
-	for (int j=started+1;j<nj;++j) draw_worker(&jobs[j]);                     /* (threads that could not be created: their ranges run here) */
-	for (int j=1;j<=started;++j) pthread_join(th[j], NULL);
+	draw_run(jobs, nj);
 	for (int b=0;b<S->B;++b) S->rng[b].offset++;
 }
 

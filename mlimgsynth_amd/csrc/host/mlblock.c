@@ -1240,16 +1240,18 @@ static void wire_ln_fold(MLCtx* C)
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
 		if (!pass) {
-			if (!need_max && !any_splitk) return;
+			/* (every way out of pass 0 still reaches restore_unfolded_promotions: a producer that pass 0 moved to the 128x160 kernel for a fold that then does not
+			 * happen -- nothing to fold, or the counter / workspace allocation failed -- gets the table's tile back) */
+			if (!need_max && !any_splitk) break;
 			if (!need_max) continue;
 			if (!C->ln_cnt) {
-				if (mlsd_malloc((void**)&C->ln_cnt, LN_CNT_WORDS * 4)) return;
-				if (mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream) || mlsd_stream_sync(C->stream)) return;
+				if (mlsd_malloc((void**)&C->ln_cnt, LN_CNT_WORDS * 4)) break;
+				if (mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream) || mlsd_stream_sync(C->stream)) break;
 			}
 			if (C->ln_ws_bytes < need_max) {
 				if (C->ln_ws) { mlsd_free(C->ln_ws); C->mem_compute -= C->ln_ws_bytes; }
 				C->ln_ws = NULL; C->ln_ws_bytes = 0;
-				if (mlsd_malloc((void**)&C->ln_ws, need_max)) return;
+				if (mlsd_malloc((void**)&C->ln_ws, need_max)) break;
 				C->ln_ws_bytes = need_max; C->mem_compute += need_max;
 			}
 		}

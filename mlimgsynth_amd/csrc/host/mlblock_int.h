@@ -127,7 +127,11 @@ struct MLCtx {
 	MLCtxInfo info;
 };
 
-#define MLW_VBASE ((char*)0x600000000000ULL)      /* virtual weight addresses: never dereferenced, replaced by slab addresses at prep */
+/* virtual weight addresses: never dereferenced, replaced by slab addresses at prep.  NON-CANONICAL on purpose: wstream_setup scans every 8-byte word of every
+ * op's argument block for addresses left in this range, and a packed (int lo, int hi) pair whose high word is a plausible dimension must not look like one -- with the
+ * former base 0x6000'0000'0000 the pair (n_img, HW = 24576) of a 192 x 128 latent did, and prep of a streamed SD1.5 / SDXL plan at 1536 x 1024 failed.  The high word is
+ * now 0xFFFF6000 = -40960 as an int, a NaN as a float: no dimension, count, stride or scale. */
+#define MLW_VBASE ((char*)0xFFFF600000000000ULL)
 typedef struct MLWAlloc { size_t voff, bytes, moff; } MLWAlloc;     /* moff: offset in the host master (segment order, wstream_setup) */
 typedef struct MLWSeg { int op0, op1; int n; struct { size_t voff, bytes, soff, moff; } *r; size_t bytes; } MLWSeg;
 void* mlctx_walloc(MLCtx* C, size_t nbytes);      /* weight storage: device memory, or a virtual address when the plan streams its weights */

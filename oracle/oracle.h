@@ -53,6 +53,7 @@ ORACLE_API void orc_set_threads(int n);
 /* test switch (default 1): 0 disables the F16 rounding of conv/linear activation operands (see o_ops.c) */
 ORACLE_API void orc_set_act_rounding(int on);
 ORACLE_API void orc_set_trace(void (*cb)(const char* path, const struct OT* t));
+ORACLE_API void orc_exp_sub(float* x, int64_t n, float mx);   /* x[j] = exp(x[j] - mx), the 8-lane polynomial of orc_attention's softmax (test hook) */
 ORACLE_API void orc_set_linear_wtype(int type);   /* ORC_F16 (default) | ORC_F32: linear weights as an fp32 checkpoint gives them (src/mlimgsynth.c:1235-1236) */
 ORACLE_API int orc_get_linear_wtype(void);
 ORACLE_API int  orc_get_threads(void);

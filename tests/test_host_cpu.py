@@ -306,3 +306,13 @@ def test_weight_streaming_plan_in_the_dry_runtime(dry):
     assert infos[1] > infos[4]
     with pytest.raises(Exception):
         dry.Unet("tinyxl", 8, 8, 2, synth=False, stream_weights_mib=1, flags=8)       # MLB_F_HIPGRAPH
+
+
+@pytest.mark.parametrize("lw,lh", [(192, 128), (128, 192), (128, 128)])
+def test_weight_streaming_prep_at_sizes_whose_dimensions_look_like_addresses(dry, lw, lh):
+    """the prep-time scan for unpatched virtual weight addresses reads every 8-byte word of an op's arguments; a packed (n_img, HW) pair with
+    HW = 192 x 128 = 24576 = 0x6000 read as the old virtual base 0x6000'0000'0000 and prep of a streamed plan at 1536 x 1024 failed.  The base is non-canonical now."""
+    s = dry.Unet("sd1", lw, lh, 2, synth=False, stream_weights_mib=256)
+    nseg, per_eval, slab, host = s.ctx.streaming_info()
+    assert nseg >= 2 and per_eval == host
+    s.ctx.destroy()

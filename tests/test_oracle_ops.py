@@ -252,3 +252,32 @@ def test_linear_weight_type_follows_the_checkpoint():
     e = rel(ys[1], ys[0])
     print(f"tiny UNet, F16 against F32 linear weights: rel-L2 {e:.2e}")
     assert 1e-5 < e < T.EVAL
+
+
+def test_softmax_exponential_of_the_oracle_against_expf():
+    """the oracle -- the ground truth of the attention parity tests -- computes its softmax exponential with an 8-lane degree-7 polynomial instead of expf
+    (tail lanes of a row still use expf): held here against float64 exp over the whole input range [-87, 0], on -inf (masked keys) and below the cut-off, bound 2e-7 relative."""
+    import ctypes
+    L = O.L()
+    L.orc_exp_sub.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_float]
+    L.orc_exp_sub.restype = None
+    rng = np.random.default_rng(0)
+    for mx in (0.0, 3.25, -11.5):
+        t = np.concatenate([np.linspace(-87.0, 0.0, 200001), -rng.random(50000) * 87.0, -rng.random(50000) ** 4 * 5.0, [0.0, -1e-8, -86.99]]).astype(np.float32)
+        t = t[: (t.size // 8) * 8 + 5]                                   # 5 tail lanes: the scalar expf path of the same row
+        x = (t + np.float32(mx)).astype(np.float32)
+        want = np.exp((x.astype(np.float64) - np.float64(np.float32(mx))))
+        got = x.copy()
+        L.orc_exp_sub(got.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), got.size, mx)
+        live = (x - np.float32(mx)) >= -87.0
+        rel = np.abs(got[live].astype(np.float64) - want[live]) / want[live]
+        assert rel.max() < 2e-7, (mx, rel.max())
+        assert np.all(got[~live][: (got.size // 8) * 8] >= 0) and np.all(got[~live] < 2e-38)
+    dead = np.array([-np.inf, -1000.0, -88.0, -87.5, -np.inf, -200.0, -np.inf, -90.0, 0.0], np.float32)     # one 8-lane group of dead keys + a live tail lane
+    L.orc_exp_sub(dead.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), dead.size, 0.0)
+    assert np.array_equal(dead[:8], np.zeros(8, np.float32)) and dead[8] == 1.0
+    # a softmax row is sum-normalised afterwards: the polynomial and expf lanes of one row agree to the same bound
+    row = (-rng.random(77) * 30).astype(np.float32)
+    a = row.copy(); L.orc_exp_sub(a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size, 0.0)
+    b = np.exp(row.astype(np.float64))
+    assert np.abs(a / a.sum() - b / b.sum()).max() / (b / b.sum()).max() < 3e-7

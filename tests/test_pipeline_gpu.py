@@ -268,6 +268,38 @@ def test_bench_two_gpu_smoke_when_available():
     assert line["n_gpus"] == 2 and line["value"] > 0
 
 
+@pytest.mark.timeout(900)
+def test_bench_world2_branch_on_one_gpu_over_the_host_transport():
+    """bench.py's `world > 1` branch -- communicator + gather sizing, the fence, max-over-ranks, the rank != 0 exit -- executed on the 1-GPU box: two
+    ranks launched exactly as the driver launches them (torch.distributed.run, one process per rank), both on cuda:0, the library's communicator over the host transport
+    (RCCL refuses two ranks on one device).  The 8-GPU run of the driver then exercises only the RCCL calls themselves."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--transport", "host", "--workload", "tiny",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=800, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])          # torch.distributed.run returns non-zero when ANY rank does
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                                      # rank 0 alone prints
+    d = json.loads(lines[0])
+    B = d["config"]["batch_per_gpu"]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * B * 1e3 / d["ms_per_step"]) / d["value"] < 0.02     # value = the units ALL ranks processed / the max-over-ranks time
+    assert d["transport"] == "host" and d["host_transport_ranks"] == 2 and "rccl_ranks" not in d
+    assert "HOST transport" in d["config"]["parallelism"] and d["roofline"]["frac"] > 0
+    # a rank that fails must end the job non-zero (no re-exec, no hang): --gpus disagrees with the launched world
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port + 1 if port < 65000 else port - 1), os.path.join(root, "bench.py"), "--gpus", "3", "--transport", "host",
+                          "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0
+
+
 def test_bench_json_contract_on_tiny_workload():
     """bench.py prints ONE JSON line with the driver's contract keys plus the `roofline` and `cpu_baseline` objects (run on the
     tiny workload so that the CPU leg takes a second); values are sane and the metric / config follow BASELINE.json's wording"""
@@ -320,6 +352,11 @@ def test_bench_line_carries_the_whole_baseline_metric():
         assert e["config"].startswith(cfg) and e["value"] > 0 and e["unit"] == "images/s" and e["ms_per_step"] > 0
         assert abs(e["value"] - (4 if key == "sdxl_tae" else 1) * 1e3 / e["ms_per_step"]) / e["value"] < 0.02
         assert e["roofline"]["frac"] > 0 and 0 < e["unet_eval_mfma"]["frac_of_mfma_peak"] < 1
+        # the dominant label of the SDXL b4 / SD1.5 b1 plans is a key of the NEWEST committed PMC summaries (profiles/r<N>_*_pmc_{traffic,mfma}.json):
+        # `traffic` can only be null again if somebody breaks tools/kernel_labels.py AND tests/test_profile_labels_cpu.py
+        r_ = e["roofline"]
+        assert r_["traffic"] and r_["traffic"] > 0 and r_["traffic_source"].startswith("profiles/r") and r_["mfma_busy_frac_pmc"], (key, r_["kernel"], r_["traffic_source"])
+        assert r_["traffic"] >= 0.5 * r_["algorithmic_bytes_per_launch"], (key, r_)
     assert d["sdxl_tae"]["config"].endswith("-tae") and d["sd15"]["config"].endswith("-vae")
     # round 4: one rank's share of configs[3] (batch 8 per GPU) and configs[4] with the weights streamed (--unet-split)
     b8, sp = d["sdxl_b8"], d["sdxl_tae_split"]
@@ -330,4 +367,4 @@ def test_bench_line_carries_the_whole_baseline_metric():
     assert ws["unet_params_on_device_mib"] < 2500 and sp["value"] < d["sdxl_tae"]["value"]          # PCIe-bound at batch 4: never faster than the resident plan
     assert d["sd15"]["tile_table_misses"] == 0 and d["cpu_baseline"]["host_cpus"] >= d["cpu_baseline"]["cores"]
     c15 = d["cpu_baseline"]["sd15"]
-    assert c15["kind"] == "port" and c15["value"] > 0 and c15["s_per_unet_eval"] > 0 and "SD1.5" in c15["sample"]
+    assert c15["kind"] == "port" and c15["value"] > 0 and c15["s_per_unet_eval"] > 0 and "SD1.5" in c15["sample"] and c15["linear_weights"] == "f32" and d["sd15"]["value"] > 50 * c15["value"]       # (the GPU / CPU ratio asserted on a workload that is not launch-bound -- measured ~300 x;) configs[0] is the fp32 checkpoint: fp32 linear weights in the CPU sample (src/mlimgsynth.c:1235-1236)

@@ -7,7 +7,7 @@ matrix pipe was executing (gfx94x MfmaUtil formula; ROCm 7.2 ships no gfx950 der
 f16_tflops_from_mops = SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 FLOP / kernel duration (a MOPS unit = 512 FLOP)."""
 import csv, json, sys, collections
 sys.path.insert(0, __import__("os").path.dirname(__file__))
-from pmc_summary import label
+from kernel_labels import label
 
 out, f = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
