@@ -162,6 +162,18 @@ typedef struct mlsd_gemm_args {
 	const void* chain_W; int64_t chain_ldb;
 	const float* chain_bias;
 	void* chain_C16; int64_t chain_ldc16;
+	/* CROSS ATTENTION at the end of its q projection (round 6; the 128 x 320 ping-pong tile = 128 query rows x 5 heads of 64).  When xa_k is set and
+	 * mlsd_gemm_xattn_fused(args) == 1 the launch does NOT store the projection: a tile's q (rounded to fp16 exactly as the unfused launch's C16 would hold it) stays in LDS
+	 * and the launch ends with  xa_out[m][64 h + d] = fp16( softmax_key( q_h[m] . K_h[key] / sqrt(64) ) . V_h )  over the xa_Tk <= 80 keys of row m's image -- what
+	 * mlb_nn_linear (q_proj) + ggml_nn_attention compute at src/mlblock_nn.c:200-223, src/ggml_extend.c:200-222 for the text context (77 keys).  One dispatch and one
+	 * round trip of q through HBM fewer per cross attention (70 per SDXL evaluation).  Operands: xa_k = K [n_img * xa_Tk][xa_ldk] fp16 (key r of image b in row
+	 * b * xa_Tk + r; the N columns are the projection's: head h = columns 64 h ..); xa_vt = V TRANSPOSED and zero padded, [n_img][N][96] fp16 (mlsd_xattn_pack_vt, run
+	 * once per conditioning); xa_Tq = query rows per image (a multiple of 128: a tile never straddles two images).  Needs N % 320 == 0, M % 128 == 0, fp16 arithmetic
+	 * as the unfused pair (fp16 q, K, V, P; fp32 accumulation and softmax).  mlsd_gemm FAILS when xa_k is set and the launch cannot honour it. */
+	const void* xa_k; int64_t xa_ldk;
+	const void* xa_vt;
+	void* xa_out; int64_t xa_ldo;
+	int xa_Tq, xa_Tk;
 } mlsd_gemm_args;
 
 int mlsd_gemm(const mlsd_gemm_args* a, void* stream);
@@ -172,6 +184,10 @@ int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
 /* 1 if this launch (chain_* fields set) also runs the Linear that consumes its LayerNorm: see mlsd_gemm_args.chain_W */
 int mlsd_gemm_chained(const mlsd_gemm_args* a);
+/* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: see mlsd_gemm_args.xa_k.  MLSD_XATTN=0 in the environment answers 0 (A/B). */
+int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a);
+/* vt[b][n][key] = v[b * Tk + key][n] for key < Tk, 0 for Tk <= key < 96: the V operand of the fused launch (fp16; v row stride ldv halfs; N columns; Tk <= 96) */
+int mlsd_xattn_pack_vt(const void* v, int64_t ldv, int n_img, int Tk, int N, void* vt, void* stream);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
 /* 1 if this launch (gn_* fields set) ends its split-K reduce pass with the GroupNorm of its output (see mlsd_gemm_args.gn_y16) */
 int mlsd_gemm_gn_fused(const mlsd_gemm_args* a);
@@ -194,6 +210,10 @@ void mlsd_gemm_set_splitk_inline(int on);
  * builds with EXPERIMENTS=1, and off unless switched on here / by MLSD_SPLITK_PAR=1. */
 void mlsd_gemm_set_splitk_parallel(int on);
 int mlsd_gemm_splitk_parallel(const mlsd_gemm_args* a);   /* 1 if this launch would do so (an in-launch hand-off: mlctx_handoff_check covers it) */
+/* != 0 if mlsd_gemm runs this launch on the small-Cout streaming convolution (tile variant 31, conv_smalln.hip): 3x3, stride 1, pad 1, Cout <= 16, Cin 64 / 128, fp32 output + bias --
+ * the KL-VAE decoder's conv_out (src/vae.c:163-165) and TAESD's last layer (src/tae.c:88-89).  MLSD_CONV_SMALLN=0 in the environment keeps the implicit-GEMM tile (A/B). */
+int mlsd_conv_smalln_eligible(const mlsd_gemm_args* a);
+void mlsd_conv_smalln_set(int ring_rows, int strip_rows);   /* diagnostics: input-row ring depth (4..6) and strip height of the next launches */
 size_t mlsd_gemm_streamk_ws_bytes(void);   /* workspace of a stream-K launch (slabs); the flags are 256 x 4 bytes, zeroed once */
 void mlsd_gemm_set_cus(int n);      /* CUs a persistent GEMM launch occupies (default 256; 128 for half-chip partitions) */
 void mlsd_gemm_set_trace(void* buf);        /* diagnostics: device buffer of 256 x 8 uint64 cycle stamps filled by the ping-pong kernels (NULL = off) */

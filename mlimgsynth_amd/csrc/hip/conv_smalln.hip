@@ -79,15 +79,19 @@ __global__ __launch_bounds__(256, 2) void conv_smalln_kernel(const SNP p)
         const int pxl = t * PPI + lane / CH, cs = lane % CH;
         d_pxl[t] = pxl; d_coff[t] = (cs ^ swz(pxl)) * 8;
     }
+    const uintptr_t zaddr = (uintptr_t)zsrc;
     auto issue_row = [&](int yi, int slot) {
         const bool rowok = (unsigned)yi < (unsigned)p.H;
-        const _Float16* rowp = Aimg + (long)yi * p.W * p.lda;
+        const uintptr_t rowa = (uintptr_t)(Aimg + (long)yi * p.W * p.lda);
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
             const int gx = x0 - 2 + d_pxl[t];
             const bool ok = rowok && (unsigned)gx < (unsigned)p.W && d_pxl[t] >= 1 && d_pxl[t] <= 18;
-            const _Float16* src = ok ? rowp + (long)gx * p.lda + d_coff[t] : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            // ONE instruction per piece whatever the lanes need: the address is blended arithmetically (as a branch the compiler emitted two DMA instructions per piece,
+            // one per side, and the counted waits below count instructions)
+            const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+            const uintptr_t addr = ((rowa + ((uintptr_t)((long)gx * p.lda + d_coff[t]) << 1)) & m) | (zaddr & ~m);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
                                              (__attribute__((address_space(3))) void*)(ring + slot * ROWB + t * 1024), 16, 0, 0);
         }
     };
@@ -96,13 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv_smalln_kernel(const SNP p)
 #pragma unroll
     for (int r = 0; r < NR - 1; ++r) issue_row(y0 - 1 + r, r);
     const int wi = lane & 15, kc = lane >> 4;
+    const int wrow = wi < p.N ? wi : p.N - 1;
     f16x8 wf[9][KS];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            f16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (wi < p.N) w = *reinterpret_cast<const f16x8*>(p.Wt + (long)wi * p.ldb + t * CIN + 32 * s + 8 * kc);
+            f16x8 w = *reinterpret_cast<const f16x8*>(p.Wt + (long)wrow * p.ldb + t * CIN + 32 * s + 8 * kc);
+            if (wi >= p.N) w = f16x8{0, 0, 0, 0, 0, 0, 0, 0};      // (a select, not a branch: lanes of absent output channels read the last row and drop it)
             wf[t][s] = w;
         }
     float bv[4];
@@ -136,13 +141,17 @@ __global__ __launch_bounds__(256, 2) void conv_smalln_kernel(const SNP p)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const unsigned char* rowb = ring + rs * ROWB;
+            // the 3 x KS fragments of an input row are read as one batch (12 ds_read_b128 in flight), then consumed: left to itself the compiler waits for every pair
+            f16x8 px[3][KS];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const f16x8 px = *reinterpret_cast<const f16x8*>(rowb + foff[kw][s]);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kh * 3 + kw][s], px, acc, 0, 0, 0);
-                }
+                for (int s = 0; s < KS; ++s) px[kw][s] = *reinterpret_cast<const f16x8*>(rowb + foff[kw][s]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kh * 3 + kw][s], px[kw][s], acc, 0, 0, 0);
             if (++rs == NR) rs = 0;
         }
         if (col_ok) {
@@ -164,7 +173,7 @@ bool sn_on()
     if (on < 0) { const char* e = getenv("MLSD_CONV_SMALLN"); on = (e && *e == '0') ? 0 : 1; }      // A/B switch: MLSD_CONV_SMALLN=0 keeps the implicit-GEMM tile
     return on != 0;
 }
-int g_sn_nr = 5, g_sn_tr = 32;
+int g_sn_nr = 0, g_sn_tr = 0;      // 0 = automatic (below); tools/conv_smalln_bench.py sets them
 
 }  // namespace
 
@@ -181,8 +190,8 @@ extern "C" MLSD_API int mlsd_conv_smalln_eligible(const mlsd_gemm_args* a)
 /* diagnostics (tools/conv_smalln_bench.py): ring depth 4..6 and strip height of the next launches */
 extern "C" MLSD_API void mlsd_conv_smalln_set(int ring_rows, int strip_rows)
 {
-    if (ring_rows >= 4 && ring_rows <= 6) g_sn_nr = ring_rows;
-    if (strip_rows >= 1 && strip_rows <= 4096) g_sn_tr = strip_rows;
+    g_sn_nr = (ring_rows >= 4 && ring_rows <= 6) ? ring_rows : 0;
+    g_sn_tr = (strip_rows >= 1 && strip_rows <= 4096) ? strip_rows : 0;
 }
 
 extern "C" int mlsd_conv_smalln(const mlsd_gemm_args* a, void* stream)
@@ -191,11 +200,17 @@ extern "C" int mlsd_conv_smalln(const mlsd_gemm_args* a, void* stream)
     SNP p;
     p.A = (const _Float16*)a->A; p.lda = a->lda; p.Wt = (const _Float16*)a->W_; p.ldb = a->ldb; p.bias = a->bias; p.C32 = a->C32; p.ldc32 = a->ldc32;
     p.n_img = a->n_img; p.H = a->H; p.W = a->W; p.N = a->N;
-    p.TR = g_sn_tr < a->H ? g_sn_tr : a->H;
-    p.tiles_x = (a->W + 63) / 64; p.tiles_y = (a->H + p.TR - 1) / p.TR;
+    p.tiles_x = (a->W + 63) / 64;
+    /* strip height: every strip re-reads 2 halo rows and pays one pipeline fill, so the tallest strip that still leaves >= 512 blocks (two per CU) -- measured on SDXL b4
+     * (4 x 1024 x 1024 x 128): 240 us at 128 rows (512 blocks), 246 at 64, 254 at 16; on one 512 x 512 image: 21 us at 16 rows (256 blocks), 31 at 32, 96 at 128
+     * (profiles/r6_conv_smalln_bench.txt) */
+    int tr = g_sn_tr;
+    if (tr <= 0) { tr = 128; while (tr > 8 && (long)p.tiles_x * ((a->H + tr - 1) / tr) * a->n_img < 512) tr >>= 1; }
+    p.TR = tr < a->H ? tr : a->H;
+    p.tiles_y = (a->H + p.TR - 1) / p.TR;
     const long nblk = (long)p.tiles_x * p.tiles_y * p.n_img;
     if (nblk > 0x7fffffffL) return mlsd_set_error(-1, "mlsd_conv_smalln: grid too large");
-    const int nr = g_sn_nr;
+    const int nr = g_sn_nr ? g_sn_nr : (a->Cin == 128 ? 4 : 5);      /* ring depth: 8 waves per CU one row ahead at 256-byte pixels, two rows ahead at 128-byte pixels (measured) */
     auto go = [&](auto kfn, size_t lds) -> int {
         static thread_local const void* attr_done[8]; static thread_local int n_done = 0;      // (one host call per kernel, not per launch)
         bool seen = false;

@@ -166,9 +166,36 @@ inline int nblocks(long n, int per = 256, int cap = 4096)
     return (int)b;
 }
 
+// V operand of the cross attention that ends its q projection (gemm_pp.hpp PP_EPI_XATTN): vt[b][n][key] = v[b Tk + key][n], keys Tk .. 95 zero.  Runs once per
+// conditioning (the context's K / V projections are step-invariant).  One thread per (b, n, 8 keys): 16-byte stores; the strided reads hit L2 (616 x 2 N bytes per layer).
+__global__ __launch_bounds__(256) void xattn_pack_vt_kernel(const _Float16* __restrict__ v, long ldv, int n_img, int Tk, int N, _Float16* __restrict__ vt)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)n_img * N * 12;
+    if (idx >= total) return;
+    const int kc = (int)(idx % 12);
+    const long bn = idx / 12;
+    const int n = (int)(bn % N), b = (int)(bn / N);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int key = kc * 8 + e;
+        o[e] = key < Tk ? v[((long)b * Tk + key) * ldv + n] : (_Float16)0.f;
+    }
+    *reinterpret_cast<f16x8*>(vt + bn * 96 + kc * 8) = o;
+}
+
 }  // namespace
 
 extern "C" {
+
+MLSD_API int mlsd_xattn_pack_vt(const void* v, int64_t ldv, int n_img, int Tk, int N, void* vt, void* stream)
+{
+    if (!v || !vt || n_img <= 0 || Tk <= 0 || Tk > 96 || N <= 0 || ((uintptr_t)vt & 15)) return mlsd_set_error(-1, "mlsd_xattn_pack_vt: bad arguments");
+    const long total = (long)n_img * N * 12;
+    hipLaunchKernelGGL(xattn_pack_vt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)v, (long)ldv, n_img, Tk, N, (_Float16*)vt);
+    return mlsd_check_launch("xattn_pack_vt");
+}
 
 MLSD_API int mlsd_nchw_to_nhwc_f16(const float* src, int n_src, int C, int HW, void* dst, int n_dst, int Cpad,
                                    const float* scale, float scale0, int mode, void* stream)

@@ -85,6 +85,12 @@ struct GemmP {
     float* ln_ws;
     unsigned* ln_cnt;
     int gn_G, gn_hw, gn_silu;   // splitk_reduce_gn: groups, rows per image, SiLU (gamma / beta / eps / output in the ln_* fields)
+    // cross attention at the end of its q projection (gemm_pp.hpp PP_EPI_XATTN): K [n_img * Tk][ldk], V^T [n_img][N][96], output, rows per image, keys, log2(e) / sqrt(64)
+    const _Float16 *xa_k, *xa_vt;
+    _Float16* xa_out;
+    long xa_ldk, xa_ldo;
+    int xa_Tq, xa_Tk;
+    float xa_sc;
 };
 
 // LDS tile: rows of BK halfs (128 B at BK=64, 64 B at BK=32); the 16-byte chunk c of row r lives at slot
@@ -1178,9 +1184,27 @@ bool ln_eligible(const mlsd_gemm_args* a)
     return (one_round || whole_rounds) && a->M / 128 <= 256 && pp_eligible(a, 128, 320) && device_cus() >= g_gemm_ncu;      // (counters: 16 words per (row block, wave row) in 8192 words)
 }
 
+// launches that END with the cross attention of the q they project (gemm_pp.hpp PP_EPI_XATTN): linear, whole 128 x 320 tiles (5 heads of 64), fp16 "output" that is never
+// stored, K / V^T / output operands, a tile inside one image, at most 77 keys held in LDS.  MLSD_XATTN=0 switches the form off (the plan builder asks mlsd_gemm_xattn_fused).
+bool xattn_on()
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MLSD_XATTN"); on = (e && *e == '0') ? 0 : 1; }
+    return on != 0;
+}
+bool xattn_eligible(const mlsd_gemm_args* a)
+{
+    if (!a->xa_k || !a->xa_vt || !a->xa_out || !xattn_on() || a->conv || a->act != MLSD_ACT_NONE || a->C32 || a->resid || a->rowbias || a->bias_m || a->colstats) return false;
+    if (a->ln_y16 || a->gn_y16 || a->chain_W || (a->M % 128) || (a->N % 320) || (a->K & 63) || a->K < 192) return false;
+    if (a->xa_Tq <= 0 || (a->xa_Tq % 128) || (a->M % a->xa_Tq) || a->xa_Tk < 1 || a->xa_Tk > 77) return false;
+    if ((a->xa_ldk & 7) || (a->xa_ldo & 7) || ((uintptr_t)a->xa_k & 15) || ((uintptr_t)a->xa_vt & 15) || ((uintptr_t)a->xa_out & 15) || (a->bias && ((uintptr_t)a->bias & 15))) return false;
+    return g_gemm_epi != 1 && !(g_gemm_dbg & 2);
+}
+
 // which epilogue body a ping-pong launch of these arguments uses (gemm_pp.hpp PP_EPI_*)
 int pp_epilogue_kind(const mlsd_gemm_args* a, int BN)
 {
+    if (a->xa_k && BN == 320 && xattn_eligible(a)) return PP_EPI_XATTN;
     if ((g_gemm_dbg & 2) || a->bias_m) return PP_EPI_GENERIC;
     const bool c16_wide = a->C16 && !(a->ldc16 & 7) && !((uintptr_t)a->C16 & 15);     // the fp16 fast paths store 16 bytes per lane
     if (a->act == MLSD_ACT_NONE) {
@@ -1252,6 +1276,14 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS + 4096, st, p);
         return mlsd_check_launch("gemm_pp_kernel(+LN)");
     };
+    auto go_xa = [&](auto kfn) -> int {              // cross attention at the end: ONE tile per block (the epilogue re-uses the ring's LDS), K + q images = 138 KB
+        constexpr int XLDS = 57344 + 128 * 656;
+        p.xa_k = (const _Float16*)a->xa_k; p.xa_vt = (const _Float16*)a->xa_vt; p.xa_out = (_Float16*)a->xa_out; p.xa_ldk = a->xa_ldk; p.xa_ldo = a->xa_ldo;
+        p.xa_Tq = a->xa_Tq; p.xa_Tk = a->xa_Tk; p.xa_sc = 1.4426950408889634f * 0.125f;      /* log2(e) / sqrt(64) */
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS));
+        hipLaunchKernelGGL(kfn, dim3(ntiles), block, XLDS, st, p);
+        return mlsd_check_launch("gemm_pp_kernel(+attention)");
+    };
     // the epilogue the kernel is built with (gemm_pp.hpp): the bulk launches of the UNet / VAE have no activation in the GEMM
     const int epi = pp_epilogue_kind(a, BN);
     p.colstats = (epi == PP_EPI_F32_STATS || epi == PP_EPI_F32_RES_STATS) ? a->colstats : nullptr;
@@ -1301,6 +1333,9 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     case PP_EPI_GEGLU16:
         if constexpr (BN == 256) return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GEGLU16, false, NPH, SCH>);
         break;
+    case PP_EPI_XATTN:
+        if constexpr (BM == 128 && BN == 320 && NPH == 4 && SCH == 0) return go_xa(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_XATTN, false, 4, 0>);
+        return mlsd_set_error(-1, "mlsd_gemm: cross attention at the end of a projection runs on the four-phase 128x320 tile only");
     default: break;
     }
     return go(gemm_pp_kernel<BM, BN, CB0, CB1, RESBATCH, false, PP_EPI_GENERIC, false, NPH, SCH>);
@@ -1386,6 +1421,8 @@ static int mlsd_gemm_w4(const mlsd_gemm_args*, int, void*, int) { return -1; }
 
 extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu);     // gemm_tt.hip: 128 x 160 tile, 4 waves, two blocks per CU (variant 30)
 extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu);
+extern "C" int mlsd_conv_smalln_eligible(const mlsd_gemm_args* a);                // conv_smalln.hip: 3x3 convolutions with Cout <= 16 as a streaming op (variant 31)
+extern "C" int mlsd_conv_smalln(const mlsd_gemm_args* a, void* stream);
 // CUs the 128 x 160 kernel may count on for launches whose tiles wait for each other (LayerNorm endings: all partner tiles resident together): the stream's budget, and not
 // more than the device has (a partitioned device); the dry runtime has no device and plans for the full part
 static int tt_ncu() { if (mlsd_runtime_is_dry()) return g_gemm_ncu; const int c = device_cus(); return c < g_gemm_ncu ? c : g_gemm_ncu; }
@@ -1425,12 +1462,16 @@ const Variant kVariants[] = {
     {"skinny128x64", 128, 64, 512},     // 29: M <= 128 weight streaming (gemm_skinny.hpp): all rows in one block, weights global -> registers, 7 K steps in flight, K slices + fixed-order reduce
     {"128x160x64tt", 128, 160, 512},    // 30: TWO tiles in flight per CU (gemm_tt.hip, round 5): 4-wave blocks, two resident per CU in two priority classes, so that one tile's residual
                                         //     read / output burst runs under the other tile's K loop -- the single-round 8192 x 1280 outputs of the SDXL transformer blocks
+    {"conv3x3n16", 64, 16, 512},        // 31: 3x3 convolutions with Cout <= 16 over full-resolution maps (the VAE / TAESD output layers) as a STREAMING op (conv_smalln.hip, round 6): every wave walks
+                                        //     a 16-pixel strip with a ring of input rows in its own LDS slice, weights in registers, one pass over the activations
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int pick_variant(const mlsd_gemm_args* a)
 {
     if (g_gemm_variant >= 0 && g_gemm_variant < kNumVariants) return g_gemm_variant;
+    if (a->xa_k && xattn_eligible(a) && pp_eligible(a, 128, 320)) return 18;      // the one tile that ends with the attention
+    if (mlsd_conv_smalln_eligible(a)) return 31;      // a SHAPE rule above the table (A/B: MLSD_CONV_SMALLN=0): no GEMM tile is the right tool for Cout = 3
     if (a->tile_variant > 0 && a->tile_variant <= kNumVariants) return a->tile_variant - 1;
     if (a->M <= 64) return 1;
     // 128x128 (2 blocks/CU) vs 256x128 (1 block/CU): the bigger tile moves 25 % fewer operand bytes per
@@ -1462,7 +1503,7 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (a->M != a->n_img * a->OH * a->OW) return mlsd_set_error(-1, "mlsd_gemm: conv M mismatch");
     }
     if (a->act == MLSD_ACT_GEGLU && (a->N & 63)) return mlsd_set_error(-1, "mlsd_gemm: GEGLU needs N %% 64 == 0");
-    if (!a->C32 && !a->C16) return mlsd_set_error(-1, "mlsd_gemm: no output");
+    if (!a->C32 && !a->C16 && !a->xa_k) return mlsd_set_error(-1, "mlsd_gemm: no output");
     if (a->colstats && a->colstats_rows > 0 && mlsd_gemm_colstats_rows(a) != a->colstats_rows)
         return mlsd_set_error(-1, "mlsd_gemm: a GroupNorm was planned on this launch's column statistics (blocks of %d rows) but the launch "
                               "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
@@ -1470,6 +1511,8 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a GroupNorm for this launch's reduce pass but the launch would not run it (tile or K-split settings changed after planning)");
     if (a->chain_W && !mlsd_gemm_chained(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped the launch of a consuming Linear for this launch's second GEMM but the launch would not run it (tile settings changed after planning)");
+    if (a->xa_k && !mlsd_gemm_xattn_fused(a))
+        return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a cross attention for this projection's launch but the launch would not run it (tile settings changed after planning)");
     if (a->ln_y16 && !mlsd_gemm_ln_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a LayerNorm for this launch's *_LN epilogue but the launch would not run it (tile or epilogue settings changed after planning)");
     hipStream_t st = (hipStream_t)stream;
@@ -1498,6 +1541,9 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
         if (pp_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true>(a, st);      // anything else: the ping-pong tile nearest in shape
         if (a->act == MLSD_ACT_GEGLU) return mlsd_set_error(-1, "mlsd_gemm: the 128x320 tiles do not support GEGLU");
         return launch<128, 320, 64, 4, 2, 2>(a, st);
+    case 31:
+        if (mlsd_conv_smalln_eligible(a)) return mlsd_conv_smalln(a, st);
+        return launch<128, 128, 64, 2, 2, 2>(a, st);
     case 28:
         if (sk_eligible(a, 128, 320)) return launch_pp<128, 320, 3, 2, true, true>(a, st);
         [[fallthrough]];
@@ -1681,6 +1727,13 @@ MLSD_API int mlsd_gemm_chained(const mlsd_gemm_args* a)
     return (e == 6 || e == 7) ? 1 : 0;
 }
 
+/* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: the plan builder then records no attention launch */
+MLSD_API int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a)
+{
+    if (!a || !a->xa_k || g_gemm_variant >= 0) return 0;
+    return (xattn_eligible(a) && pp_eligible(a, 128, 320) && pick_variant(a) == 18) ? 1 : 0;
+}
+
 MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
 {
     static thread_local char buf[64];
@@ -1693,6 +1746,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
         return buf;
     }
     if (v == 30 && !mlsd_gemm_tt_eligible(a, tt_ncu())) v = 18;
+    if (v == 31 && !mlsd_conv_smalln_eligible(a)) v = 0;
     if (v == 26 && !mlsd_gemm_w4_eligible(a, 0)) v = 17;
     if (v == 27 && !mlsd_gemm_w4_eligible(a, 1)) v = 18;
     if ((v == 17 || v == 21) && !pp_eligible(a, 256, 256)) v = 9;
@@ -1706,6 +1760,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     const int bk = strstr(kVariants[v].name, "x32s") ? 32 : 64;
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : (mlsd_gemm_gn_fused(a) ? "+groupnorm" : ""), ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
+    else if (mlsd_gemm_xattn_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+attention>", kVariants[v].name);      /* the q projection of a cross attention that ends with it */
     else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm%s>", kVariants[v].name, mlsd_gemm_chained(a) ? "+linear" : "");      /* the launch ends with the LayerNorm of its output (and runs the Linear that consumes it) */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;

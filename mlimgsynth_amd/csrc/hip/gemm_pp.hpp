@@ -100,7 +100,18 @@ __device__ __forceinline__ PPTile pp_tile_plain(const GemmP& p, int bid)
 // per-row bias, any output combination: decided per element at run time), 1 = fp16 out, 2 = fp32 out, 3 = fp32 out + fp32
 // residual, 4 = GEGLU fp16 out (256-wide tile); 1..4: no activation / per-row bias, straight-line code (see epi_fast).
 enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, PP_EPI_GEGLU16 = 4, PP_EPI_F32_STATS = 5, PP_EPI_F32_RES_STATS = 6,
-       PP_EPI_F32_LN = 7, PP_EPI_F32_RES_LN = 8 };
+       PP_EPI_F32_LN = 7, PP_EPI_F32_RES_LN = 8, PP_EPI_XATTN = 9 };
+// XATTN (round 6, 128 x 320 tile = 128 query rows x 5 heads of 64, one output tile per block): the launch is the q projection of a cross attention and ENDS with that
+// attention (mlsd_gemm_args.xa_*).  Nothing of q reaches HBM.  After the K loop (LDS map: K [77][656 B] at 0, q [128][656 B] at 50 KB; V^T [320][208 B] later over q):
+//   1. the tail stages of the ring are drained (they target the LDS this epilogue re-uses), the image's K rows of the tile's 320 columns go global -> LDS by LDS-DMA;
+//   2. every wave rounds its 64 x 80 accumulators to fp16 (the rounding point of the unfused launch's C16) and writes them into the q image (80-column wave tiles
+//      straddle the 64-column heads: q changes hands through LDS, 80 KB written and read once);
+//   3. wave w takes query rows 16 w .. 16 w + 15 of all 5 heads: its 10 q fragments (B operands) go to registers, the q image is dead, V^T is DMA'd over it and lands
+//      while the scores are computed;
+//   4. per head: S^T[key][row] = K_h . q_h^T (5 key tiles x 2 MFMAs), mask keys >= Tk, softmax over the key axis (in lane + two cross-group exchanges), P -> fp16 in the
+//      k order the accumulator tiles give (elements 0-3: key 32 ks + 4 lg + e of tile 2 ks, 4-7: key 32 ks + 16 + 4 lg + e of tile 2 ks + 1);
+//   5. per head: O^T[d][row] = V_h^T . P (4 d tiles x 3 MFMAs; the V^T fragments are read in the same permuted key order), O / l -> fp16, 16-byte stores.
+// Same rounding points as the unfused pair (fp16 q, K, V, P; fp32 scores, softmax statistics and accumulation); the fp32 summation orders differ from attn_tk96's.
 // *_LN (round 3, 128 x 320 tile, single-round linear launches): the launch ENDS with the LayerNorm of its fp32 output instead of being followed by one.  The 4 (N = 1280)
 // column tiles of a row block run at the same time on CUs of one XCD; each computes, per row, the mean and the centred sum of squares of its 320 columns (4 lanes by shuffles,
 // 4 wave columns through 4 KB of LDS, Chan's pairwise combination: no cancellation), publishes them (1 KB per wave row, write-through), takes a ticket on the row block's
@@ -672,6 +683,151 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             }
         }
     };
+    auto epi_xattn = [&](int wrow0, int wcol0) __attribute__((always_inline)) {
+        if constexpr (BM == 128 && BN == 320 && !CONV && !SK) {
+            (void)wrow0; (void)wcol0;
+            constexpr int QP = 656, VP = 208;                        // LDS row pitches: 640 B of q / K + 16 (b128 fragment reads of 16 rows hit every bank once), 192 B of V^T keys + 16
+            constexpr int KROWS = 77;                                // K rows kept (Tk <= 77 real keys; rows beyond Tk are clamped duplicates, masked below)
+            constexpr int QOFF = 57344;                              // q image behind K: the K image is 77 x 656 = 50 512 B, its 7 x 512 DMA slots cover 56 KB (the surplus lanes re-fetch the last chunk)
+            constexpr int KCH = KROWS * 41, VCH = 320 * 13;          // 16-byte chunks of the padded K / V^T images
+            constexpr int KIT = (KCH + 511) / 512, VIT = (VCH + 511) / 512;      // LDS-DMA instructions per thread: 7, 9
+            static_assert(KIT * 512 * 16 <= QOFF && QOFF + 128 * QP <= 160 * 1024 && VIT * 512 * 16 <= 128 * QP, "LDS map");
+            const int img = tcur.m0 / p.xa_Tq;
+            const int Tk = p.xa_Tk;
+            // 1. ring drained (every wave's own tail DMAs, then everybody's), K on its way
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            {
+                const _Float16* kb = p.xa_k + (long)img * Tk * p.xa_ldk + tcur.n0;
+#pragma unroll
+                for (int it = 0; it < KIT; ++it) {
+                    const int q = min(it * 512 + tid, KCH - 1);                        // (every lane of every instruction loads: the counted wait below counts instructions)
+                    const int row = min(q / 41, Tk - 1), cc = min(q % 41, 39);       // (chunk 40 of a row is the pad, rows >= Tk duplicates: any valid address)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + (long)row * p.xa_ldk + cc * 8),
+                                                     (__attribute__((address_space(3))) void*)(smem + (it * 512 + wave * 64) * 16), 16, 0, 0);
+                }
+            }
+            // 2. q -> fp16 -> LDS [row][320 columns]
+            {
+                unsigned char* qw = smem + QOFF + (wr * WM + l15) * QP + (wc * WN + 4 * lg) * 2;
+#pragma unroll
+                for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                    for (int i = 0; i < RA; ++i)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) {
+                            const f32x4 v = acc[qa][i][c] + cb[c];
+                            const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *reinterpret_cast<f16x4*>(qw + (qa * (WM / 2) + i * 16) * QP + c * 32) = h;
+                        }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the ds_writes have LANDED before the barrier lets the readers through (a raw s_barrier waits for nothing)
+            __builtin_amdgcn_s_barrier();
+            // 3. this wave's q fragments: rows 16 wave + l15, head h, k-step s (natural k order: d = 32 s + 8 lg + e)
+            f16x8 qf[5][2];
+            {
+                const unsigned char* qr = smem + QOFF + (wave * 16 + l15) * QP + lg * 16;
+#pragma unroll
+                for (int h = 0; h < 5; ++h)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) qf[h][s2] = *reinterpret_cast<const f16x8*>(qr + h * 128 + s2 * 64);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // fragments in registers: the q image may be overwritten
+            __builtin_amdgcn_s_barrier();
+            {
+                const _Float16* vb = p.xa_vt + ((long)img * p.N + tcur.n0) * 96;
+#pragma unroll
+                for (int it = 0; it < VIT; ++it) {
+                    const int q = min(it * 512 + tid, VCH - 1);
+                    const int row = q / 13, cc = min(q % 13, 11);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + (long)row * 96 + cc * 8),
+                                                     (__attribute__((address_space(3))) void*)(smem + QOFF + (it * 512 + wave * 64) * 16), 16, 0, 0);
+                }
+            }
+            wait_vmcnt<VIT>();                                        // K landed (this wave's part; the V^T instructions are younger)
+            __builtin_amdgcn_s_barrier();
+            // 4. scores + softmax, head by head; P stays in registers (3 k-steps of 32 keys per head; keys 80..95 are zero)
+            f16x8 pf[5][3];
+            float linv[5];
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                f32x4 sa[5];
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt) {
+                    const unsigned char* kr = smem + min(16 * kt + l15, Tk - 1) * QP + lg * 16 + h * 128;
+                    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(kr + s2 * 64), qf[h][s2], a4, 0, 0, 0);
+                    sa[kt] = a4;
+                }
+                // keys of tile kt in this lane: 16 kt + 4 lg + e
+#pragma unroll
+                for (int kt = 4; kt < 5; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (16 * kt + 4 * lg + e >= Tk) sa[kt][e] = -3.0e38f;
+                if (Tk <= 64) {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (16 * kt + 4 * lg + e >= Tk) sa[kt][e] = -3.0e38f;
+                }
+                float mx = sa[0][0];
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sa[kt][e]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float msc = -mx * p.xa_sc;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float pe = __builtin_amdgcn_exp2f(fmaf(sa[kt][e], p.xa_sc, msc)); sa[kt][e] = pe; sum += pe; }
+                sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+                linv[h] = 1.0f / sum;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    f16x8 f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[e] = (_Float16)sa[2 * ks][e];
+                        f[4 + e] = (2 * ks + 1 < 5) ? (_Float16)sa[(2 * ks + 1 < 5) ? 2 * ks + 1 : 0][e] : (_Float16)0.f;
+                    }
+                    pf[h][ks] = f;
+                }
+            }
+            wait_vmcnt<0>();                                          // V^T landed
+            __builtin_amdgcn_s_barrier();
+            // 5. O^T = V^T . P, normalised, fp16; pairs of 16-column blocks exchange halves so that every lane stores 16 contiguous bytes (as epi_fast)
+            _Float16* orow = p.xa_out + (long)(tcur.m0 + wave * 16 + l15) * p.xa_ldo + tcur.n0 + 8 * (lg >> 1) + 16 * (lg & 1);
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                f32x4 oa[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const unsigned char* vr = smem + QOFF + (h * 64 + dt * 16 + l15) * VP + lg * 8;
+                    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        union { f16x4 h4[2]; f16x8 f; } vf;
+                        vf.h4[0] = *reinterpret_cast<const f16x4*>(vr + ks * 64);            // keys 32 ks + 4 lg ..
+                        vf.h4[1] = *reinterpret_cast<const f16x4*>(vr + ks * 64 + 32);       // keys 32 ks + 16 + 4 lg ..
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.f, pf[h][ks], a4, 0, 0, 0);
+                    }
+                    oa[dt] = a4 * linv[h];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; dt += 2) {
+                    const f16x4 h0 = {(_Float16)oa[dt][0], (_Float16)oa[dt][1], (_Float16)oa[dt][2], (_Float16)oa[dt][3]};
+                    const f16x4 h1 = {(_Float16)oa[dt + 1][0], (_Float16)oa[dt + 1][1], (_Float16)oa[dt + 1][2], (_Float16)oa[dt + 1][3]};
+                    const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1);
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    *reinterpret_cast<u32x4*>(orow + h * 64 + dt * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+            }
+        }
+    };
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int wrow0 = tcur.m0 + wr * WM, wcol0 = tcur.n0 + wc * WN;
         if (wrow0 >= p.M || wcol0 >= p.N) return;             // M % WM == 0, N % WN == 0: a wave's block is all in or all out
@@ -695,6 +851,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         if constexpr (EPI == PP_EPI_GEGLU16) { epi_fast_geglu(wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_F32_LN) { epi_ln(F{}, wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_F32_RES_LN) { epi_ln(T{}, wrow0, wcol0); return; }
+        if constexpr (EPI == PP_EPI_XATTN) { epi_xattn(wrow0, wcol0); return; }
         if constexpr (EPI == PP_EPI_GENERIC) {
         if constexpr (RESBATCH) {
             if (p.resid) {

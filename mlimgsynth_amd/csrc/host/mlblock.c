@@ -666,6 +666,7 @@ static int run_op(MLCtx* C, MLOp* op)
 	case OP_SOFTMAX: return mlsd_softmax_rows(op->u.smax.in, op->u.smax.ld_in, op->u.smax.out, op->u.smax.ld_out,
 	                                   op->u.smax.rows, op->u.smax.cols, op->u.smax.scale, st);
 	case OP_COPY_F32: return mlsd_memcpy(op->u.copy.dst, op->u.copy.src, op->u.copy.nbytes, 2, st);
+	case OP_XA_VT: return mlsd_xattn_pack_vt(op->u.xavt.v, op->u.xavt.ldv, op->u.xavt.n_img, op->u.xavt.Tk, op->u.xavt.N, op->u.xavt.vt, st);
 	}
 	return mlsd_set_error(-1, "unknown op kind %d", (int)op->kind);
 }
@@ -806,6 +807,8 @@ static int streamk_get(MLCtx* C, mlsd_gemm_args* g)
 static int select_gemm(MLCtx* C, MLOp* op)
 {
 	mlsd_gemm_args *g = &op->u.gemm;
+	if (g->xa_k && mlsd_gemm_xattn_fused(g) == 1) { g->tile_variant = 19; g->ksplit = 1; return 1; }      /* a q projection that ends with its cross attention: one tile does that (a shape rule above the table, not a miss) */
+	if (mlsd_conv_smalln_eligible(g)) { g->tile_variant = 0; g->ksplit = 1; return 1; }                       /* likewise the small-Cout streaming convolution */
 	const TuneKey k = tune_key(g);
 	int best = 0, ks = 1;
 	int exact = tune_lookup(&k, &best, &ks);
@@ -1057,6 +1060,7 @@ static int op_outputs(const MLOp* o, const void* out[3])
 		if (o->u.gemm.C16) out[n++] = o->u.gemm.C16;
 		if (o->u.gemm.ln_y16 && n < 3) out[n++] = o->u.gemm.ln_y16;
 		if (o->u.gemm.gn_y16 && n < 3) out[n++] = o->u.gemm.gn_y16;
+		if (o->u.gemm.xa_k && n < 3) out[n++] = o->u.gemm.xa_out;
 		break;
 	case OP_ATTN: out[n++] = o->u.attn.out; break;
 	case OP_GN: out[n++] = o->u.gn.y16; if (o->u.gn.raw16) out[n++] = o->u.gn.raw16; break;
@@ -1068,6 +1072,7 @@ static int op_outputs(const MLOp* o, const void* out[3])
 	case OP_CLIP_EMBED: out[n++] = o->u.cemb.out; break;
 	case OP_SOFTMAX: out[n++] = o->u.smax.out; break;
 	case OP_COPY_F32: out[n++] = o->u.copy.dst; break;
+	case OP_XA_VT: out[n++] = o->u.xavt.vt; break;
 	}
 	return n;
 }
@@ -1567,7 +1572,7 @@ MLB_API int mlctx_prep(MLCtx* C)
 	for (int i=0;i<C->n_ops;++i) {
 		MLOp *op = &C->ops[i];
 		if (op->kind == OP_GEMM) {
-			if (!op->u.gemm.C32 && !op->u.gemm.C16) return mlctx_fail(C, "op %d (%s): output never consumed", i, op->label);
+			if (!op->u.gemm.C32 && !op->u.gemm.C16 && !op->u.gemm.xa_k) return mlctx_fail(C, "op %d (%s): output never consumed", i, op->label);
 			if (op->u.gemm.conv) nconv++;
 			/* tile selection: a pure function of the shape (table), unless the offline timing mode is on */
 			if (!autotune_on()) { int r = select_gemm(C, op); if (r < 0) return -1; if (r != 1) { C->n_tune_miss++; g_tune_miss++; } }     /* (2: a neighbour's tile; 0: the static rule) */
@@ -1715,6 +1720,7 @@ MLB_API double mlctx_op_bytes(const MLCtx* C, int i)
 		if (g->resid) b += 4.0 * g->M * nout;
 		if (g->C32) b += 4.0 * g->M * nout;
 		if (g->C16) b += 2.0 * g->M * nout;
+		if (g->xa_k) b += 2.0 * g->M * nout + 2.0 * 2.0 * (g->M / g->xa_Tq) * (double)g->xa_Tk * g->N;      /* the attention's output + the images' K and V */
 		return b;
 	}
 	case OP_ATTN: {

@@ -12,7 +12,7 @@ int mlsd_set_error(int code, const char* fmt, ...);
 
 typedef enum {
 	OP_GEMM, OP_ATTN, OP_GN, OP_LN, OP_NCHW2NHWC, OP_NHWC2NCHW, OP_TEMB, OP_ACT, OP_CLIP_EMBED, OP_SOFTMAX,
-	OP_COPY_F32,
+	OP_COPY_F32, OP_XA_VT,
 } MLOpKind;
 
 typedef struct MLOp {
@@ -37,6 +37,7 @@ typedef struct MLOp {
 		struct { const int32_t* tok; int n, T, d; const void* tw; const float* pw; float* out; } cemb;
 		struct { const float* in; int64_t ld_in; void* out; int64_t ld_out; int rows, cols; float scale; } smax;
 		struct { const void* src; void* dst; size_t nbytes; } copy;
+		struct { const void* v; int64_t ldv; int n_img, Tk, N; void* vt; } xavt;      /* V^T pack of a cross attention that ends its q projection (mlsd_xattn_pack_vt) */
 	} u;
 } MLOp;
 

@@ -404,9 +404,27 @@ MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int
 		mlb_release(C, qkv);
 	} else {
 		if (k != v) { mlctx_fail(C, "attention: k and v must share their input"); return NULL; }
+		const int kv_batched = C->kvb.ctx == k && !bias && k->c == C->kvb.n_in && C->kvb.n_used + 2*d_embed <= C->kvb.n_total;
+		/* Round 6: the cross attention of the text context (<= 77 keys, d_head 64: every cross attention of SDXL / SD2) runs at the END of its q projection's launch
+		 * (mlsd_gemm_args.xa_*, gemm_pp.hpp PP_EPI_XATTN): no attention dispatch, q never reaches HBM.  Decided here from the shapes alone (mlsd_gemm_xattn_fused is a pure
+		 * function of them: the tile rule sits above the table); the V operand's transposed, zero-padded copy is one more step-invariant op behind the batched context
+		 * projection -- recorded BEFORE the projection so that an eager first evaluation runs it first.  MLSD_XATTN=0 keeps the two launches (A/B, parity test). */
+		void *xa_vt = NULL; const char *xa_pk = NULL;
+		if (kv_batched && !mask && d_head == 64 && C->kvb.ctx->is_input) {
+			mlsd_gemm_args probe; memset(&probe, 0, sizeof(probe));
+			probe.A = probe.W_ = (const void*)16; probe.lda = probe.ldb = q->c; probe.M = (int)rows_of(q); probe.N = d_embed; probe.K = q->c;
+			probe.xa_k = probe.xa_vt = (const void*)16; probe.xa_out = (void*)16; probe.xa_ldk = C->kvb.n_total; probe.xa_ldo = d_embed; probe.xa_Tq = Tq; probe.xa_Tk = Tk;
+			if (!(q->c % 8) && mlsd_gemm_xattn_fused(&probe)) {
+				xa_pk = C->kvb.out16 + (size_t)C->kvb.n_used * 2;
+				xa_vt = mlctx_dalloc(C, (size_t)nb * d_embed * 96 * 2, 0);      /* never recycled: written once per conditioning */
+				MLOp *vo = mlctx_op_new(C, OP_XA_VT, "xattn_pack_vt");
+				vo->u.xavt.v = xa_pk + (size_t)d_embed*2; vo->u.xavt.ldv = C->kvb.n_total; vo->u.xavt.n_img = nb; vo->u.xavt.Tk = Tk; vo->u.xavt.N = d_embed; vo->u.xavt.vt = xa_vt;
+				vo->once = 1; C->n_once++;
+			}
+		}
 		MLTensor *qp = MLN("q_proj", mlb_linear_ex(C, q, d_embed, bias, NULL, 0));
 		if (!qp) return NULL;
-		if (C->kvb.ctx == k && !bias && k->c == C->kvb.n_in && C->kvb.n_used + 2*d_embed <= C->kvb.n_total) {
+		if (kv_batched) {
 			/* slices of the batched context projection: parameters registered under the reference's names */
 			const int off = C->kvb.n_used, n_in = k->c;
 			for (int i=0;i<2;++i) {
@@ -415,9 +433,19 @@ MLTensor* mlb_attn_mhead_ex(MLCtx* C, MLTensor* q, MLTensor* k, MLTensor* v, int
 				mlctx_named_op(C, n_kv[i]);
 			}
 			C->kvb.n_used += 2*d_embed;
-			const char *pq = (const char*)mlt_need16(C, qp), *pk = C->kvb.out16 + (size_t)off * 2;
-			record_attn(C, pq, d_embed, pk, C->kvb.n_total, pk + (size_t)d_embed*2, C->kvb.n_total, a->d16, d_embed,
-				nb, Tq, Tk, n_head, d_head, mask);
+			const char *pk = C->kvb.out16 + (size_t)off * 2;
+			MLOp *qo = (xa_vt && qp->prod >= 0) ? &C->ops[qp->prod] : NULL;
+			if (qo && qo->kind == OP_GEMM) {
+				mlsd_gemm_args *g = &qo->u.gemm;
+				g->xa_k = pk; g->xa_ldk = C->kvb.n_total; g->xa_vt = xa_vt; g->xa_out = a->d16; g->xa_ldo = d_embed; g->xa_Tq = Tq; g->xa_Tk = Tk;
+				if (mlsd_gemm_xattn_fused(g) == 1) qo->flops += 4.0 * nb * (double)Tq * Tk * n_head * d_head;
+				else { g->xa_k = NULL; g->xa_vt = NULL; g->xa_out = NULL; qo = NULL; }
+			} else qo = NULL;
+			if (!qo) {
+				const char *pq = (const char*)mlt_need16(C, qp);
+				record_attn(C, pq, d_embed, pk, C->kvb.n_total, pk + (size_t)d_embed*2, C->kvb.n_total, a->d16, d_embed,
+					nb, Tq, Tk, n_head, d_head, mask);
+			}
 			mlb_release(C, qp);
 		} else {
 			MLTensor *kv = fused_proj(C, k, d_embed, bias, n_kv, 2);

@@ -28,7 +28,7 @@ def test_hip_unet_vs_independent_golden(key, model, lat, n, sigmas):
     got = un.run(x, cond, label, np.array(sigmas, np.float32))
     errs = [rel(got[i], GOLD[key][i]) for i in range(n)]
     print(key, errs)
-    assert max(errs) < TOL
+    assert max(errs) < T.EVAL_SMALL       # test-sized latents: the bound of the summation-order scatter (tests/tolerances.py)
 
 
 @pytest.mark.parametrize("key,model,lat", G.VAE_CASES, ids=[c[0] for c in G.VAE_CASES])
@@ -89,7 +89,7 @@ def test_hip_unet_headline_size_vs_independent_golden(key, model, lat, n, sigmas
     got = un.run(x, cond, label, np.array(sigmas, np.float32))
     e = rel(got[0], HEAD[key][0])
     print(key, e)
-    assert e < TOL
+    assert e < T.EVAL_HEADLINE
 
 
 @pytest.mark.parametrize("key,model,lat", G.HEADLINE_VAE_CASES, ids=[c[0] for c in G.HEADLINE_VAE_CASES])
@@ -132,7 +132,7 @@ def test_hip_unet_bench_plan_sdxl_batch8_vs_independent_golden(slot):
     assert np.isfinite(got).all()
     e = rel(got[slot], HEAD[key][0])
     print(key, "batch 8, slot", slot, e)
-    assert e < TOL
+    assert e < T.EVAL_HEADLINE
 
 
 def test_hip_unet_config4_streamed_plan_as_benched_vs_resident_and_golden():
@@ -158,7 +158,7 @@ def test_hip_unet_config4_streamed_plan_as_benched_vs_resident_and_golden():
         assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), rep
         e = rel(b[slot], HEAD[key][0])
         print(key, "streamed, evaluation", rep, e)
-        assert e < TOL
+        assert e < T.EVAL_HEADLINE
 
 
 @pytest.mark.parametrize("slot", [0, 1])
@@ -182,7 +182,7 @@ def test_hip_unet_bench_plan_sd15_batch2_hipgraph_vs_independent_golden(slot):
     assert np.array_equal(got, again)
     e = rel(got[slot], HEAD[key][0])
     print(key, "batch 2 hipGraph, slot", slot, e)
-    assert e < TOL
+    assert e < T.EVAL_HEADLINE
 
 
 # ---- BASELINE configs[3]: 8 GPUs x 8 images.  One rank's workload is 8 images x cond/uncond = the BATCH-16 SDXL plan
@@ -207,5 +207,5 @@ def test_hip_unet_config3_per_rank_plan_sdxl_batch16_vs_independent_golden():
     assert np.isfinite(got).all()
     errs = [rel(got[s], HEAD[key][0]) for s in slots]
     print(key, "batch 16, slots", slots, errs)
-    assert max(errs) < TOL
+    assert max(errs) < T.EVAL_HEADLINE
     assert np.array_equal(got[slots[0]], got[slots[1]]) and np.array_equal(got[slots[0]], got[slots[2]])     # bits do not depend on the slot

@@ -158,6 +158,54 @@ def test_conv2d(K, n, h, w, cin, cout, k, s, p, ups, emb):
     assert rel(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("ring", [4, 5, 6])
+@pytest.mark.parametrize("n,h,w,cin,cout,strip", [
+    (2, 128, 128, 128, 3, 32),      # the KL-VAE decoder's conv_out (src/vae.c:163-165) at a small map: whole 64-pixel blocks
+    (1, 160, 176, 64, 3, 32),       # TAESD's last layer (src/tae.c:88-89): 64 channels, ragged block / wave / strip edges (176 = 2 x 64 + 48, 160 = 5 x 32)
+    (1, 131, 150, 128, 3, 40),      # nothing aligned: the last wave strip is 6 pixels wide, the last strip 11 rows tall
+    (1, 128, 128, 128, 8, 17),      # more output channels than one lane group holds (lanes 16..31 carry channels 4..7)
+    (1, 128, 130, 64, 16, 128)])    # the full 16, one strip per column, a 2-pixel last wave
+def test_conv2d_small_n(K, ring, n, h, w, cin, cout, strip):
+    """Round 6: 3x3 convolutions with a handful of output channels run as a streaming op (conv_smalln.hip, tile variant 31) -- per-wave row rings in LDS, weights in registers,
+    zero padding and ragged edges from a zero page.  Against orc_conv2d at the fp32-output bound, for every ring depth; the switch MLSD_CONV_SMALLN=0 / an ineligible launch
+    keeps the implicit-GEMM tile (same bound), and both agree with each other to summation order."""
+    kernels, _lib = K
+    L = _lib.lib()
+    rng = np.random.default_rng(cin * 3 + cout + h)
+    x = f16r(rng.standard_normal((n, cin, h, w)))
+    wt = f16r(rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9))
+    bias = rng.standard_normal(cout).astype(np.float32)
+    P = O.Params()
+    pw, pb = P.set("w", wt, f16=True), P.set("b", bias)
+    ref = np.stack([O.from_ot(O.L().orc_conv2d(O.to_ot(x[i:i + 1]), pw, pb, 1, 1))[0] for i in range(n)])
+    x_nhwc = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16)
+    dX, dW, dB = dev(_lib, x_nhwc), dev(_lib, repack_conv_w(wt, cin).astype(np.float16)), dev(_lib, bias)
+    M = n * h * w
+    dC = _lib.DeviceBuffer(M * cout * 4 + 64)
+    guard = np.full(16, 12345.0, np.float32)
+
+    def run(**kw):
+        dC.upload(np.concatenate([np.full(M * cout, np.nan, np.float32), guard]))
+        a = kernels.GemmArgs(A=dX.ptr, lda=cin, conv=1, n_img=n, H=h, W=w, Cin=cin, OH=h, OW=w, KH=3, KW=3, stride=1, pad=1, upsample=0, W_=dW.ptr,
+                             ldb=9 * cin, M=M, N=cout, K=9 * cin, bias=dB.ptr, rows_per_batch=h * w, ldrb=cout, C32=dC.ptr, ldc32=cout, **kw)
+        lab = kernels.gemm_variant(a)
+        kernels.gemm(a)
+        out = dC.download((M * cout + 16,), np.float32)
+        assert np.array_equal(out[M * cout:], guard)            # nothing written past the last pixel
+        return lab, out[:M * cout].reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+
+    L.mlsd_conv_smalln_set(ring, strip)
+    try:
+        lab, got = run()
+        assert lab == "gemm<conv3x3n16,conv>", lab
+        assert np.isfinite(got).all()
+        assert rel(got, ref) < 2e-5
+        lab2, got2 = run(act=kernels.ACT_RELU)                   # an epilogue the streaming kernel does not have: the launch stays on a GEMM tile
+        assert lab2 != lab and rel(got2, np.maximum(ref, 0)) < 2e-5
+    finally:
+        L.mlsd_conv_smalln_set(0, 0)
+
+
 def test_gemm_rejects_bad_args(K):
     kernels, _lib = K
     a = kernels.GemmArgs(A=16, lda=12, W_=16, ldb=8, M=4, N=4, K=12, C32=16, ldc32=4)
@@ -1383,6 +1431,75 @@ def test_attention(K, nb, heads, dh, tq, tk, causal):
     got = do.download((nb, tq, D), np.float16).astype(np.float32)
     assert np.isfinite(got).all()
     assert rel(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("nb,tq,heads,kd,tk,use_bias", [
+    (2, 256, 10, 320, 77, False),       # two tile columns (10 heads), two row blocks per image, the text context's 77 keys
+    (1, 128, 5, 192, 50, True),         # the smallest launch: one tile, 3 K tiles; keys end inside key tile 3 (mask of tiles 3 and 4), a projection bias
+    (3, 128, 5, 640, 77, False),        # a tile per image: every tile takes another image's K / V
+    (2, 1024, 20, 1280, 77, False),     # SDXL's 1024-token level: 8192 x 1280 x 1280 at batch 2 (one tile per block: 64 blocks here, 256 in the plan)
+    (1, 128, 5, 256, 1, False), (1, 128, 5, 256, 64, False), (1, 128, 5, 256, 65, False)])
+def test_gemm_that_ends_with_its_cross_attention(K, nb, tq, heads, kd, tk, use_bias):
+    """Round 6: the q projection of a cross attention ENDS with that attention (mlsd_gemm_args.xa_*, gemm_pp.hpp PP_EPI_XATTN): q never reaches HBM and
+    no attention launch follows.  Against the oracle's orc_linear + orc_attention (all fp32 except the fp16 operand roundings: the attention bound) and against the unfused
+    HIP pair on the same operands (same rounding points: they agree to the fp16 rounding of the output); K / V are slices of a wider buffer as in the plan (the batched
+    context projection), the output has its own row stride, nothing is written outside the rows."""
+    kernels, _lib = K
+    L, vp = _lib.lib(), _lib.vp
+    rng = np.random.default_rng(heads * 7 + tq + tk)
+    D = heads * 64
+    M = nb * tq
+    x = f16r(rng.standard_normal((M, kd)))
+    wq = f16r(rng.standard_normal((D, kd)) / np.sqrt(kd))
+    bias = (rng.standard_normal(D) * 0.3).astype(np.float32)
+    ldkv, koff, voff = 2 * D + 72, 8, D + 40                            # K at columns 8 .., V at D + 40 .. of rows of 2 D + 72 halfs
+    kv = f16r(rng.standard_normal((nb * tk, ldkv)))
+    kmat, vmat = kv[:, koff:koff + D], kv[:, voff:voff + D]
+    P = O.Params()
+    qref = O.from_ot(O.L().orc_linear(O.to_ot(x.reshape(1, 1, M, kd)), P.set("w", wq, f16=True), P.set("b", bias) if use_bias else None)).reshape(nb, tq, D)
+    ref = np.stack([O.from_ot(O.L().orc_attention(O.to_ot(qref[i][None, None]), O.to_ot(kmat[i * tk:(i + 1) * tk][None, None]),
+                                                   O.to_ot(vmat[i * tk:(i + 1) * tk][None, None]), heads, 0)).reshape(tq, D) for i in range(nb)])
+    dX, dW, dB, dKV = dev(_lib, x.astype(np.float16)), dev(_lib, wq.astype(np.float16)), dev(_lib, bias), dev(_lib, kv.astype(np.float16))
+    dVT = _lib.DeviceBuffer(nb * D * 96 * 2)
+    _lib.check(L.mlsd_memset(vp(dVT.ptr), 0x7C, ctypes.c_size_t(dVT.nbytes), None))
+    L.mlsd_xattn_pack_vt.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    _lib.check(L.mlsd_xattn_pack_vt(vp(dKV.ptr + 2 * voff), ldkv, nb, tk, D, vp(dVT.ptr), None), "pack")
+    vt = dVT.download((nb, D, 96), np.float16).astype(np.float32)
+    assert np.array_equal(vt[:, :, :tk], vmat.reshape(nb, tk, D).transpose(0, 2, 1)) and not vt[:, :, tk:].any()
+    ldo = D + 8
+    dO = _lib.DeviceBuffer((M * ldo + 16) * 2)
+    _lib.check(L.mlsd_memset(vp(dO.ptr), 0x7C, ctypes.c_size_t(dO.nbytes), None))
+    a = kernels.GemmArgs(A=dX.ptr, lda=kd, conv=0, W_=dW.ptr, ldb=kd, M=M, N=D, K=kd, bias=dB.ptr if use_bias else None,
+                         xa_k=dKV.ptr + 2 * koff, xa_ldk=ldkv, xa_vt=dVT.ptr, xa_out=dO.ptr, xa_ldo=ldo, xa_Tq=tq, xa_Tk=tk)
+    L.mlsd_gemm_xattn_fused.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
+    assert L.mlsd_gemm_xattn_fused(ctypes.byref(a)) == 1
+    assert kernels.gemm_variant(a) == "gemm<128x320x64pp,linear+attention>"
+    kernels.gemm(a)
+    raw = dO.download((M * ldo + 16,), np.float16)
+    got = raw[:M * ldo].reshape(M, ldo)
+    assert (np.concatenate([got[:, D:].ravel(), raw[M * ldo:]]).view(np.uint16) == 0x7C7C).all()          # nothing outside the rows
+    got = got[:, :D].astype(np.float32).reshape(nb, tq, D)
+    assert np.isfinite(got).all()
+    e = rel(got, ref)
+    # the unfused pair: projection with an fp16 output, then the attention launch
+    dQ, dO2 = _lib.DeviceBuffer(M * D * 2), _lib.DeviceBuffer(M * D * 2)
+    g = kernels.GemmArgs(A=dX.ptr, lda=kd, conv=0, W_=dW.ptr, ldb=kd, M=M, N=D, K=kd, bias=dB.ptr if use_bias else None, C16=dQ.ptr, ldc16=D)
+    kernels.gemm(g)
+    at = kernels.AttnArgs(q=dQ.ptr, k=dKV.ptr + 2 * koff, v=dKV.ptr + 2 * voff, out=dO2.ptr, ldq=D, ldk=ldkv, ldv=ldkv, ldo=D, bsq=tq * D, bsk=tk * ldkv,
+                          bsv=tk * ldkv, bso=tq * D, n_batch=nb, n_head=heads, d_head=64, Tq=tq, Tk=tk, causal=0)
+    kernels.attention(at)
+    two = dO2.download((nb, tq, D), np.float16).astype(np.float32)
+    e2, e12 = rel(two, ref), rel(got, two)
+    print(f"q projection + cross attention {M}x{D}x{kd}, {tk} keys: fused vs oracle {e:.2e}, unfused pair vs oracle {e2:.2e}, fused vs unfused {e12:.2e}")
+    assert e < 2e-3 and e12 < 1e-3
+    # bit-repeatable (no atomics, no hand-off), and an ineligible launch is refused by name rather than run without its attention
+    kernels.gemm(a)
+    assert np.array_equal(dO.download((M * ldo + 16,), np.float16).view(np.uint16), raw.view(np.uint16))
+    bad = kernels.GemmArgs(A=dX.ptr, lda=kd, conv=0, W_=dW.ptr, ldb=kd, M=M, N=D, K=kd, xa_k=dKV.ptr + 2 * koff, xa_ldk=ldkv, xa_vt=dVT.ptr, xa_out=dO.ptr, xa_ldo=ldo,
+                           xa_Tq=tq, xa_Tk=90)
+    assert L.mlsd_gemm_xattn_fused(ctypes.byref(bad)) == 0
+    with pytest.raises(_lib.MlsdError):
+        kernels.gemm(bad)
 
 
 @pytest.mark.parametrize("dh,tq,tk", [(64, 256, 77), (64, 200, 130), (40, 192, 77), (80, 130, 77), (160, 64, 64)])

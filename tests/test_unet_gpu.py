@@ -48,7 +48,7 @@ def test_unet_tiny_parity(model, lat, n):
     assert np.isfinite(got).all()
     err = [rel(got[i], ref[i]) for i in range(n)]
     print(model, lat, "per-image rel-L2:", err)
-    assert max(err) < TOL
+    assert max(err) < T.EVAL_SMALL
     # parameter keys / shapes agree with the oracle's (= the reference's naming, src/mlblock.c:67-105)
     mine = {k: tuple(ne) for k, _, ne in un.ctx.param_list()}
     theirs = {k: tuple(ne) for k, _, ne in OP.names()}
@@ -91,7 +91,7 @@ def test_unet_sd15_real_config_small_latent():
     ref, _ = oracle_eval("sd1", x, cond, None, sigma)
     err = [rel(got[i], ref[i]) for i in range(n)]
     print("sd1 16x16 per-image rel-L2:", err)
-    assert max(err) < TOL
+    assert max(err) < T.EVAL_SMALL
 
 
 def test_unet_sdxl_eval_is_bit_repeatable_and_finite():
@@ -197,7 +197,7 @@ def test_unet_sdxl_headline_size_parity():
     err = rel(got[0], ref[0])
     print("sdxl 128x128 rel-L2:", err)
     assert np.isfinite(got).all()
-    assert err < TOL
+    assert err < T.EVAL_HEADLINE
 
 
 def test_groupnorm_statistics_from_producers_equal_two_pass(monkeypatch):
@@ -249,7 +249,7 @@ def test_unet_parity_in_the_ggml_f16_table_mode():
     d = max(rel(ref1[i], ref0[i]) for i in range(n))
     print(f"{model}: HIP vs oracle exact-GELU {e0:.3e}, vs ggml-F16-table mode {e1:.3e}; the two oracle modes differ by {d:.3e}")
     assert d > 0, "the table mode changed nothing: is the switch wired?"
-    assert e0 < TOL and e1 < TOL
+    assert e0 < T.EVAL_SMALL and e1 < T.EVAL_SMALL
 
 
 @pytest.mark.parametrize("model,lat,n,min_ops", [("sdxl", 128, 8, 100), ("sd1", 64, 2, 30)], ids=["sdxl-b4", "sd15-b1"])

@@ -14,12 +14,12 @@ Template parameter lists (csrc/hip):
 """
 import re
 
-PP_EPI = {0: "generic", 1: "f16", 2: "f32", 3: "f32+res", 4: "geglu16", 5: "f32+stats", 6: "f32+res+stats", 7: "f32+ln", 8: "f32+res+ln"}
+PP_EPI = {0: "generic", 1: "f16", 2: "f32", 3: "f32+res", 4: "geglu16", 5: "f32+stats", 6: "f32+res+stats", 7: "f32+ln", 8: "f32+res+ln", 9: "q+cross attention"}
 TT_EPI = {1: "f16", 2: "f32", 3: "f32+res", 4: "f32+ln", 5: "f32+res+ln", 6: "f32+ln+chain", 7: "f32+res+ln+chain"}
 
 # every GEMM / attention kernel family of csrc/hip: a name that contains one of these MUST be parsed by its family rule in known()
 FAMILIES = ("gemm_pp_kernel", "gemm_tt_kernel", "gemm_w4_kernel", "gemm_skinny_kernel", "gemm_kernel", "attn64x2_kernel", "attn64pp_kernel",
-            "attn_tk96_kernel", "attn_q_kernel", "attn_kernel", "gemm_xattn_kernel")
+            "attn_tk96_kernel", "attn_q_kernel", "attn_kernel", "conv_smalln_kernel")
 
 
 def _ident(name):
@@ -86,7 +86,7 @@ def known(name):
                 sch = a[9] if len(a) > 9 else 0
                 conv = int(conv)                    # bool (rounds 1-4) or int 0 / 1 / 2 (round 5: 2 = through a nearest-2x upsample)
                 kind = "ppsk" if sk else "pp2" if nph == 2 else "ppb" if sch == 1 else "pp"
-                what = "linear+layernorm" if epi in (7, 8) else "conv" if conv else "linear"
+                what = "linear+layernorm" if epi in (7, 8) else "linear+attention" if epi == 9 else "conv" if conv else "linear"
                 return f"gemm<{bm}x{bn}x64{kind},{what}>", PP_EPI.get(epi, str(epi)) + (",upsampled" if conv == 2 else "")
             if fn == "gemm_tt_kernel":
                 e = a[0]
@@ -108,15 +108,15 @@ def known(name):
                 return f"attention<{a[0]},queue>", ""
             if fn == "attn_tk96_kernel":
                 return f"attention<{a[0]},one pass>", ""
-            if fn == "gemm_xattn_kernel":
-                return "gemm<128x256x64xa,linear+attention>", ""
+            if fn == "conv_smalln_kernel":
+                return "gemm<conv3x3n16,conv>", f"cin {a[0]}, ring {a[1]}"
             if fn == "attn64x2_kernel":
                 return "attention<64,64 rows/wave>", ""
             if fn == "attn64pp_kernel":
                 return "attention<64,ping-pong>", ""
         except (ValueError, IndexError, TypeError):
             return None
-    if "gemm" in name or "attn" in name:
+    if "gemm" in name or "attn" in name or "conv_smalln" in name:
         return None                                 # a tile family this table does not know: the CPU test fails on it
     k = _ident(name)
     return (k, "") if k else None
