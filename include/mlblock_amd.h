@@ -48,7 +48,6 @@ void   mlctx_set_wtype(MLCtx* C, int wtype);               /* linear weight type
 int    mlctx_prep(MLCtx* C);              /* resolve parameter names, finish the plan (result = last tensor) */
 int    mlctx_compute(MLCtx* C);           /* replay the plan on the context's stream (asynchronous) */
 int    mlctx_sync(MLCtx* C);
-int    mlctx_chained(const MLCtx* C);     /* Linears of the plan that run as the second GEMM of the launch producing their input (round 5 experiment: 0 unless MLSD_TT_CHAIN=1 on an EXPERIMENTS build) */
 int    mlctx_handoff_check(MLCtx* C);  /* 0 / < 0: an in-launch hand-off (stream-K, LayerNorm statistics) of this plan gave up waiting since the last check: results
                                         * invalid; the flag / counter blocks are zeroed again before the error is returned */
 /* WEIGHT STREAMING (the reference's --unet-split, src/unet.c:390-458; BASELINE configs[4]): the plan's weights live in pinned host memory and pass through THREE TO FIVE device

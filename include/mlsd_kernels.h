@@ -137,15 +137,18 @@ typedef struct mlsd_gemm_args {
 	unsigned* sk_flags;
 	/* LayerNorm at the END of the launch (round 3): when ln_y16 is set and mlsd_gemm_ln_fused(args) says so, the launch also writes
 	 * ln_y16[m][n] = fp16(LayerNorm(C32 row m) * ln_gamma + ln_beta) (row stride ldln halfs, eps ln_eps): the LayerNorm that would follow
-	 * (ggml_norm + mul + add, src/mlblock_nn.c:65-71) needs no launch of its own.  Linear launches on the 128x320 ping-pong tile whose tiles are all
-	 * resident at once (M % 128 == 0, N % 320 == 0, (M/128)(N/320) <= 256), fp32 output (+ residual).  ln_ws: >= (M/128)(N/320) * 128 * 8 bytes of scratch;
-	 * ln_cnt: 8192 zeroed 32-bit words that stay zero between launches (word 8191 is a sticky give-up indicator like sk_flags[4095]).
+	 * (ggml_norm + mul + add, src/mlblock_nn.c:65-71) needs no launch of its own.  Linear launches on the 128x320 ping-pong tile (or the 128x160 tile) whose tiles are all
+	 * resident at once (M % 128 == 0, N % 320 == 0, (M/128)(N/320) <= 256), fp32 output (+ residual), at most 8 column tiles per row block.  The column tiles of a row
+	 * block exchange their row statistics inside the launch as self-tagged records (round 6: no counters, nothing to reset): ln_ws = scratch OF THIS LAUNCH'S OWN
+	 * (zeroed once, never shared with another launch: >= M * (N / tile columns) * 16 bytes -- 16 bytes per row and column tile); ln_cnt = a block of 8192 32-bit words
+	 * zeroed once, ln_cnt[ln_slot] (0 <= ln_slot < 8191) = this launch's epoch, advanced by the launch itself; word 8191 = sticky give-up indicator like sk_flags[4095].
 	 * mlsd_gemm FAILS when ln_y16 is set and the launch cannot honour it. */
 	void* ln_y16; int64_t ldln;
 	const float *ln_gamma, *ln_beta;
 	float ln_eps;
 	float* ln_ws;
 	unsigned* ln_cnt;
+	int ln_slot;
 	/* GroupNorm at the END of a split-K launch's reduce pass (round 4; mlsd_gemm_gn_fused): when gn_y16 is set and the launch qualifies -- general tile, ksplit > 1, fp32
 	 * output, N % gn_groups == 0 with N / gn_groups a multiple of 4, an (image, group) slab of gn_hw * N / gn_groups <= 10240 values -- the reduce pass runs one block
 	 * per (image, group): slices added in slice order + the epilogue (C32 bit-identical to splitk_reduce), then
@@ -155,13 +158,6 @@ typedef struct mlsd_gemm_args {
 	const float *gn_gamma, *gn_beta;
 	float gn_eps;
 	int gn_groups, gn_hw, gn_silu;
-	/* A SECOND GEMM in the same launch (round 5; the 128 x 160 kernel, tile variant 30, on launches that end with a LayerNorm): the Linear that consumes that LayerNorm --
-	 * chain_C16[m][n] = fp16(sum_k ln_y16[m][k] chain_W[n][k] + chain_bias[n]), N columns, K = N (src/mlblock_nn.c:200-203: the cross-attention q projection behind norm2).
-	 * Honoured when mlsd_gemm_chained(args) == 1 (M % 128 == 0, N % 320 == 0, at most two 128 x 160 tiles per CU; EXPERIMENTS builds only: measured, correct, not faster in
-	 * the plan -- profiles/NOTES.md "Round 5"); mlsd_gemm FAILS when chain_W is set and it is not. */
-	const void* chain_W; int64_t chain_ldb;
-	const float* chain_bias;
-	void* chain_C16; int64_t chain_ldc16;
 	/* CROSS ATTENTION at the end of its q projection (round 6; the 128 x 320 ping-pong tile = 128 query rows x 5 heads of 64).  When xa_k is set and
 	 * mlsd_gemm_xattn_fused(args) == 1 the launch does NOT store the projection: a tile's q (rounded to fp16 exactly as the unfused launch's C16 would hold it) stays in LDS
 	 * and the launch ends with  xa_out[m][64 h + d] = fp16( softmax_key( q_h[m] . K_h[key] / sqrt(64) ) . V_h )  over the xa_Tk <= 80 keys of row m's image -- what
@@ -182,8 +178,6 @@ int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
 /* != 0 if this launch (ln_* fields set) ends with the LayerNorm of its output (see mlsd_gemm_args.ln_y16): 1 = inside the launch, the tiles of a row block exchanging their
  * row statistics (128x320 ping-pong tile; an in-launch hand-off); 2 = in the reduce pass of a split-K launch (one block per finished row: no hand-off; ln_ws / ln_cnt unused) */
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
-/* 1 if this launch (chain_* fields set) also runs the Linear that consumes its LayerNorm: see mlsd_gemm_args.chain_W */
-int mlsd_gemm_chained(const mlsd_gemm_args* a);
 /* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: see mlsd_gemm_args.xa_k.  MLSD_XATTN=0 in the environment answers 0 (A/B). */
 int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a);
 /* vt[b][n][key] = v[b * Tk + key][n] for key < Tk, 0 for Tk <= key < 96: the V operand of the fused launch (fp16; v row stride ldv halfs; N columns; Tk <= 96) */

@@ -182,7 +182,7 @@ extern "C" MLSD_API int mlsd_conv_smalln_eligible(const mlsd_gemm_args* a)
 {
     if (!a || !sn_on() || !a->conv || a->KH != 3 || a->KW != 3 || a->stride != 1 || a->pad != 1 || a->upsample) return 0;
     if (a->N < 1 || a->N > 16 || (a->Cin != 128 && a->Cin != 64) || a->OH != a->H || a->OW != a->W || a->M < 16384) return 0;
-    if (!a->C32 || a->C16 || a->resid || a->rowbias || a->bias_m || a->act != MLSD_ACT_NONE || a->colstats || a->ln_y16 || a->gn_y16 || a->chain_W) return 0;
+    if (!a->C32 || a->C16 || a->resid || a->rowbias || a->bias_m || a->act != MLSD_ACT_NONE || a->colstats || a->ln_y16 || a->gn_y16) return 0;
     if ((a->lda & 7) || a->lda < a->Cin || ((uintptr_t)a->A & 15) || ((uintptr_t)a->W_ & 15) || (a->ldb & 7) || a->ldb != 9L * a->Cin || a->ldc32 < a->N) return 0;
     return 1;
 }

@@ -84,6 +84,7 @@ struct GemmP {
     long ldln;
     float* ln_ws;
     unsigned* ln_cnt;
+    int ln_slot;                // index of this launch's epoch word in ln_cnt (round 6: self-tagged records, no counters)
     int gn_G, gn_hw, gn_silu;   // splitk_reduce_gn: groups, rows per image, SiLU (gamma / beta / eps / output in the ln_* fields)
     // cross attention at the end of its q projection (gemm_pp.hpp PP_EPI_XATTN): K [n_img * Tk][ldk], V^T [n_img][N][96], output, rows per image, keys, log2(e) / sqrt(64)
     const _Float16 *xa_k, *xa_vt;
@@ -1181,7 +1182,7 @@ bool ln_eligible(const mlsd_gemm_args* a)
     const long nbn = a->N / 320, tiles = (long)(a->M / 128) * nbn;
     const bool one_round = tiles <= g_gemm_ncu;
     const bool whole_rounds = g_gemm_ncu == 256 && !(tiles % 256) && (nbn == 1 || nbn == 2 || nbn == 4);
-    return (one_round || whole_rounds) && a->M / 128 <= 256 && pp_eligible(a, 128, 320) && device_cus() >= g_gemm_ncu;      // (counters: 16 words per (row block, wave row) in 8192 words)
+    return (one_round || whole_rounds) && nbn <= 8 && a->ln_slot >= 0 && a->ln_slot < 8191 && pp_eligible(a, 128, 320) && device_cus() >= g_gemm_ncu;      // (<= 8 partner tiles per row: two per lane group of the gathering wave)
 }
 
 // launches that END with the cross attention of the q they project (gemm_pp.hpp PP_EPI_XATTN): linear, whole 128 x 320 tiles (5 heads of 64), fp16 "output" that is never
@@ -1195,7 +1196,7 @@ bool xattn_on()
 bool xattn_eligible(const mlsd_gemm_args* a)
 {
     if (!a->xa_k || !a->xa_vt || !a->xa_out || !xattn_on() || a->conv || a->act != MLSD_ACT_NONE || a->C32 || a->resid || a->rowbias || a->bias_m || a->colstats) return false;
-    if (a->ln_y16 || a->gn_y16 || a->chain_W || (a->M % 128) || (a->N % 320) || (a->K & 63) || a->K < 192) return false;
+    if (a->ln_y16 || a->gn_y16 || (a->M % 128) || (a->N % 320) || (a->K & 63) || a->K < 192) return false;
     if (a->xa_Tq <= 0 || (a->xa_Tq % 128) || (a->M % a->xa_Tq) || a->xa_Tk < 1 || a->xa_Tk > 77) return false;
     if ((a->xa_ldk & 7) || (a->xa_ldo & 7) || ((uintptr_t)a->xa_k & 15) || ((uintptr_t)a->xa_vt & 15) || ((uintptr_t)a->xa_out & 15) || (a->bias && ((uintptr_t)a->bias & 15))) return false;
     return g_gemm_epi != 1 && !(g_gemm_dbg & 2);
@@ -1260,7 +1261,7 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK * 2; // the ring; the epilogue needs no LDS
     const int ntiles = p.nbm * p.nbn;
     p.sk_L = 0; p.sk_ws = nullptr; p.sk_flag = nullptr;
-    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt; p.ln_slot = a->ln_slot;
     if constexpr (SK) {
         p.sk_L = sk_share(ntiles, a->K / BK, g_gemm_ncu);
         p.sk_ws = (float*)a->ws; p.sk_flag = a->sk_flags;
@@ -1271,13 +1272,13 @@ int launch_pp(const mlsd_gemm_args* a, hipStream_t st)
         hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
         return mlsd_check_launch("gemm_pp_kernel");
     };
-    auto go_ln = [&](auto kfn) -> int {              // + 4 KB beyond the ring for the wave columns' partial row statistics
-        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS + 4096)));
-        hipLaunchKernelGGL(kfn, grid, block, LDS + 4096, st, p);
+    auto go_ln = [&](auto kfn) -> int {              // + 4 KB beyond the ring for the wave columns' partial row statistics + 8 KB for the partner tiles' (<= 8 per row)
+        MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS + 4096 + 8192)));
+        hipLaunchKernelGGL(kfn, grid, block, LDS + 4096 + 8192, st, p);
         return mlsd_check_launch("gemm_pp_kernel(+LN)");
     };
     auto go_xa = [&](auto kfn) -> int {              // cross attention at the end: ONE tile per block (the epilogue re-uses the ring's LDS), K + q images = 138 KB
-        constexpr int XLDS = 57344 + 128 * 656;
+        constexpr int XLDS = 57344 + 128 * 640;
         p.xa_k = (const _Float16*)a->xa_k; p.xa_vt = (const _Float16*)a->xa_vt; p.xa_out = (_Float16*)a->xa_out; p.xa_ldk = a->xa_ldk; p.xa_ldo = a->xa_ldo;
         p.xa_Tq = a->xa_Tq; p.xa_Tk = a->xa_Tk; p.xa_sc = 1.4426950408889634f * 0.125f;      /* log2(e) / sqrt(64) */
         MLSD_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS));
@@ -1509,8 +1510,6 @@ MLSD_API int mlsd_gemm(const mlsd_gemm_args* a, void* stream)
                               "would write %d-row blocks / none: tile or epilogue settings changed after planning", a->colstats_rows, mlsd_gemm_colstats_rows(a));
     if (a->gn_y16 && !mlsd_gemm_gn_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a GroupNorm for this launch's reduce pass but the launch would not run it (tile or K-split settings changed after planning)");
-    if (a->chain_W && !mlsd_gemm_chained(a))
-        return mlsd_set_error(-1, "mlsd_gemm: the plan dropped the launch of a consuming Linear for this launch's second GEMM but the launch would not run it (tile settings changed after planning)");
     if (a->xa_k && !mlsd_gemm_xattn_fused(a))
         return mlsd_set_error(-1, "mlsd_gemm: the plan dropped a cross attention for this projection's launch but the launch would not run it (tile settings changed after planning)");
     if (a->ln_y16 && !mlsd_gemm_ln_fused(a))
@@ -1719,14 +1718,6 @@ MLSD_API int mlsd_gemm_gn_fused(const mlsd_gemm_args* a)
 #endif
 }
 
-/* 1 if this launch (chain_* fields set) also runs the GEMM that consumes its LayerNorm (mlsd_gemm_args.chain_W): the plan builder then drops that launch */
-MLSD_API int mlsd_gemm_chained(const mlsd_gemm_args* a)
-{
-    if (!a || !a->chain_W || !a->ln_y16 || pick_variant(a) != 30) return 0;
-    const int e = mlsd_gemm_tt_eligible(a, tt_ncu());
-    return (e == 6 || e == 7) ? 1 : 0;
-}
-
 /* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: the plan builder then records no attention launch */
 MLSD_API int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a)
 {
@@ -1761,7 +1752,7 @@ MLSD_API const char* mlsd_gemm_variant(const mlsd_gemm_args* a)
     const int ns = ((v >= 17 && v <= 22) || v >= 25) ? 1 : splitk_slices(a, bk, nullptr);   /* (the persistent tiles never split K over the grid) */
     if (ns > 1) snprintf(buf, sizeof(buf), "gemm<%s,%s%s,k/%d%s>", kVariants[v].name, a->conv ? "conv" : "linear", mlsd_gemm_ln_fused(a) == 2 ? "+layernorm" : (mlsd_gemm_gn_fused(a) ? "+groupnorm" : ""), ns, mlsd_gemm_splitk_parallel(a) ? "p" : "");
     else if (mlsd_gemm_xattn_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+attention>", kVariants[v].name);      /* the q projection of a cross attention that ends with it */
-    else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm%s>", kVariants[v].name, mlsd_gemm_chained(a) ? "+linear" : "");      /* the launch ends with the LayerNorm of its output (and runs the Linear that consumes it) */
+    else if (mlsd_gemm_ln_fused(a)) snprintf(buf, sizeof(buf), "gemm<%s,linear+layernorm>", kVariants[v].name);      /* the launch ends with the LayerNorm of its output */
     else snprintf(buf, sizeof(buf), "gemm<%s,%s>", kVariants[v].name, a->conv ? "conv" : "linear");
     return buf;
 }

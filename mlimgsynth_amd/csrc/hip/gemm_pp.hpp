@@ -114,12 +114,12 @@ enum { PP_EPI_GENERIC = 0, PP_EPI_F16 = 1, PP_EPI_F32 = 2, PP_EPI_F32_RES = 3, P
 // Same rounding points as the unfused pair (fp16 q, K, V, P; fp32 scores, softmax statistics and accumulation); the fp32 summation orders differ from attn_tk96's.
 // *_LN (round 3, 128 x 320 tile, single-round linear launches): the launch ENDS with the LayerNorm of its fp32 output instead of being followed by one.  The 4 (N = 1280)
 // column tiles of a row block run at the same time on CUs of one XCD; each computes, per row, the mean and the centred sum of squares of its 320 columns (4 lanes by shuffles,
-// 4 wave columns through 4 KB of LDS, Chan's pairwise combination: no cancellation), publishes them (1 KB per wave row, write-through), takes a ticket on the row block's
-// counter; ONE wave per (block, wave row) polls it until all tiles have published (every wave polling starved the arrivals: 30 us per launch), the others wait at a
-// barrier; then every wave reads the partials with agent-scope loads (an acquire fence in 2048 waves cost 15 us), combines them in tile order (bit-repeatable), normalises
-// the values it still holds in its accumulators and writes the fp16 rows.  A second counter (departures) clears both for the next launch.  Bounded polling; a give-up
-// raises a sticky word (ln_cnt[8191]) that the host reads with the results.  Measured (tools/ln_fold_bench.py): 8192x1280x1280 GEMM 40.3 + LayerNorm 12.0 = 53.3 us as two
-// launches, 50.9 us as one (46.6 without the exchange); K = 5120: 135.4 -> 128.1; SDXL b4 evaluation 65.50 -> 65.05 ms (same box, MLSD_NO_LN_FOLD=1 for the A/B).
+// 4 wave columns through 4 KB of LDS, Chan's pairwise combination: no cancellation) and publishes them as self-tagged records (round 6: {mean, tag, m2, tag}, write-through;
+// the tag is the launch's epoch + 1, the scratch is the launch's own: epi_ln step 4).  ONE wave per (block, wave row) loads the partners' records until their tags match
+// (every wave polling starved the arrivals: 30 us per launch), the others wait at a barrier and take the values from LDS; then every wave combines them in tile order
+// (bit-repeatable), normalises the values it still holds in its accumulators and writes the fp16 rows.  No ticket, no arrival / departure counters, nothing to reset (rounds 3-5
+// had all three: three serial round trips per launch).  Bounded polling; a give-up raises a sticky word (ln_cnt[8191]) that the host reads with the results.  Measured
+// (tools/ln_fold_bench.py): 8192x1280x1280 GEMM 40.3 + LayerNorm 12.0 = 53.3 us as two launches, 50.9 us as one with the counters (46.6 without any exchange).
 // *_STATS: additionally the column sums / sums of squares of the wave's rows (GemmP::colstats) for a consuming GroupNorm
 // NPH = 2: TWO phases per K tile instead of four (round 3).  In-kernel stamps of the four-phase loop on the 128 x 320 tile: 2075 clocks
 // per K tile against 1280 of matrix work, the same with the staging switched off (profiles/r2_gemm_trace_*: the loop is not fill-bound
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) stay on the SALU
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
+    unsigned ln_epoch = 0;      // *_LN epilogues: the epoch of this launch's record scratch (its records carry epoch + 1)
+    if constexpr (EPI == PP_EPI_F32_LN || EPI == PP_EPI_F32_RES_LN) ln_epoch = __hip_atomic_load(p.ln_cnt + p.ln_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nblk = p.nbm * p.nbn;
     const int G = gridDim.x;
     const int nkt = p.K / BK;
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 for (int c = 0; c < NCB; ++c) {
                     f32x4 v = acc[qa][i][c] + cb[c];
                     if constexpr (RES) v += rr[r][c];
-                    acc[qa][i][c] = v;                              // (stored to C32 after the ticket: the publish must not wait behind the tile's 160 KB of stores)
+                    acc[qa][i][c] = v;                              // (stored to C32 after the records are on their way: the publish must not wait behind the tile's 160 KB of stores)
                     s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 }
                 // 2. the row's 80 columns of this wave sit in the 4 lanes l15 + 16 lg: mean, then the centred sum of squares
@@ -602,49 +604,77 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 for (int w = 1; w < 4; ++w) chan(n, mu, m2, (float)WN, e[w][0], e[w][1]);
                 mean_t[r] = mu; m2_t[r] = m2;
             }
-            // 4. publish (wave column 0 of each wave row), ticket, poll
+            // 4. publish + gather (round 6: no ticket, no counters -- the records carry their own validity).  Per row ONE 16-byte record {mean, tag, m2, tag} = two self-tagged
+            //    8-byte granules, written through (sc1), tag = this launch's epoch + 1: the epoch is the launch's own word (ln_cnt[ln_slot], read at kernel entry, advanced by
+            //    tile (0, 0) once it holds its partners' records) and the scratch is the launch's own (mlblock.c wire_ln_fold), so a record with the right tag can only be
+            //    this launch's.  ONE wave per (block, wave row) loads the partners' records with agent-scope loads until both tags of all of them match (bounded; every wave
+            //    polling starved the arrivals themselves in round 3), hands them to the other waves through LDS; the others wait at the barrier.  The chain is now: record
+            //    visible in L2 -> load returns it (was: store acknowledged -> ticket -> counter seen -> partials loaded), and there is nothing to reset.
             const int rbk = tcur.m0 / BM, bnk = tcur.n0 / BN, nbn = p.nbn;
-            f32x2* gws = reinterpret_cast<f32x2*>(p.ln_ws) + ((long)rbk * nbn * BM);          // [tile column][128 rows]
-            unsigned* cnt = p.ln_cnt + (rbk * 2 + wr) * 16;                                    // [row block][wave row]{arrivals, departures}, 64 bytes apart (8192 words: 256 row blocks)
-            if (wc == 0) {
-                if (lg == 0) {
-                    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gws + (long)bnk * BM), 0, BM * 8, 0x00020000);
+            const unsigned tag = ln_epoch + 1u;
+            u32x4* gws = reinterpret_cast<u32x4*>(p.ln_ws) + ((long)rbk * nbn * BM);           // [tile column][128 rows] records
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)gws, 0, nbn * BM * 16, 0x00020000);
+            if (wc == 0 && lg == 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const f32x2 t = {mean_t[r], m2_t[r]};
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rs, (wr * 64 + row_of(r) + l15) * 8, 0, 16);   // sc1: write-through
-                    }
+                for (int r = 0; r < NR; ++r) {
+                    const u32x4 rec = {__builtin_bit_cast(unsigned, mean_t[r]), tag, __builtin_bit_cast(unsigned, m2_t[r]), tag};
+                    __builtin_amdgcn_raw_buffer_store_b128(rec, rs, (bnk * BM + wr * 64 + row_of(r) + l15) * 16, 0, 16);      // sc1: write-through
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // the fp32 output goes out while the other tiles' partials arrive
+            // the fp32 output goes out while the other tiles' records arrive
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int c = 0; c < NCB; ++c)
                     *reinterpret_cast<f32x4*>(c32b + (long)row_of(r) * p.ldc32 + c * 16) = acc[r / RA][r % RA][c];
-            // ONE wave per (block, wave row) polls (2048 polling waves on a few lines starved the arrivals themselves: 30 us per launch); the others wait at the barrier
+            f32x2* red2 = reinterpret_cast<f32x2*>(smem + 2 * STAGE + 4096);                   // [128 rows][8 tiles], beyond the ring and the wave columns' exchange
             if (wc == 0) {
+                // lane (l15, lg): partner tiles lg and lg + 4, rows row_of(r) + l15 of this wave row.  (This tile's own record comes from registers.)
+                const bool act0 = lg < nbn, act1 = lg + 4 < nbn;
+                const bool own0 = lg == bnk, own1 = lg + 4 == bnk;
+                u32x4 rec0[NR], rec1[NR];
                 unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
-                if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    bool ok = true;
+                    asm volatile("" ::: "memory");      // the record loads below are plain (readonly) buffer loads to the compiler: without this it hoists them out of the poll loop
+                    if (act0 && !own0) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) rec0[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lg * BM + wr * 64 + row_of(r) + l15) * 16, 0, 16);      // sc1: past the vector L1
+                    }
+                    if (act1 && !own1) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) rec1[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lg + 4) * BM + wr * 64 + row_of(r) + l15) * 16, 0, 16);
+                    }
+                    if (act0 && !own0) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) ok = ok && rec0[r][1] == tag && rec0[r][3] == tag;
+                    }
+                    if (act1 && !own1) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) ok = ok && rec1[r][1] == tag && rec1[r][3] == tag;
+                    }
+                    if (__all(ok) || ++spins >= (1u << 20)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky give-up word (mlctx_handoff_check)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    f32x2* e = red2 + (wr * 64 + row_of(r) + l15) * 8;
+                    if (act0) e[lg] = own0 ? f32x2{mean_t[r], m2_t[r]} : f32x2{__uint_as_float(rec0[r][0]), __uint_as_float(rec0[r][2])};
+                    if (act1) e[lg + 4] = own1 ? f32x2{mean_t[r], m2_t[r]} : f32x2{__uint_as_float(rec1[r][0]), __uint_as_float(rec1[r][2])};
+                }
+                if (rbk == 0 && bnk == 0 && wr == 0 && lane == 0) __hip_atomic_store(p.ln_cnt + p.ln_slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch of this op uses tag + 1
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the ds_writes have LANDED before the barrier lets the readers through
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // program order only: the partials below must not be hoisted above the poll / barrier by the compiler
-            // (no AGENT acquire fence: 2048 waves invalidating their caches cost 15 us per launch; the partials are read with agent-scope loads instead)
             // 5. all tiles' partials in tile order -> mean, 1 / sqrt(var + eps)
             float mean_r[NR], rstd_r[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const f32x2* e = gws + wr * 64 + row_of(r) + l15;
-                auto ld2 = [&](const f32x2* q) __attribute__((always_inline)) {
-                    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return __builtin_bit_cast(f32x2, u);
-                };
-                f32x2 t = ld2(e);
+                const f32x2* e = red2 + (wr * 64 + row_of(r) + l15) * 8;
+                f32x2 t = e[0];
                 float n = (float)BN, mu = t[0], m2 = t[1];
-                for (int b = 1; b < nbn; ++b) { t = ld2(e + (long)b * BM); chan(n, mu, m2, (float)BN, t[0], t[1]); }
+                for (int b = 1; b < nbn; ++b) { t = e[b]; chan(n, mu, m2, (float)BN, t[0], t[1]); }
                 mean_r[r] = mu; rstd_r[r] = 1.0f / sqrtf(m2 / n + p.ln_eps);
             }
             // 6. y = (v - mean) rstd gamma + beta -> fp16, 16-byte stores (pairs of column blocks exchange halves, as epi_fast)
@@ -672,44 +702,44 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 if constexpr (NCB & 1)
                     *reinterpret_cast<f16x4*>(p.ln_y + (long)(wrow0 + l15 + row_of(r)) * p.ldln + wcol0 + (NCB - 1) * 16 + 4 * lg) = y4(NCB - 1);
             }
-            // departures: the last of the nbn pollers of this (row block, wave row) clears both counters for the next launch.  AFTER the rows are on their way (round 5): the
-            // returned ticket is needed for nothing but this reset, and waiting for it in front of the barrier held all 8 waves for an L2 round trip per launch
-            if (wc == 0 && lane == 0) {
-                const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)(nbn - 1)) {
-                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
         }
     };
     auto epi_xattn = [&](int wrow0, int wcol0) __attribute__((always_inline)) {
         if constexpr (BM == 128 && BN == 320 && !CONV && !SK) {
             (void)wrow0; (void)wcol0;
-            constexpr int QP = 656, VP = 208;                        // LDS row pitches: 640 B of q / K + 16 (b128 fragment reads of 16 rows hit every bank once), 192 B of V^T keys + 16
+            constexpr int QP = 640, VP = 208;                        // LDS row pitches: q / K rows are 640 B with the ring's XOR swizzle of the 16-byte chunks inside every 128-byte segment
+                                                                     // (chunk c of row r at slot c ^ ((r >> 1) & 7): b128 fragment reads of 16 rows touch every bank once); V^T rows 192 B of keys + 16
             constexpr int KROWS = 77;                                // K rows kept (Tk <= 77 real keys; rows beyond Tk are clamped duplicates, masked below)
-            constexpr int QOFF = 57344;                              // q image behind K: the K image is 77 x 656 = 50 512 B, its 7 x 512 DMA slots cover 56 KB (the surplus lanes re-fetch the last chunk)
-            constexpr int KCH = KROWS * 41, VCH = 320 * 13;          // 16-byte chunks of the padded K / V^T images
+            constexpr int QOFF = 57344;                              // q image behind K: the K image is 77 x 640 = 49 280 B, its 7 x 512 DMA slots cover 56 KB (the surplus lanes re-fetch the last chunk)
+            constexpr int KCH = KROWS * 40, VCH = 320 * 13;          // 16-byte chunks of the K / V^T images
             constexpr int KIT = (KCH + 511) / 512, VIT = (VCH + 511) / 512;      // LDS-DMA instructions per thread: 7, 9
             static_assert(KIT * 512 * 16 <= QOFF && QOFF + 128 * QP <= 160 * 1024 && VIT * 512 * 16 <= 128 * QP, "LDS map");
             const int img = tcur.m0 / p.xa_Tq;
             const int Tk = p.xa_Tk;
+            auto xstamp = [&](int slot) __attribute__((always_inline)) {       // diagnostics (tools/xattn_bench.py): a second block of 8 stamps per block behind the loop's 4096 x 8
+                if (p.tbuf && tid == 0 && blockIdx.x < 4096) p.tbuf[32768 + (long)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+            };
+            xstamp(0);
             // 1. ring drained (every wave's own tail DMAs, then everybody's), K on its way
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+            xstamp(1);
             {
                 const _Float16* kb = p.xa_k + (long)img * Tk * p.xa_ldk + tcur.n0;
 #pragma unroll
                 for (int it = 0; it < KIT; ++it) {
                     const int q = min(it * 512 + tid, KCH - 1);                        // (every lane of every instruction loads: the counted wait below counts instructions)
-                    const int row = min(q / 41, Tk - 1), cc = min(q % 41, 39);       // (chunk 40 of a row is the pad, rows >= Tk duplicates: any valid address)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + (long)row * p.xa_ldk + cc * 8),
+                    const int row = q / 40, sl = q % 40;                               // LDS slot sl of row `row` holds the chunk whose swizzled position it is
+                    const int cc = (sl & ~7) | ((sl & 7) ^ ((row >> 1) & 7));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + (long)min(row, Tk - 1) * p.xa_ldk + cc * 8),      // (rows >= Tk: duplicates of the last key)
                                                      (__attribute__((address_space(3))) void*)(smem + (it * 512 + wave * 64) * 16), 16, 0, 0);
                 }
             }
             // 2. q -> fp16 -> LDS [row][320 columns]
             {
-                unsigned char* qw = smem + QOFF + (wr * WM + l15) * QP + (wc * WN + 4 * lg) * 2;
+                // row = wr WM + qa WM/2 + 16 i + l15 (swizzle term l15 >> 1), columns wc WN + 16 c + 4 lg .. + 3 = chunk 10 wc + 2 c + (lg >> 1), byte 8 (lg & 1) of it
+                unsigned char* qw = smem + QOFF + (wr * WM + l15) * QP + (lg & 1) * 8;
+                const int sw = l15 >> 1;
 #pragma unroll
                 for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -718,22 +748,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                         for (int c = 0; c < NCB; ++c) {
                             const f32x4 v = acc[qa][i][c] + cb[c];
                             const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                            *reinterpret_cast<f16x4*>(qw + (qa * (WM / 2) + i * 16) * QP + c * 32) = h;
+                            const int ch = wc * (WN / 8) + 2 * c + (lg >> 1);
+                            *reinterpret_cast<f16x4*>(qw + (qa * (WM / 2) + i * 16) * QP + (((ch & ~7) | ((ch & 7) ^ sw)) << 4)) = h;
                         }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the ds_writes have LANDED before the barrier lets the readers through (a raw s_barrier waits for nothing)
             __builtin_amdgcn_s_barrier();
+            xstamp(2);
             // 3. this wave's q fragments: rows 16 wave + l15, head h, k-step s (natural k order: d = 32 s + 8 lg + e)
             f16x8 qf[5][2];
             {
-                const unsigned char* qr = smem + QOFF + (wave * 16 + l15) * QP + lg * 16;
+                const unsigned char* qr = smem + QOFF + (wave * 16 + l15) * QP;
+                const int sw = l15 >> 1;
 #pragma unroll
                 for (int h = 0; h < 5; ++h)
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) qf[h][s2] = *reinterpret_cast<const f16x8*>(qr + h * 128 + s2 * 64);
+                    for (int s2 = 0; s2 < 2; ++s2) qf[h][s2] = *reinterpret_cast<const f16x8*>(qr + h * 128 + (((4 * s2 + lg) ^ sw) << 4));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // fragments in registers: the q image may be overwritten
             __builtin_amdgcn_s_barrier();
+            xstamp(3);
             {
                 const _Float16* vb = p.xa_vt + ((long)img * p.N + tcur.n0) * 96;
 #pragma unroll
@@ -746,86 +780,143 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
             }
             wait_vmcnt<VIT>();                                        // K landed (this wave's part; the V^T instructions are younger)
             __builtin_amdgcn_s_barrier();
-            // 4. scores + softmax, head by head; P stays in registers (3 k-steps of 32 keys per head; keys 80..95 are zero)
+            xstamp(4);
+            // 4. scores + softmax.  Every stage runs over ALL five heads before the next one starts: a head's chain (fragment reads -> MFMAs -> max -> exchange -> exp -> sum ->
+            //    exchange -> pack) is ~1300 clocks of latency end to end, and with two waves per SIMD nothing else hides it -- as five interleaved independent chains the
+            //    stages cost their issue time (in-kernel stamps, tools/xattn_bench.py: 6.7k -> clocks per block for this phase).  P stays in registers (3 k-steps of 32
+            //    keys per head; keys 80..95 are zero).
             f16x8 pf[5][3];
             float linv[5];
+            f32x4 sa[5][5];
 #pragma unroll
-            for (int h = 0; h < 5; ++h) {
-                f32x4 sa[5];
+            for (int kt = 0; kt < 5; ++kt) {
+                const int krow = min(16 * kt + l15, KROWS - 1);              // (rows >= Tk of the image hold duplicates of the last key: masked below)
+                const int ksw = (krow >> 1) & 7;
 #pragma unroll
-                for (int kt = 0; kt < 5; ++kt) {
-                    const unsigned char* kr = smem + min(16 * kt + l15, Tk - 1) * QP + lg * 16 + h * 128;
+                for (int h = 0; h < 5; ++h) {
+                    const unsigned char* kr = smem + krow * QP + h * 128;
                     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(kr + s2 * 64), qf[h][s2], a4, 0, 0, 0);
-                    sa[kt] = a4;
+                    for (int s2 = 0; s2 < 2; ++s2) a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(kr + (((4 * s2 + lg) ^ ksw) << 4)), qf[h][s2], a4, 0, 0, 0);
+                    sa[h][kt] = a4;
                 }
-                // keys of tile kt in this lane: 16 kt + 4 lg + e
+            }
+            // keys of tile kt in this lane: 16 kt + 4 lg + e
+            {
+                const int kfirst = 4 * lg;
 #pragma unroll
-                for (int kt = 4; kt < 5; ++kt)
+                for (int kt = 0; kt < 5; ++kt) {
+                    if (kt < 4 && Tk > 64) continue;                     // (the text context: only the last key tile is ragged; wave-uniform test)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (16 * kt + 4 * lg + e >= Tk) sa[kt][e] = -3.0e38f;
-                if (Tk <= 64) {
+                    for (int e = 0; e < 4; ++e) {
+                        const bool dead = 16 * kt + kfirst + e >= Tk;
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (16 * kt + 4 * lg + e >= Tk) sa[kt][e] = -3.0e38f;
+                        for (int h = 0; h < 5; ++h) if (dead) sa[h][kt][e] = -3.0e38f;
+                    }
                 }
-                float mx = sa[0][0];
+            }
+            // v (op) the value of lane ^ 16 / lane ^ 32 without an LDS round trip: v_permlane16_swap / v_permlane32_swap exchange odd rows (the upper half) of their first
+            // operand with even rows (the lower half) of the second; on two copies of v both results together hold the pair.  hipcc (ROCm 7.2) needs two opaque fences here:
+            // handed the same value twice it may give both tied operands one register (the instruction then swaps a register with itself), and an arithmetic use of BOTH
+            // results folds to the first one (`r[0] + r[1]` compiled to v + v: seen in the ISA, and as softmax sums off by a constant factor per row) -- the empty asm
+            // statements make the copy and the two results distinct values for the optimiser and emit nothing but one v_mov.
+            auto xor16 = [&](float v, auto op) __attribute__((always_inline)) {
+                unsigned c;
+                asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(v));
+                const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), c, false, false);
+                unsigned r0 = r[0], r1 = r[1];
+                asm volatile("" : "+v"(r0), "+v"(r1));
+                return op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+            };
+            auto xor32 = [&](float v, auto op) __attribute__((always_inline)) {
+                unsigned c;
+                asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(v));
+                const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), c, false, false);
+                unsigned r0 = r[0], r1 = r[1];
+                asm volatile("" : "+v"(r0), "+v"(r1));
+                return op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+            };
+            auto fmx = [](float a, float b) __attribute__((always_inline)) { return fmaxf(a, b); };
+            auto fad = [](float a, float b) __attribute__((always_inline)) { return a + b; };
+            float msc[5];
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                f32x4 m4 = sa[h][0];
+#pragma unroll
+                for (int kt = 1; kt < 5; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m4[e] = fmaxf(m4[e], sa[h][kt][e]);
+                msc[h] = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            }
+#pragma unroll
+            for (int h = 0; h < 5; ++h) msc[h] = xor16(msc[h], fmx);
+#pragma unroll
+            for (int h = 0; h < 5; ++h) msc[h] = -xor32(msc[h], fmx) * p.xa_sc;
+            float lsum[5];
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sa[kt][e]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float msc = -mx * p.xa_sc;
-                float sum = 0.f;
+                    for (int e = 0; e < 4; ++e) { const float pe = __builtin_amdgcn_exp2f(fmaf(sa[h][kt][e], p.xa_sc, msc[h])); sa[h][kt][e] = pe; s4[e] += pe; }
+                lsum[h] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            }
 #pragma unroll
-                for (int kt = 0; kt < 5; ++kt)
+            for (int h = 0; h < 5; ++h) lsum[h] = xor16(lsum[h], fad);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float pe = __builtin_amdgcn_exp2f(fmaf(sa[kt][e], p.xa_sc, msc)); sa[kt][e] = pe; sum += pe; }
-                sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-                linv[h] = 1.0f / sum;
+            for (int h = 0; h < 5; ++h) linv[h] = 1.0f / xor32(lsum[h], fad);
+#pragma unroll
+            for (int h = 0; h < 5; ++h)
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
                     f16x8 f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        f[e] = (_Float16)sa[2 * ks][e];
-                        f[4 + e] = (2 * ks + 1 < 5) ? (_Float16)sa[(2 * ks + 1 < 5) ? 2 * ks + 1 : 0][e] : (_Float16)0.f;
+                        f[e] = (_Float16)sa[h][2 * ks][e];
+                        f[4 + e] = (2 * ks + 1 < 5) ? (_Float16)sa[h][(2 * ks + 1 < 5) ? 2 * ks + 1 : 0][e] : (_Float16)0.f;
                     }
                     pf[h][ks] = f;
                 }
-            }
+            xstamp(5);
             wait_vmcnt<0>();                                          // V^T landed
             __builtin_amdgcn_s_barrier();
-            // 5. O^T = V^T . P, normalised, fp16; pairs of 16-column blocks exchange halves so that every lane stores 16 contiguous bytes (as epi_fast)
+            xstamp(6);
+            // 5. O^T = V^T . P, normalised, fp16; pairs of 16-column blocks exchange halves so that every lane stores 16 contiguous bytes (as epi_fast).  Per head: the 24
+            //    8-byte fragment reads first, then 4 independent accumulation chains (one per 16 columns of d), k-step outermost
             _Float16* orow = p.xa_out + (long)(tcur.m0 + wave * 16 + l15) * p.xa_ldo + tcur.n0 + 8 * (lg >> 1) + 16 * (lg & 1);
 #pragma unroll
             for (int h = 0; h < 5; ++h) {
-                f32x4 oa[4];
+                union VF { f16x4 h4[2]; f16x8 f; };
+                VF vf[4][3];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const unsigned char* vr = smem + QOFF + (h * 64 + dt * 16 + l15) * VP + lg * 8;
-                    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 3; ++ks) {
-                        union { f16x4 h4[2]; f16x8 f; } vf;
-                        vf.h4[0] = *reinterpret_cast<const f16x4*>(vr + ks * 64);            // keys 32 ks + 4 lg ..
-                        vf.h4[1] = *reinterpret_cast<const f16x4*>(vr + ks * 64 + 32);       // keys 32 ks + 16 + 4 lg ..
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.f, pf[h][ks], a4, 0, 0, 0);
+                        vf[dt][ks].h4[0] = *reinterpret_cast<const f16x4*>(vr + ks * 64);            // keys 32 ks + 4 lg ..
+                        vf[dt][ks].h4[1] = *reinterpret_cast<const f16x4*>(vr + ks * 64 + 32);       // keys 32 ks + 16 + 4 lg ..
                     }
-                    oa[dt] = a4 * linv[h];
                 }
+                f32x4 oa[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][ks].f, pf[h][ks], oa[dt], 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < 4; dt += 2) {
-                    const f16x4 h0 = {(_Float16)oa[dt][0], (_Float16)oa[dt][1], (_Float16)oa[dt][2], (_Float16)oa[dt][3]};
-                    const f16x4 h1 = {(_Float16)oa[dt + 1][0], (_Float16)oa[dt + 1][1], (_Float16)oa[dt + 1][2], (_Float16)oa[dt + 1][3]};
+                    const f32x4 o0 = oa[dt] * linv[h], o1 = oa[dt + 1] * linv[h];
+                    const f16x4 h0 = {(_Float16)o0[0], (_Float16)o0[1], (_Float16)o0[2], (_Float16)o0[3]};
+                    const f16x4 h1 = {(_Float16)o1[0], (_Float16)o1[1], (_Float16)o1[2], (_Float16)o1[3]};
                     const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1);
                     const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
                     *reinterpret_cast<u32x4*>(orow + h * 64 + dt * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
                 }
             }
+            xstamp(7);
         }
     };
     auto epilogue = [&]() __attribute__((always_inline)) {

@@ -34,13 +34,11 @@ struct TTP {
     float* C32; long ldc32;
     _Float16* C16; long ldc16;
     int nbm, nbn, prio;
-    const float *ln_g, *ln_b; float ln_eps; _Float16* ln_y; long ldln; float* ln_ws; unsigned* ln_cnt;
+    const float *ln_g, *ln_b; float ln_eps; _Float16* ln_y; long ldln; float* ln_ws; unsigned* ln_cnt; int ln_slot;
     unsigned long long* tbuf;      // diagnostics: 4 words per block {start, loop end, exit (100 MHz), HW_ID | XCC_ID << 32}
-    // TT_CHAIN_*: the SECOND GEMM of the launch, C16b = fp16(ln_y . B2^T + bias2): same M, N columns, K = N (see the kernel)
-    const _Float16* B2; long ldb2; const float* bias2; _Float16* C16b; long ldc16b;
 };
 
-enum { TT_F16 = 1, TT_F32 = 2, TT_F32_RES = 3, TT_F32_LN = 4, TT_F32_RES_LN = 5, TT_CHAIN_LN = 6, TT_CHAIN_RES_LN = 7 };
+enum { TT_F16 = 1, TT_F32 = 2, TT_F32_RES = 3, TT_F32_LN = 4, TT_F32_RES_LN = 5 };
 
 template <int N>
 __device__ __forceinline__ void tt_wait_vmcnt()
@@ -73,12 +71,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     const int m0 = bmi * BM, n0 = bni * BN;
     // priority class: blocks 0..255 (the first one on every CU), 512..767, ... run ahead of the others
     if (p.prio && !((v >> 8) & 1)) __builtin_amdgcn_s_setprio(2);
-    if constexpr (EPI == TT_CHAIN_LN || EPI == TT_CHAIN_RES_LN) {
-        // the second GEMM reads its partners' rows from the XCD's L2: the partner tiles (blocks 8 apart) must sit on this block's XCD.  They do (block id % 8, measured on
-        // every grid size: tools/gemm_tt_xcd_check.py); should a driver ever place them otherwise the launch says so through the sticky give-up word and the plan retries
-        // on separate launches
-        if (tid == 0 && (int)(__builtin_amdgcn_s_getreg(63508) & 0xf) != (v & 7)) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    unsigned ln_epoch = 0;
+    if constexpr (EPI == TT_F32_LN || EPI == TT_F32_RES_LN) ln_epoch = __hip_atomic_load(p.ln_cnt + p.ln_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every lane the same word: the tag of this launch's records is epoch + 1)
     if (p.tbuf && tid == 0) {
         p.tbuf[(long)v * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         p.tbuf[(long)v * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -90,16 +84,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     const _Float16* pa = p.A + (long)(m0 + srow) * p.lda + schunk;
     const _Float16* pb = p.B + (long)(n0 + srow) * p.ldb + schunk;
     long a32 = 32 * p.lda, b32 = 32 * p.ldb;
-    constexpr bool CHAIN = EPI == TT_CHAIN_LN || EPI == TT_CHAIN_RES_LN;
-    bool second = false;                                                          // CHAIN: staging for the second GEMM (block-uniform)
     auto issue_one = [&](int g, int st) __attribute__((always_inline)) {          // g 0..NI-1: A row groups, NI..NS-1: B row groups; K tile = where pa / pb stand
         if (g < NI) {
-            // the A operand of the second GEMM was written by the partner tiles a moment ago and sits at addresses this CU may have read in the first GEMM (the LayerNorm rows
-            // often land on the first A operand): agent-scope loads go past the vector L1 to the XCD's L2, where the partners' rows are
-            if (CHAIN && second)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + g * a32),
-                                                 (__attribute__((address_space(3))) void*)(smem + st * A_ST + wave * 1024 + g * 4096), 16, 0, 16);
-            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + g * a32),
                                              (__attribute__((address_space(3))) void*)(smem + st * A_ST + wave * 1024 + g * 4096), 16, 0, 0);
         } else
@@ -219,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             }
     } else {
         // *_LN: fp32 output (+ residual) AND the LayerNorm of the finished rows as fp16 (gemm_pp.hpp epi_ln with nbn = N / 160 partner tiles and 2 wave columns)
-        constexpr bool RES = EPI == TT_F32_RES_LN || EPI == TT_CHAIN_RES_LN;
+        constexpr bool RES = EPI == TT_F32_RES_LN;
         f32x4 rr[RES ? NI : 1][RES ? NC : 1];
         if constexpr (RES) {
             const float* resp = p.resid + (long)(wrow0 + l15) * p.ldr + wcol0 + 4 * lg;
@@ -272,47 +258,75 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             chan(n, mu, m2, (float)WN, e[1][0], e[1][1]);
             mean_t[i] = mu; m2_t[i] = m2;
         }
+        // ---- the partner tiles' row statistics (round 6: no ticket, no counters -- the records carry their own validity).  Every tile writes, per row, ONE 16-byte record
+        // {mean, tag, m2, tag} = two self-tagged 8-byte granules (write-through store), tag = this launch's epoch + 1.  The epoch is this launch's own word (ln_cnt[ln_slot]),
+        // read at kernel entry and advanced by tile (0, 0) once it has its partners' records; the scratch is the launch's own too (mlblock.c), so a record with the right tag
+        // can only be this launch's.  One wave per wave row loads the partners' records with agent-scope loads UNTIL both tags of all of them match (bounded), hands them to
+        // the other waves through LDS, and everything else is as before: same fp32 values, combined in tile order.  Nothing to reset, nothing to clear after a give-up.
         const int nbn = p.nbn;
-        f32x2* gws = reinterpret_cast<f32x2*>(p.ln_ws) + ((long)bmi * nbn * BM);          // [tile column][128 rows]
-        unsigned* cnt = p.ln_cnt + (bmi * 2 + wr) * 16;                                    // [row block][wave row]{arrivals, departures}
-        if (wc == 0) {
-            if (lg == 0) {
-                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gws + (long)bni * BM), 0, BM * 8, 0x00020000);
+        const unsigned tag = ln_epoch + 1u;
+        u32x4* gws = reinterpret_cast<u32x4*>(p.ln_ws) + ((long)bmi * nbn * BM);           // [tile column][128 rows] records
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)gws, 0, nbn * BM * 16, 0x00020000);
+        if (wc == 0 && lg == 0) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const f32x2 tt = {mean_t[i], m2_t[i]};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tt), rs, (wr * 64 + i * 16 + l15) * 8, 0, 16);   // sc1: write-through
-                }
+            for (int i = 0; i < NI; ++i) {
+                const u32x4 rec = {__builtin_bit_cast(unsigned, mean_t[i]), tag, __builtin_bit_cast(unsigned, m2_t[i]), tag};
+                __builtin_amdgcn_raw_buffer_store_b128(rec, rs, (bni * BM + wr * 64 + i * 16 + l15) * 16, 0, 16);      // sc1: write-through
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         float* c32b = p.C32 + (long)(wrow0 + l15) * p.ldc32 + wcol0 + 4 * lg;
-        auto store_c32 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(c32b + (long)i * 16 * p.ldc32 + c * 16) = acc[i][c];
-        };
-        if constexpr (!CHAIN) store_c32();      // (CHAIN: after the fp16 rows, see below -- the second GEMM waits for the rows, the fp32 output can drain under it)
+            for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(c32b + (long)i * 16 * p.ldc32 + c * 16) = acc[i][c];      // the fp32 output goes out while the partners' records arrive
+        // (in the ring's LDS: every wave passed its last fragment reads before the barrier above, and this loop leaves no LDS-DMA in flight)
+        f32x2* red2 = reinterpret_cast<f32x2*>(smem);                                      // [128 rows][8 tiles]
         if (wc == 0) {
+            // lane (l15, lg): partner tiles lg and lg + 4, rows 16 i + l15 of this wave row.  (This tile's own record comes from registers.)
+            const bool act0 = lg < nbn, act1 = lg + 4 < nbn;
+            const bool own0 = lg == bni, own1 = lg + 4 == bni;
+            u32x4 rec0[NI], rec1[NI];
             unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
-            if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                bool ok = true;
+                asm volatile("" ::: "memory");      // the record loads below are plain (readonly) buffer loads to the compiler: without this it hoists them out of the poll loop
+                if (act0 && !own0) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) rec0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lg * BM + wr * 64 + i * 16 + l15) * 16, 0, 16);      // sc1: past the vector L1, to the XCD's L2
+                }
+                if (act1 && !own1) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) rec1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lg + 4) * BM + wr * 64 + i * 16 + l15) * 16, 0, 16);
+                }
+                if (act0 && !own0) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) ok = ok && rec0[i][1] == tag && rec0[i][3] == tag;
+                }
+                if (act1 && !own1) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) ok = ok && rec1[i][1] == tag && rec1[i][3] == tag;
+                }
+                if (__all(ok) || ++spins >= (1u << 20)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky give-up word (mlctx_handoff_check)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                f32x2* e = red2 + (wr * 64 + i * 16 + l15) * 8;
+                if (act0) e[lg] = own0 ? f32x2{mean_t[i], m2_t[i]} : f32x2{__uint_as_float(rec0[i][0]), __uint_as_float(rec0[i][2])};
+                if (act1) e[lg + 4] = own1 ? f32x2{mean_t[i], m2_t[i]} : f32x2{__uint_as_float(rec1[i][0]), __uint_as_float(rec1[i][2])};
+            }
+            if (bmi == 0 && bni == 0 && wr == 0 && lane == 0) __hip_atomic_store(p.ln_cnt + p.ln_slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch of this op uses tag + 1
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the ds_writes have LANDED before the barrier lets the readers through
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // program order only: the partner tiles' partials below are relaxed agent-scope loads and must not be hoisted above the poll / barrier
         float mean_r[NI], rstd_r[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const f32x2* e = gws + wr * 64 + i * 16 + l15;
-            auto ld2 = [&](const f32x2* qp) __attribute__((always_inline)) {
-                const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(qp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return __builtin_bit_cast(f32x2, u);
-            };
-            f32x2 tt = ld2(e);
+            const f32x2* e = red2 + (wr * 64 + i * 16 + l15) * 8;
+            f32x2 tt = e[0];
             float n = (float)BN, mu = tt[0], m2 = tt[1];
-            for (int b = 1; b < nbn; ++b) { tt = ld2(e + (long)b * BM); chan(n, mu, m2, (float)BN, tt[0], tt[1]); }
+            for (int b = 1; b < nbn; ++b) { tt = e[b]; chan(n, mu, m2, (float)BN, tt[0], tt[1]); }
             mean_r[i] = mu; rstd_r[i] = 1.0f / sqrtf(m2 / n + p.ln_eps);
         }
         f32x4 gm[NC], bt[NC];
@@ -336,50 +350,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 *reinterpret_cast<u32x4*>(rowp + c * 16) = u32x4{r0[0], r1[0], r0[1], r1[1]};
             }
             *reinterpret_cast<f16x4*>(p.ln_y + (long)(wrow0 + l15 + i * 16) * p.ldln + wcol0 + (NC - 1) * 16 + 4 * lg) = y4(NC - 1);
-        }
-        // departures (after the rows are on their way: see gemm_pp.hpp): the last poller of this (row block, wave row) clears both counters for the next launch
-        if (wc == 0 && lane == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)(nbn - 1)) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }        if constexpr (CHAIN) {
-            // ---- the SECOND GEMM of the launch (round 5): C16b = fp16(ln_y . B2^T + bias2) for the same tile coordinates -- the projection that consumes this LayerNorm
-            // (the cross-attention q projection behind the self-attention output projection).  Its A rows [m0, m0 + 128) x N are the fp16 rows the nbn partner tiles of
-            // this row block have just written: every tile counts itself in once its rows are acknowledged (vmcnt(0) of all four waves, then one ticket), one wave polls,
-            // and the K loop runs again on the new operands.  What it buys: no dispatch boundary, no cold prologue, and the fp32 output of the first GEMM (80 KB per tile,
-            // issued after the ticket) drains to memory under the second K loop instead of in front of a kernel end.
-            unsigned* cnt2 = p.ln_cnt + (bmi * 2) * 16 + 2;                                  // {arrivals, departures} of the row block's finished tiles (words 2, 3 of its first group)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // this wave's fp16 rows are in the XCD's L2
-            __builtin_amdgcn_s_barrier();
-            if (tid == 0) __hip_atomic_fetch_add(cnt2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            store_c32();
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            second = true;
-            pa = p.ln_y + (long)(m0 + srow) * p.ldln + schunk; a32 = 32 * p.ldln;
-            pb = p.B2 + (long)(n0 + srow) * p.ldb2 + schunk; b32 = 32 * p.ldb2;
-            if (wave == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
-                if (spins >= (1u << 20) && lane == 0) __hip_atomic_store(p.ln_cnt + 8191, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (as above: the second GEMM's loads of the finished rows stay behind the poll / barrier)
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(cnt2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)(nbn - 1)) {
-                    __hip_atomic_store(cnt2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt2 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            mainloop(p.N / BK);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cb[c] = p.bias2 ? *reinterpret_cast<const f32x4*>(p.bias2 + wcol0 + c * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
-            epi_f16(p.C16b, p.ldc16b);
         }
     }
     if (p.tbuf && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.tbuf[(long)v * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
@@ -406,22 +376,10 @@ extern "C" int mlsd_gemm_tt_eligible(const mlsd_gemm_args* a, int ncu)
             // The N / 160 tiles of a row block wait for each other inside the launch: all of them must be resident together, which a grid of at most 2 blocks per CU guarantees
             // without any assumption on the dispatch order (larger grids work while blocks are dispatched in id order -- the soak runs them with MLSD_TT_LN_ANYGRID=1 -- but are
             // not taken).  Partner tiles are blocks 8 apart: one XCD (checked: XCC_ID == id % 8 for every block of 256 .. 1024-block grids, tools/gemm_tt_xcd_check.py), so the
-            // write-through partials and agent-scope loads meet in that XCD's L2.  Counters: 16 words per (row block, wave row) in 8192 words.
+            // write-through records and agent-scope loads meet in that XCD's L2.  At most 8 partner tiles (two per lane group of the gathering wave).
             static int anygrid = -1;      // MLSD_TT_LN_ANYGRID=1: also grids of more than 2 blocks per CU (tools/soak_r5.py)
             if (anygrid < 0) { const char* e = getenv("MLSD_TT_LN_ANYGRID"); anygrid = (e && *e == '1') ? 1 : 0; }
-            if (a->M / 128 > 256 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > 2L * ncu)) return 0;
-            // MEASURED AND NOT ADOPTED (profiles/NOTES.md "Round 5", tools/gemm_chain_bench.py, profiles/r5_ab_chain.txt): bit-identical to the separate launches, 86 -> 81 us on the
-            // pair of 8192x1280x1280 launches against 80.5 for the plan's ping-pong + 128x160 pair; in the plan SDXL b4 +1.5 %, b2 +0.7 %, SD1.5 b1 -0.3 %.  EXPERIMENTS builds only.
-#ifdef MLSD_GEMM_EXPERIMENTS
-            if (a->chain_W) {      // + the GEMM that consumes the LayerNorm, in the same launch (TT_CHAIN_*): fp16(ln_y16 . chain_W^T + chain_bias) -> chain_C16, N columns, K = N
-                if (!a->chain_C16 || (a->N & 63) || a->N < 128 || a->ldln < a->N || (a->chain_ldb & 7) || a->chain_ldb < a->N || (a->chain_ldc16 & 7) || a->chain_ldc16 < a->N ||
-                    ((uintptr_t)a->chain_W & 15) || ((uintptr_t)a->chain_C16 & 15) || (a->chain_bias && ((uintptr_t)a->chain_bias & 15)) ||
-                    (long)(a->M / 128) * (a->N / 160) > 2L * ncu) return 0;      // (all tiles resident together: the second GEMM waits for its partners' rows)
-                return a->resid ? TT_CHAIN_RES_LN : TT_CHAIN_LN;
-            }
-#else
-            if (a->chain_W) return 0;
-#endif
+            if (a->N / 160 > 8 || a->ln_slot < 0 || a->ln_slot >= 8191 || ncu < 256 || (!anygrid && (long)(a->M / 128) * (a->N / 160) > 2L * ncu)) return 0;
             return a->resid ? TT_F32_RES_LN : TT_F32_LN;
         }
         return a->resid ? TT_F32_RES : TT_F32;
@@ -437,8 +395,7 @@ extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu)
     p.A = (const _Float16*)a->A; p.B = (const _Float16*)a->W_; p.lda = a->lda; p.ldb = a->ldb; p.M = a->M; p.N = a->N; p.K = a->K;
     p.bias = a->bias; p.resid = a->resid; p.ldr = a->ldr; p.C32 = a->C32; p.ldc32 = a->ldc32; p.C16 = (_Float16*)a->C16; p.ldc16 = a->ldc16;
     p.nbm = a->M / 128; p.nbn = a->N / 160; p.prio = g_tt_prio;
-    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt; p.tbuf = g_tt_tbuf;
-    p.B2 = (const _Float16*)a->chain_W; p.ldb2 = a->chain_ldb; p.bias2 = a->chain_bias; p.C16b = (_Float16*)a->chain_C16; p.ldc16b = a->chain_ldc16;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_y = (_Float16*)a->ln_y16; p.ldln = a->ldln; p.ln_ws = a->ln_ws; p.ln_cnt = a->ln_cnt; p.ln_slot = a->ln_slot; p.tbuf = g_tt_tbuf;
     const bool ln = epi >= TT_F32_LN;
     const size_t LDS = 2 * (size_t)(128 + 160) * 128 + (ln ? 2048 : 0);
     const dim3 grid(p.nbm * p.nbn), block(256);
@@ -458,10 +415,6 @@ extern "C" int mlsd_gemm_tt(const mlsd_gemm_args* a, void* stream, int ncu)
     case TT_F32: return go(gemm_tt_kernel<TT_F32>);
     case TT_F32_RES: return go(gemm_tt_kernel<TT_F32_RES>);
     case TT_F32_LN: return go(gemm_tt_kernel<TT_F32_LN>);
-#ifdef MLSD_GEMM_EXPERIMENTS
-    case TT_CHAIN_LN: return go(gemm_tt_kernel<TT_CHAIN_LN>);
-    case TT_CHAIN_RES_LN: return go(gemm_tt_kernel<TT_CHAIN_RES_LN>);
-#endif
     default: return go(gemm_tt_kernel<TT_F32_RES_LN>);
     }
 }

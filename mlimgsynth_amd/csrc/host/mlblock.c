@@ -25,7 +25,7 @@
 #define VARIANT_TT 31           /* two tiles in flight per CU (gemm_tt.hip, round 5) */
 #define VARIANT_SKINNY 30       /* the skinny-M weight-streaming kernel (gemm_skinny.hpp): always runs through the split-K workspace */
 #define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile; word 4095: sticky give-up */
-#define LN_CNT_WORDS 8192       /* LayerNorm fold: arrival / departure counters per (row block, wave row); word 8191: sticky give-up */
+#define LN_CNT_WORDS 8192       /* LayerNorm fold: one epoch word per folded launch (round 6: self-tagged records instead of arrival / departure counters); word 8191: sticky give-up */
 
 #define VEC_PUSH(C, arr, n, cap, T) \
 	(((n) == (cap) ? ((cap) = (cap) ? (cap)*2 : 64, (arr) = (T*)realloc((arr), sizeof(T)*(cap))) : 0), &(arr)[(n)++])
@@ -84,7 +84,7 @@ static void ctx_reset_(MLCtx* C)
 	C->n_chunks = 0; C->cur = NULL; C->cur_left = 0; C->n_free = 0;
 	C->mem_compute = C->mem_params = C->mem_live = C->mem_peak_live = 0;
 	C->err = 0; C->prepared = 0; C->tuned = 0; C->n_tune_miss = 0; C->n_tune_near = 0; C->static_valid = 0; C->n_once = 0;
-	C->n_ln_fused = 0; C->n_ln_alias = 0; C->n_gn_fused = 0; C->n_chained = 0;
+	C->n_ln_fused = 0; C->n_ln_alias = 0; C->n_gn_fused = 0;
 	memset(&C->kvb, 0, sizeof(C->kvb));
 	memset(&C->epb, 0, sizeof(C->epb));
 	memset(&C->info, 0, sizeof(C->info));
@@ -117,7 +117,6 @@ MLB_API MLTensor* mlctx_result(MLCtx* C) { return C->result; }
 MLB_API int mlctx_sync(MLCtx* C) { return mlsd_stream_sync(C->stream) ? -1 : 1; }
 
 MLB_API int mlctx_ln_fused(const MLCtx* C) { return C ? C->n_ln_fused : 0; }
-MLB_API int mlctx_chained(const MLCtx* C) { return C ? C->n_chained : 0; }      /* Linears that run as the second GEMM of the launch that produces their (LayerNorm'ed) input */
 MLB_API int mlctx_ln_alias_refused(const MLCtx* C) { return C ? C->n_ln_alias : 0; }   /* LayerNorm folds refused because the fp16 rows would have overwritten an operand of their producer */
 /* CUs the plan's stream may use (a CU-masked stream, a partitioned device); 0 = the whole device.  Below 256 the plan is built without in-launch hand-offs
  * (stream-K, LayerNorm fold): their blocks wait for partners that a masked stream may never make resident.  Call before mlctx_prep. */
@@ -138,7 +137,8 @@ MLB_API int mlctx_handoff_check(MLCtx* C)
 	if (!w && !w2) return 0;
 	mlsd_stream_sync(C->stream);
 	if (C->sk_flags) mlsd_memset(C->sk_flags, 0, SK_FLAG_WORDS * 4, C->stream);
-	if (C->ln_cnt) mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream);
+	if (C->ln_cnt) mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream);      /* epochs back to 0 ... */
+	if (C->ln_ws) mlsd_memset(C->ln_ws, 0, C->ln_ws_bytes, C->stream);              /* ... and every record with them: a half-written generation must not meet its own tag again */
 	mlsd_stream_sync(C->stream);
 	return mlsd_set_error(-8, "an in-launch hand-off (%s) timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid",
 	                      w ? "stream-K" : "LayerNorm statistics");
@@ -173,10 +173,6 @@ MLB_API int mlctx_handoffs_off(MLCtx* C)
 		MLOp *o = &C->ops[i];
 		if (o->kind != OP_GEMM) continue;
 		mlsd_gemm_args *g = &o->u.gemm;
-		if (g->chain_W && i + 2 < C->n_ops && C->ops[i+2].kind == OP_GEMM && C->ops[i+2].fused) {      /* the consuming Linear gets its own launch back */
-			C->ops[i+2].fused = 0; o->flops -= C->ops[i+2].flops; C->n_chained--;
-			g->chain_W = NULL; g->chain_bias = NULL; g->chain_C16 = NULL;
-		}
 		if (g->ln_y16 && mlsd_gemm_ln_fused(g) == 1) {      /* (a LayerNorm in a split-K reduce pass waits for nobody: it stays) */
 			g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL;
 			if (i + 1 < C->n_ops && C->ops[i+1].kind == OP_LN && C->ops[i+1].fused) { C->ops[i+1].fused = 0; C->n_ln_fused--; }
@@ -647,8 +643,7 @@ static int run_op(MLCtx* C, MLOp* op)
 {
 	void *st = C->stream;
 	switch (op->kind) {
-	case OP_GEMM: if (op->fused) return 0;                  /* runs as the second GEMM of its producer's launch (wire_ln_fold, chain_candidate) */
-	              return mlsd_gemm(&op->u.gemm, st);
+	case OP_GEMM: return mlsd_gemm(&op->u.gemm, st);
 	case OP_ATTN: return mlsd_attention(&op->u.attn, st);
 	case OP_GN:   if (op->fused) return 0;                    /* its producer's reduce pass ends with it (wire_gn_fold) */
 	              return mlsd_groupnorm(&op->u.gn, st);
@@ -1148,27 +1143,6 @@ static int tt_ln_on(void)
 	if (on < 0) { const char *e = getenv("MLSD_TT_LN"); on = (e && *e == '0') ? 0 : 1; }
 	return on;
 }
-/* Round 5: the Linear that consumes a handed-over LayerNorm as the SECOND GEMM of the producer's launch (gemm_tt.hip TT_CHAIN_*, mlsd_gemm_args.chain_W): the cross-attention
- * q projection behind the self-attention output projection (src/mlblock_nn.c:200-203 after :224-229).  `li` = index of the LayerNorm op; producer li - 1, consumer li + 1.
- * MLSD_TT_CHAIN=1 switches it on (EXPERIMENTS builds; A/B). */
-static int chain_on(void)
-{
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("MLSD_TT_CHAIN"); on = (e && *e == '1') ? 1 : 0; }      /* measured and not adopted (gemm_tt.hip): off unless asked for, and only EXPERIMENTS builds run it */
-	return on;
-}
-static int chain_candidate(const MLCtx* C, int li)
-{
-	if (!chain_on() || C->pstream || li < 1 || li + 1 >= C->n_ops) return 0;      /* (streamed weights: the consumer's weights belong to a later segment) */
-	const MLOp *o = &C->ops[li-1], *l = &C->ops[li], *n = &C->ops[li+1];
-	if (o->kind != OP_GEMM || l->kind != OP_LN || n->kind != OP_GEMM || o->once || n->once) return 0;
-	const mlsd_gemm_args *g = &o->u.gemm, *h = &n->u.gemm;
-	if (g->conv || h->conv || h->A != l->u.ln.y16 || h->lda != g->N || h->M != g->M || h->N != g->N || h->K != g->N || (g->M % 128) || (g->N % 320)) return 0;
-	if ((long)(g->M / 128) * (g->N / 160) > 512 || g->ksplit > 1 || g->act != MLSD_ACT_NONE || g->rowbias || g->bias_m || g->colstats || g->C16 || !g->C32) return 0;
-	if (h->act != MLSD_ACT_NONE || !h->C16 || h->C32 || h->resid || h->rowbias || h->bias_m || h->colstats || h->ln_y16 || h->gn_y16 || h->ksplit > 1) return 0;
-	return 1;
-}
-
 /* producers moved to the 128 x 160 kernel for a LayerNorm that then could not be handed over (alias rule, scratch) go back to the table's tile */
 static void restore_unfolded_promotions(MLCtx* C)
 {
@@ -1183,10 +1157,11 @@ static void wire_ln_fold(MLCtx* C)
 	const char *e = getenv("MLSD_NO_LN_FOLD");
 	if (e && *e && *e != '0') return;
 	if (C->cu_budget > 0 && C->cu_budget < 256) return;      /* the tiles of a row block must be resident together: not on a CU-masked stream */
-	/* pass 0 sizes the scratch block (largest user), pass 1 hands the LayerNorms over */
+	/* pass 0 sizes the scratch (round 6: a region PER folded launch -- its tiles exchange self-tagged records there, and a tag only has to tell this launch's own
+	 * generations apart: 16 bytes per row and column tile, 512 KB for 8192 x 1280), pass 1 hands the LayerNorms over: region + epoch word (ln_cnt[slot]) each */
 	for (int pass=0; pass<2; ++pass) {
-		size_t need_max = 0;
-		int any_splitk = 0;
+		size_t need_max = 0, ws_off = 0;
+		int any_splitk = 0, slot = 0;
 		for (int i=1;i<C->n_ops;++i) {
 			MLOp *l = &C->ops[i];
 			if (l->kind != OP_LN || !l->u.ln.y16 || l->u.ln.y32 || !l->u.ln.b) continue;
@@ -1203,7 +1178,7 @@ static void wire_ln_fold(MLCtx* C)
 			 * Only for N <= 640 (at most 4 partner tiles): in-plan A/B, same box (profiles/r5_gemm_tt_ln_inplan.txt): SD1.5 b1 evaluation -0.8 %, b2 -0.9 % (30 dispatches
 			 * fewer); at N = 1280 (8 partners; SDXL b1 / b2's 2048 x 1280 projections) the same move cost +1.0 / +1.2 % and is not made.
 			 * MLSD_TT_LN=0 keeps the table's tile and the separate LayerNorm. */
-			if (!pass && tt_ln_on() && g->tile_variant != VARIANT_TT && !(g->ksplit > 1) && ((!(g->tile_variant == 19 && !(g->N % 320)) && g->N <= 640) || chain_candidate(C, i)) &&
+			if (!pass && tt_ln_on() && g->tile_variant != VARIANT_TT && !(g->ksplit > 1) && (!(g->tile_variant == 19 && !(g->N % 320)) && g->N <= 640) &&
 			    !(g->M % 128) && !(g->N % 160) && !(g->K & 63) && g->K >= 128 && g->act == MLSD_ACT_NONE && !g->rowbias && !g->bias_m && !g->colstats && !g->C16 &&
 			    (!g->conv || (g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && !g->upsample)) && (long)(g->M / 128) * (g->N / 160) <= 512) {
 				o->saved_variant = g->tile_variant ? g->tile_variant : -1;
@@ -1212,9 +1187,9 @@ static void wire_ln_fold(MLCtx* C)
 			const int tt_form = g->tile_variant == VARIANT_TT && !(g->M % 128) && !(g->N % 160) && !(g->ksplit > 1) &&
 			                    (long)(g->M / 128) * (g->N / 160) <= 512;      /* (N / 160 partner tiles per row block; at most two blocks per CU: all resident together, gemm_tt.hip) */
 			const int pp_form = tt_form || (g->tile_variant != VARIANT_TT && !(g->M % 128) && !(g->N % 320) && !(g->ksplit > 1));
-			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 8 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 8 : 0;
-			if (!pass) { if (need > need_max) need_max = need; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }
-			if (need > C->ln_ws_bytes) continue;
+			const size_t need = tt_form ? (size_t)(g->M / 128) * (g->N / 160) * 128 * 16 : pp_form ? (size_t)(g->M / 128) * (g->N / 320) * 128 * 16 : 0;
+			if (!pass) { need_max += (need + 255) & ~(size_t)255; if (!pp_form && g->ksplit > 1) any_splitk = 1; continue; }      /* (need_max: the SUM over the candidates) */
+			if (ws_off + need > C->ln_ws_bytes || slot >= LN_CNT_WORDS - 1) continue;
 			if (!pp_form && !(g->ksplit > 1)) continue;
 			{	/* the fp16 rows are written one op EARLIER now, by a launch that is still reading its operands: they must not land in a block the arena lent to one of
 				 * them (the attention output `a`, A operand of out_proj, is released right after out_proj is recorded and has exactly the size of the next LayerNorm's
@@ -1231,16 +1206,10 @@ static void wire_ln_fold(MLCtx* C)
 				if (clash && !(y0 == (const char*)g->A && g->K == g->N && g->lda == g->N && g->resid != (const float*)g->A &&
 				               !((const char*)g->W_ < y1 && y0 < (const char*)g->W_ + rd[2].n))) { C->n_ln_alias++; continue; }
 			}
-			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = C->ln_ws; g->ln_cnt = C->ln_cnt;
+			g->ln_y16 = l->u.ln.y16; g->ldln = g->N; g->ln_gamma = l->u.ln.g; g->ln_beta = l->u.ln.b; g->ln_eps = l->u.ln.eps; g->ln_ws = (float*)((char*)C->ln_ws + ws_off); g->ln_cnt = C->ln_cnt; g->ln_slot = slot;
 			if (mlsd_gemm_ln_fused(g) >= 1) {
 				l->fused = 1; C->n_ln_fused++; o->folded_from = o->saved_variant; o->saved_variant = 0;
-				if (tt_form && chain_candidate(C, i)) {
-					MLOp *n = &C->ops[i+1];
-					const mlsd_gemm_args *h = &n->u.gemm;
-					g->chain_W = h->W_; g->chain_ldb = h->ldb; g->chain_bias = h->bias; g->chain_C16 = h->C16; g->chain_ldc16 = h->ldc16;
-					if (mlsd_gemm_chained(g) == 1) { n->fused = 1; o->flops += n->flops; C->n_chained++; }
-					else { g->chain_W = NULL; g->chain_bias = NULL; g->chain_C16 = NULL; }
-				}
+				if (need) { ws_off += (need + 255) & ~(size_t)255; ++slot; }      /* (a LayerNorm in a split-K reduce pass needs neither) */
 			}
 			else { g->ln_y16 = NULL; g->ln_gamma = g->ln_beta = NULL; g->ln_ws = NULL; g->ln_cnt = NULL; }
 		}
@@ -1257,6 +1226,7 @@ static void wire_ln_fold(MLCtx* C)
 				if (C->ln_ws) { mlsd_free(C->ln_ws); C->mem_compute -= C->ln_ws_bytes; }
 				C->ln_ws = NULL; C->ln_ws_bytes = 0;
 				if (mlsd_malloc((void**)&C->ln_ws, need_max)) break;
+				if (mlsd_memset(C->ln_ws, 0, need_max, C->stream) || mlsd_stream_sync(C->stream)) { mlsd_free(C->ln_ws); C->ln_ws = NULL; break; }      /* tags 0: no launch ever writes that one */
 				C->ln_ws_bytes = need_max; C->mem_compute += need_max;
 			}
 		}

@@ -110,7 +110,6 @@ struct MLCtx {
 	void* splitk_ws; size_t splitk_ws_bytes;   /* split-K partial sums / stream-K slabs (one buffer: ops run in order on one stream) */
 	unsigned* sk_flags;                        /* stream-K: one flag per persistent block, zeroed once (consumers clear them) */
 	unsigned* ln_cnt; float* ln_ws; size_t ln_ws_bytes; int n_ln_fused;   /* LayerNorms ended in their producers (wire_ln_fold): counters, scratch, count */
-	int n_chained;          /* Linears that run as the second GEMM of their producer's launch */
 	int n_gn_fused;            /* GroupNorms ended in their producers' split-K reduce pass (wire_gn_fold) */
 	int n_ln_alias, cu_budget;   /* folds refused (output would alias a producer operand); CUs the plan's stream may use (0 = all) */
 	/* weight streaming (round 4; BASELINE configs[4], the reference's --unet-split: src/unet.c:390-458).  Weight storage is handed out from a VIRTUAL range, the master copy

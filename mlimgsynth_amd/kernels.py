@@ -17,9 +17,9 @@ class GemmArgs(ctypes.Structure):
                 ("resid", vp), ("ldr", c_i64), ("act", c_int), ("C32", vp), ("ldc32", c_i64), ("C16", vp),
                 ("ldc16", c_i64), ("bias_m", vp), ("act_after_resid", c_int), ("tile_variant", c_int),
                 ("ksplit", c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("colstats", vp), ("colstats_rows", c_int), ("sk_flags", vp),
-                ("ln_y16", vp), ("ldln", ctypes.c_int64), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", ctypes.c_float), ("ln_ws", vp), ("ln_cnt", vp),
+                ("ln_y16", vp), ("ldln", ctypes.c_int64), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", ctypes.c_float), ("ln_ws", vp), ("ln_cnt", vp), ("ln_slot", c_int),
                 ("gn_y16", vp), ("gn_ldy", ctypes.c_int64), ("gn_gamma", vp), ("gn_beta", vp), ("gn_eps", ctypes.c_float), ("gn_groups", c_int), ("gn_hw", c_int),
-                ("gn_silu", c_int), ("chain_W", vp), ("chain_ldb", c_i64), ("chain_bias", vp), ("chain_C16", vp), ("chain_ldc16", c_i64),
+                ("gn_silu", c_int),
                 ("xa_k", vp), ("xa_ldk", c_i64), ("xa_vt", vp), ("xa_out", vp), ("xa_ldo", c_i64), ("xa_Tq", c_int), ("xa_Tk", c_int)]
 
 

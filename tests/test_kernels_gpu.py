@@ -998,8 +998,8 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
     dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
     dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
     dY0, dY1 = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
-    ws = _lib.DeviceBuffer((M // 128) * (N // 320) * 128 * 8)
-    cnt = dev(_lib, np.zeros(8192, np.uint32))
+    ws = dev(_lib, np.zeros((M // 128) * (N // 320) * 128 * 4, np.uint32))       # 16 bytes per row and column tile, zeroed once (the records' tags start above 0)
+    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 0: this launch's epoch (ln_slot = 0), word 8191: sticky give-up
 
     def mk(dst, ln):
         a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=19)
@@ -1025,7 +1025,8 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         assert rel(y, y_ref) < 2e-4, rep
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
-        assert not cnt.download((8192,), np.uint32).any(), rep
+        c_ = cnt.download((8192,), np.uint32)
+        assert c_[8191] == 0 and c_[0] == rep + 1 and not c_[1:8191].any(), rep      # no give-up; the launch advanced its epoch, touched nothing else
     # a launch that cannot honour the request fails instead of silently skipping the LayerNorm
     a2 = mk(dC1, True); a2.act = kernels.ACT_SILU
     with pytest.raises(_lib.MlsdError):
@@ -1054,7 +1055,7 @@ def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
     stale pair -- tests/test_determinism_gpu.py saw it as one image in a few generations differing in the last bits.)"""
     kernels, _lib = K
     rng = np.random.default_rng(5)
-    ws = _lib.DeviceBuffer(2 << 20); cnt = dev(_lib, np.zeros(8192, np.uint32))
+    ws = dev(_lib, np.zeros((2 << 20) // 4, np.uint32)); cnt = dev(_lib, np.zeros(8192, np.uint32))
     for (variant, M, N, Kd) in [(30, 8192, 1280, 2560), (30, 16384, 640, 640), (30, 4096, 1280, 1280), (18, 8192, 1280, 1280), (18, 32768, 640, 640)]:
         sets = []
         for k in range(2):
@@ -1074,65 +1075,8 @@ def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
                 assert np.array_equal(sets[r & 1]["Y"].download((M * N // 2,), np.uint32), first[r & 1][1]), (variant, M, N, Kd, r)
         for k in range(2):
             assert np.array_equal(sets[k]["C"].download((M * N,), np.uint32), first[k][0])
-    assert not cnt.download((8192,), np.uint32).any()
-
-
-@pytest.mark.skipif(not HAS_EXP, reason="the chained launch is an EXPERIMENTS build variant (measured, bit-identical, not faster in the plan)")
-@pytest.mark.parametrize("M,N,Kd,res,alias", [(8192, 1280, 1280, 1, 1), (8192, 1280, 1280, 1, 0), (4096, 1280, 640, 0, 0), (8192, 320, 320, 1, 1), (2048, 640, 640, 1, 0), (16384, 640, 1920, 1, 0)])
-def test_gemm_second_gemm_of_the_launch(K, M, N, Kd, res, alias):
-    """mlsd_gemm_args.chain_W (round 5): a launch of the 128x160 kernel that ends with a LayerNorm goes on to run the Linear that consumes it -- fp16(ln_y16 . W2^T + b2), the
-    cross-attention q projection behind the self-attention output projection (src/mlblock_nn.c:200-203 behind :224-229) -- on the rows its partner tiles have just written.
-    Against the same three results from separate launches (output projection + LayerNorm; projection of the LayerNorm rows on the same kernel): bit-identical, also when the
-    LayerNorm rows land on the first GEMM's A operand (the common case in the plan), and on TWO operand sets launched alternately over one scratch / counter block (stale rows
-    of the previous launch -- another layer's in the plan -- must never be read: the second GEMM's A loads go past the vector L1)."""
-    kernels, _lib = K
-    L = _lib.lib()
-    L.mlsd_gemm_chained.argtypes = [ctypes.POINTER(kernels.GemmArgs)]
-    rng = np.random.default_rng(M + N + Kd)
-    ws = _lib.DeviceBuffer(2 << 20); cnt = dev(_lib, np.zeros(8192, np.uint32))
-    dW = dev(_lib, (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16))
-    dW2 = dev(_lib, (rng.standard_normal((N, N)) / np.sqrt(N)).astype(np.float16))
-    dB, dB2 = dev(_lib, rng.standard_normal(N).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
-    dG, dBt = dev(_lib, (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
-    assert not alias or Kd == N
-    sets, ref = [], []
-    for k in range(2):
-        A = (rng.standard_normal((M, Kd)) * (1 + k)).astype(np.float16)
-        d = dict(A0=A, A=dev(_lib, A), R=dev(_lib, (rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)), C=_lib.DeviceBuffer(M * N * 4), Q=_lib.DeviceBuffer(M * N * 2))
-        d["Y"] = d["A"] if alias else _lib.DeviceBuffer(M * N * 2)
-        sets.append(d)
-
-    def args(d, chain):
-        a = kernels.GemmArgs(A=d["A"].ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=d["C"].ptr, ldc32=N, tile_variant=31,
-                             ln_y16=d["Y"].ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dBt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
-        if res:
-            a.resid, a.ldr = d["R"].ptr, N
-        if chain:
-            a.chain_W, a.chain_ldb, a.chain_bias, a.chain_C16, a.chain_ldc16 = dW2.ptr, N, dB2.ptr, d["Q"].ptr, N
-        return a
-    # separate launches first (the LayerNorm rows may overwrite A: restore it afterwards)
-    for d in sets:
-        a1 = args(d, False)
-        assert L.mlsd_gemm_chained(ctypes.byref(a1)) == 0 and "layernorm" in kernels.gemm_variant(a1)
-        kernels.gemm(a1)
-        a2 = kernels.GemmArgs(A=d["Y"].ptr, lda=N, W_=dW2.ptr, ldb=N, M=M, N=N, K=N, bias=dB2.ptr, C16=d["Q"].ptr, ldc16=N, tile_variant=31)
-        assert "tt" in kernels.gemm_variant(a2)
-        kernels.gemm(a2)
-        ref.append((d["C"].download((M * N,), np.uint32), d["Y"].download((M * N // 2,), np.uint32), d["Q"].download((M * N // 2,), np.uint32)))
-        assert np.isfinite(d["Q"].download((M, N), np.float16).astype(np.float32)).all()
-    chained = [args(d, True) for d in sets]
-    assert L.mlsd_gemm_chained(ctypes.byref(chained[0])) == 1 and kernels.gemm_variant(chained[0]).endswith("+layernorm+linear>")
-    for r in range(300):
-        d = sets[r & 1]
-        if alias:
-            d["A"].upload(d["A0"])
-        _lib.check(L.mlsd_memset(_lib.vp(d["Q"].ptr), 0xFF, ctypes.c_size_t(M * N * 2), None))
-        kernels.gemm(chained[r & 1])
-        if r < 4 or r % 10 < 2:
-            got = (d["C"].download((M * N,), np.uint32), d["Y"].download((M * N // 2,), np.uint32), d["Q"].download((M * N // 2,), np.uint32))
-            for name, g_, e_ in zip(("fp32 output", "LayerNorm rows", "second GEMM"), got, ref[r & 1]):
-                assert np.array_equal(g_, e_), (name, r, int((g_ != e_).sum()))
-    assert not cnt.download((8192,), np.uint32).any()
+    c_ = cnt.download((8192,), np.uint32)
+    assert c_[8191] == 0 and c_[0] == 5 * 402 and not c_[1:8191].any()        # no give-up; 402 launches of each of the 5 shapes advanced the one epoch word
 
 
 @pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 640, 640, 1), (1024, 320, 2560, 0)])
@@ -1153,7 +1097,7 @@ def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
     dG, dBt = dev(_lib, (1 + 0.3 * rng.standard_normal(N)).astype(np.float32)), dev(_lib, rng.standard_normal(N).astype(np.float32))
     dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
     dY0, dY1, dH = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
-    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 128 * 8)
+    ws = dev(_lib, np.zeros(max((M // 128) * (N // 160) * 128 * 4, 4), np.uint32))      # 16 bytes per row and column tile, zeroed once
     cnt = dev(_lib, np.zeros(8192, np.uint32))
 
     def mk(variant, dst, ln=False, f16=False):
@@ -1195,7 +1139,8 @@ def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
         assert rel(y, y_ref) < 2e-4, rep
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
-        assert not cnt.download((8192,), np.uint32).any(), rep
+        c_ = cnt.download((8192,), np.uint32)
+        assert c_[8191] == 0 and c_[0] == rep + 1 and not c_[1:8191].any(), rep      # no give-up; the launch advanced its epoch, touched nothing else
 
 
 @pytest.mark.parametrize("N,Kd,f16", [(1280, 1280, 1), (640, 640, 1), (1280, 2560, 0), (320, 960, 0)])
@@ -1333,7 +1278,7 @@ def test_split_k_reduce_pass_that_ends_with_the_groupnorm(K, n_img, hw, C, Kd, k
 def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     """A REAL give-up: the LayerNorm-ending launch 1024x1280x1280 is 32 tiles whose row-block partners wait for each other; on a stream masked to 8 of
     the 256 CUs the partners of the resident tiles never become resident while those wait, the bounded polling runs out, and the launch must (a) terminate, (b) raise the
-    sticky word ln_cnt[8191] -- which is what mlctx_handoff_check turns into "zero the counters, switch the plan to separate LayerNorm launches, run again"
+    sticky word ln_cnt[8191] -- which is what mlctx_handoff_check turns into "zero the epochs and the record scratch, switch the plan to separate LayerNorm launches, run again"
     (tests/test_unet_gpu.py::test_a_timed_out_handoff_is_retried_on_the_handoff_free_plan).  The fp32 output does not depend on the exchange and stays exact."""
     kernels, _lib = K
     L = _lib.lib()
@@ -1344,13 +1289,14 @@ def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     dA, dW = dev(_lib, A), dev(_lib, W)
     dG, dBt = dev(_lib, np.ones(N, np.float32)), dev(_lib, np.zeros(N, np.float32))
     dC, dY = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
-    ws = _lib.DeviceBuffer((M // 128) * (N // 320) * 128 * 8)
-    cnt = dev(_lib, np.zeros(8192, np.uint32))
+    ws = dev(_lib, np.zeros((M // 128) * (N // 320) * 128 * 4, np.uint32))       # 16 bytes per row and column tile, zeroed once (the records' tags start above 0)
+    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 0: this launch's epoch (ln_slot = 0), word 8191: sticky give-up
     a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=19,
                          ln_y16=dY.ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dBt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
     kernels.gemm(a)                                             # whole chip: clean
     ref = dC.download((M, N), np.uint32)
-    assert not cnt.download((8192,), np.uint32).any()
+    c0 = cnt.download((8192,), np.uint32)
+    assert c0[8191] == 0 and c0[0] == 1 and not c0[1:8191].any()
     s = _lib.vp()
     mask = (ctypes.c_uint32 * 8)(0xFF, 0, 0, 0, 0, 0, 0, 0)                  # 8 CUs: one tile of each row block resident at a time
     _lib.check(L.mlsd_stream_create_masked(ctypes.byref(s), mask, 8), "masked stream")
@@ -1361,16 +1307,19 @@ def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
         _lib.check(L.mlsd_stream_sync(s), "sync")
         dt = time.time() - t0
         c = cnt.download((8192,), np.uint32)
-        print(f"masked launch took {dt:.2f} s; sticky word {c[8191]:#x}; non-zero counters left: {int((c[:8191] != 0).sum())}")
+        print(f"masked launch took {dt:.2f} s; sticky word {c[8191]:#x}; epoch word {c[0]}")
         assert c[8191] == 0xDEAD, "the launch did not report its give-up"
         assert dt < 60
         assert np.array_equal(dC.download((M, N), np.uint32), ref)
     finally:
         L.mlsd_stream_destroy(s)
-    # the recovery mlctx_handoff_check performs: counters zeroed entirely -> the next full-chip launch is clean again
+    # the recovery mlctx_handoff_check performs: epochs AND the record scratch zeroed (a half-written generation must not meet its own tag again) -> the next full-chip
+    # launch is clean again
     _lib.check(L.mlsd_memset(_lib.vp(cnt.ptr), 0, ctypes.c_size_t(8192 * 4), None))
+    _lib.check(L.mlsd_memset(_lib.vp(ws.ptr), 0, ctypes.c_size_t(ws.nbytes), None))
     kernels.gemm(a)
-    assert not cnt.download((8192,), np.uint32).any()
+    c1 = cnt.download((8192,), np.uint32)
+    assert c1[8191] == 0 and c1[0] == 1
     assert np.array_equal(dC.download((M, N), np.uint32), ref)
 
 

@@ -31,7 +31,7 @@ for (M, N, Kd) in [(8192, 1280, 1280), (8192, 1280, 5120), (32768, 640, 640), (3
     hA = rng.standard_normal((M, Kd)).astype(np.float16); hR = rng.standard_normal((M, N)).astype(np.float32)
     for s in range(NSET):
         sets.append(dict(A=_lib.from_numpy(hA), R=_lib.from_numpy(hR), C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
-    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 1024); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    ws = _lib.from_numpy(np.zeros((M // 128) * (N // 160) * 512, np.uint32))      # 16 bytes per row and column tile, zeroed; cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
     def args(s, variant, ln, res=True):
         d = sets[s]
         kw = dict(A=d["A"].ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=d["C"].ptr, ldc32=N, tile_variant=variant + 1)

@@ -13,7 +13,7 @@ for (M, N) in [(8192, 1280), (32768, 640)]:
     W = _lib.from_numpy((rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)); B = _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
     G = _lib.from_numpy((1 + 0.1 * rng.standard_normal(N)).astype(np.float32)); Bt = _lib.from_numpy((0.1 * rng.standard_normal(N)).astype(np.float32))
     dA = _lib.from_numpy(A); dA0 = _lib.from_numpy(A); dC = _lib.DeviceBuffer(M * N * 4); dY = _lib.DeviceBuffer(M * N * 2)
-    ws = _lib.DeviceBuffer((M // 128) * (N // 160) * 1024); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    ws = _lib.from_numpy(np.zeros((M // 128) * (N // 160) * 512, np.uint32)); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
     for variant in (18, 30):
         def args(y):
             return kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=dC.ptr, ldc32=N, tile_variant=variant + 1,

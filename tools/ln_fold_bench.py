@@ -19,7 +19,7 @@ for (M, N, Kd) in [(8192, 1280, 1280), (8192, 1280, 5120)]:
     R = _lib.from_numpy(rng.standard_normal((M, N)).astype(np.float32)); B = _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
     G = _lib.from_numpy(np.ones(N, np.float32)); Bt = _lib.from_numpy(np.zeros(N, np.float32))
     C = _lib.DeviceBuffer(M * N * 4); Y = _lib.DeviceBuffer(M * N * 2)
-    ws = _lib.DeviceBuffer((M // 128) * (N // 320) * 1024); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    ws = _lib.from_numpy(np.zeros((M // 128) * (N // 320) * 512, np.uint32)); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
     a0 = kernels.GemmArgs(A=A.ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=C.ptr, ldc32=N, resid=R.ptr, ldr=N, tile_variant=19)
     a1 = kernels.GemmArgs(A=A.ptr, lda=Kd, W_=W.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=B.ptr, C32=C.ptr, ldc32=N, resid=R.ptr, ldr=N, tile_variant=19,
                           ln_y16=Y.ptr, ldln=N, ln_gamma=G.ptr, ln_beta=Bt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)

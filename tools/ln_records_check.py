@@ -1,0 +1,48 @@
+"""Diagnostic: one LayerNorm-ending launch of each kernel (128x320 ping-pong, 128x160 two-per-CU); the self-tagged records its tiles exchanged (mean, centred sum of squares, tags) against numpy,
+and which statistics each column tile evidently used (recovered from its output).  usage: python3 tools/ln_records_check.py"""
+import ctypes, sys, os
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from mlimgsynth_amd import _lib, kernels
+L = _lib.lib(); vp = _lib.vp
+rng = np.random.default_rng(1)
+for variant, BN in ((19, 320), (31, 160)):
+    M, N, Kd = 1024, 1280, 256
+    A = rng.standard_normal((M, Kd)).astype(np.float16); W = (rng.standard_normal((N, Kd)) / np.sqrt(Kd)).astype(np.float16)
+    dA, dW = _lib.from_numpy(A), _lib.from_numpy(W)
+    dG, dBt = _lib.from_numpy(np.ones(N, np.float32)), _lib.from_numpy(np.zeros(N, np.float32))
+    dC, dY = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
+    nbn = N // BN
+    ws = _lib.from_numpy(np.zeros((M // 128) * nbn * 128 * 4, np.uint32)); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+    a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=variant,
+                         ln_y16=dY.ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dBt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
+    print(kernels.gemm_variant(a))
+    kernels.gemm(a); L.mlsd_device_sync()
+    c = dC.download((M, N), np.float32); y = dY.download((M, N), np.float16).astype(np.float32)
+    ref = (c - c.mean(1, keepdims=True)) / np.sqrt(c.var(1, keepdims=True) + 1e-5)
+    err = np.abs(y - ref)
+    print("  max err", err.max(), "bad rows", int((err.max(1) > 0.02).sum()), "of", M, " first bad rows", np.nonzero(err.max(1) > 0.02)[0][:20])
+    rec = ws.download(((M // 128), nbn, 128, 4), np.uint32)
+    cn = cnt.download((8192,), np.uint32)
+    print("  epoch word", cn[0], "sticky", hex(cn[8191]), " tags ok:", bool((rec[..., 1] == 1).all() and (rec[..., 3] == 1).all()), " tag values seen", np.unique(rec[..., 1])[:5])
+    mean_rec = rec[..., 0].copy().view(np.float32)      # [rb][tile][row]
+    ct = c.reshape(M // 128, 128, nbn, BN)
+    mean_ref = ct.mean(3).transpose(0, 2, 1)
+    print("  record means vs numpy: max diff", np.abs(mean_rec - mean_ref).max())
+    m2_rec = rec[..., 2].copy().view(np.float32)
+    m2_ref = ((ct - ct.mean(3, keepdims=True)) ** 2).sum(3).transpose(0, 2, 1)
+    print("  record m2 vs numpy: max rel diff", (np.abs(m2_rec - m2_ref) / m2_ref).max())
+    r = int(np.argmax(err.max(1)))
+    print("  worst row", r, "y/ref ratio:", (y[r, :6] / ref[r, :6]), " (y-ref)", (y[r,:4]-ref[r,:4]))
+    # what statistics did each tile use?  y = (v - mean_r) rstd_r  ->  rstd from two columns, then the mean
+    for t in range(nbn):
+        cols = np.arange(t * BN, t * BN + BN)
+        v = c[:, cols].astype(np.float64); yy = y[:, cols].astype(np.float64)
+        i0, i1 = v.argmax(1), v.argmin(1)
+        rows = np.arange(M)
+        rstd = (yy[rows, i0] - yy[rows, i1]) / (v[rows, i0] - v[rows, i1])
+        mean = v[rows, i0] - yy[rows, i0] / rstd
+        var_used = 1 / rstd ** 2 - 1e-5
+        true_var = c.var(1); true_mean = c.mean(1)
+        own_m2 = ((v - v.mean(1, keepdims=True)) ** 2).sum(1)
+        print(f"  tile {t}: var_used/true_var median {np.median(var_used / true_var):.4f}; var_used / (own_m2 / N) median {np.median(var_used / (own_m2 / N)):.4f}; mean_used - true_mean median abs {np.median(np.abs(mean - true_mean)):.4f}; mean_used - own_mean/nbn {np.median(np.abs(mean - v.mean(1) / nbn)):.4f}; mean_used - own_mean {np.median(np.abs(mean - v.mean(1))):.4f}")

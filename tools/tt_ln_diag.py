@@ -13,7 +13,7 @@ for k in range(2):
                      C=_lib.DeviceBuffer(M * N * 4), Y=_lib.DeviceBuffer(M * N * 2)))
 dW = _lib.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
 dG, dB = _lib.from_numpy((1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), _lib.from_numpy(rng.standard_normal(N).astype(np.float32))
-ws = _lib.DeviceBuffer(2 << 20); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
+ws = _lib.from_numpy(np.zeros((2 << 20) // 4, np.uint32)); cnt = _lib.from_numpy(np.zeros(8192, np.uint32))
 prio = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L.mlsd_gemm_tt_set_prio(prio)
 def mk(d):
