@@ -180,6 +180,8 @@ int mlsd_gemm_colstats_rows(const mlsd_gemm_args* a);
 int mlsd_gemm_ln_fused(const mlsd_gemm_args* a);
 /* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: see mlsd_gemm_args.xa_k.  MLSD_XATTN=0 in the environment answers 0 (A/B). */
 int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a);
+/* 0 = never, 1 = where the fused launch wins (128 x 320 tiles on more than half of the CUs: the default), 2 = wherever the kernel takes the launch (A/B, kernel tests); other: back to MLSD_XATTN */
+void mlsd_gemm_set_xattn(int mode);
 /* vt[b][n][key] = v[b * Tk + key][n] for key < Tk, 0 for Tk <= key < 96: the V operand of the fused launch (fp16; v row stride ldv halfs; N columns; Tk <= 96) */
 int mlsd_xattn_pack_vt(const void* v, int64_t ldv, int n_img, int Tk, int N, void* vt, void* stream);
 /* name of the kernel variant mlsd_gemm would pick for these args (for profiling reports) */
@@ -232,6 +234,7 @@ int mlsd_attention(const mlsd_attn_args* a, void* stream);
 /* diagnostics / A-B timing: 1 = the d_head 64 problems also run on the general kernel instead of the 64-rows-per-wave one */
 void mlsd_attention_force_old(int on);
 void mlsd_attention_x2_min_tq(int tq);     /* smallest Tq (multiple of 256) the 64-rows-per-wave kernel takes (default 2048) */
+void mlsd_attention_sp(int on);            /* 1 (default): 64-rows-per-wave launches with whole key tiles run software-pipelined inside the wave (attn64x2s_kernel, round 6); 0: the tile-loop form (A/B, bit-identity test) */
 void mlsd_attention_pp(int mode);          /* d_head 64 ping-pong kernel: 0 off, 1 by shape (default), 2 always 32 rows per wave, 3 always 64, 4 = 32 rows with one block per CU; + 16 / 32: s_setprio 1 around the MFMA clusters / the vector phase (A-B timing) */
 void mlsd_attention_tk96(int on, int qb);  /* Tk <= 96 one-pass kernel on/off (A-B timing); qb = 128-row query blocks per workgroup, 0 = automatic */
 void mlsd_attention_wide_stores(int on);  /* diagnostics / A-B timing: 0 = the output in 8-byte pieces per lane */

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include "common.hpp"
 #include "mlsd_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -534,6 +535,253 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
         store(o0, ls0[0], 0);
         store(o1, ls1[0], 1);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn64x2s (round 6): the 64-rows-per-wave kernel above, SOFTWARE-PIPELINED inside the wave.  d_head 64, Tq % 256 == 0, Tk % 64 == 0, Tk >= 128 (the self attentions of SDXL).
+//
+// Why.  At d = 64 a 64-key tile of one 32-row query block is 16 MFMAs (512 matrix clocks) against ~550 issue clocks of softmax (32 v_exp_f32 at 8, 16 packed FMAs, 16 packed
+// adds, 16 converts, 18 max3), and in the tile-loop kernels the two streams ADD: the compiler's schedule has the 16 QK^T MFMAs of both query blocks first, then block 0's whole
+// softmax with the matrix pipe idle, then block 1's softmax partly under block 0's P.V (~1240 clocks per 32-row wave-tile whatever the occupancy: profiles/NOTES.md).  What
+// does overlap is a wave's OWN vector instructions in the shadow of its own MFMAs (an MFMA holds the issue port for a fraction of its 32 clocks: MI355X_MICROARCH.md).
+//
+// Here the two query blocks (A, B) of a wave run HALF A STEP APART on 32-key sub-tiles (u = 0, 1 of tile t), and every quarter pairs one block's softmax of 16 scores per lane
+// with 8 MFMAs of the OTHER block, which do not depend on it:
+//     Q1(t):  softmax A(t,0)   |   QK^T B(t,0)    (4)  +  P.V B(t-1,1)  (4)        fragments X(t)  = K(t) u 0, V(t-1) u 1   (second use)
+//     Q2(t):  softmax B(t,0)   |   QK^T A(t,1)    (4)  +  P.V A(t,0)    (4)        fragments Y(t)  = K(t) u 1, V(t) u 0     (first use)
+//     Q3(t):  softmax A(t,1)   |   QK^T B(t,1)    (4)  +  P.V B(t,0)    (4)        fragments Y(t)                            (second use)
+//     Q4(t):  softmax B(t,1)   |   QK^T A(t+1,0)  (4)  +  P.V A(t,1)    (4)        fragments X(t+1) = K(t+1) u 0, V(t) u 1  (first use)
+// written as 8 slices of {1 MFMA, at most one fragment read, 1/8 of the softmax} with a scheduling barrier between slices, so that the emitted stream IS the interleave
+// (maximum + rescale decision in the first slice, then 8 exp chunks of 2 scores).  Every K / V fragment is read from LDS ONCE and serves both query blocks in two consecutive
+// quarters (32 registers), as in the tile-loop kernel: a first form that re-read them per block moved 8 KB per quarter and wave through a 128 B / clock port.  The reads of a
+// fragment set are issued one per slice in the quarter BEFORE its first use, into the registers the previous set leaves one slice earlier (the last one in the first slice of the
+// first use): seven slices of flight.
+// LDS reads and their waits are inline asm.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 it emits from the builtin while an LDS-DMA is
+// in flight (the intrinsic carries no alias information, so it "may alias" the DMA's target) -- in the tile-loop kernels that is one early wait per tile, here it exposed a
+// whole global round trip twice per tile (the first build of this kernel ran at HALF the tile loop's speed for that reason alone).  The counted lgkmcnt waits take the fragment
+// as an in/out operand so that no use can be scheduled above them; counts are the LDS instructions issued after the fragment (any the compiler adds only make the wait longer).
+// K / V tiles go global -> LDS by LDS-DMA into rings of three buffers: tile t + 2 is issued at the top of iteration t into the buffer tile t - 1 left, drained (`vmcnt(0)`, a
+// whole tile of compute later) and published by the ONE barrier at the end of the iteration; tile t + 1's first fragments are read in Q3(t).
+// Same fragment layouts and per-element arithmetic as the tile-loop kernels (row sums on the VALU), but the running maximum is revisited every 32 keys instead of every 64.
+template <int I_> using sp_ic = std::integral_constant<int, I_>;
+template <int B_, int E_, class F_> __device__ __forceinline__ void sp_for(F_&& f) { if constexpr (B_ < E_) { f(sp_ic<B_>{}); sp_for<B_ + 1, E_>(f); } }
+template <int OFF> __device__ __forceinline__ void sp_read_b128(f16x8& r, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void sp_read_tr64(u32x2& r, unsigned a) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void sp_wait(f16x8& r) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N)); }
+template <int N> __device__ __forceinline__ void sp_wait2(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+__global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
+{
+    constexpr int DH = 64, RB = 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char Ks3[3][64 * RB];
+    __shared__ __attribute__((aligned(1024))) unsigned char Vs3[3][64 * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gk = slot / p.nq, qb = slot - gk * p.nq;
+    const int grp = gk * 8 + xcd;
+    if (grp >= p.G) return;
+    const int head = grp % p.n_head, b = grp / p.n_head;
+    const int qw = qb * 256 + wave * 64;
+
+    const _Float16* Qg = p.q + (long)b * p.bsq + (long)head * DH;
+    const _Float16* Kg = p.k + (long)b * p.bsk + (long)head * DH;
+    const _Float16* Vg = p.v + (long)b * p.bsv + (long)head * DH;
+
+    f16x8 qf[2][4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[sb][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh));
+
+    const int nt = p.Tk / 64;
+    const int srow = lane >> 3, sslot = lane & 7;
+    // LDS-DMA of this wave's 16 rows of a tile: two 1-KiB pieces per operand (chunk swizzles applied to the SOURCE, as in the kernel above)
+    auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + srow;
+            const int ck = sslot ^ ((row >> 1) & 7), cv = sslot ^ (((row >> 1) & 1) << 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + (long)(t * 64 + row) * p.ldk + ck * 8),
+                                             (__attribute__((address_space(3))) void*)(Ks3[buf] + (wave * 16 + i * 8) * RB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (long)(t * 64 + row) * p.ldv + cv * 8),
+                                             (__attribute__((address_space(3))) void*)(Vs3[buf] + (wave * 16 + i * 8) * RB), 16, 0, 0);
+        }
+    };
+
+    f32x16 oA[2], oB[2];                              // O^T accumulators of query block A / B: [d-block of 32]
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oA[d][e] = 0.f; oB[d][e] = 0.f; }
+    float mA = -1.0e30f, mB = -1.0e30f;
+    f32x2 vsA = {0.f, 0.f}, vsB = {0.f, 0.f};
+    f16x8 pfA[2], pfB[2];                             // P of one 32-key sub-tile as B operands: keys 16 sx ..
+    const f16x8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+    pfA[0] = pfA[1] = pfB[0] = pfB[1] = hzero;
+
+    // fragment addressing (byte offsets inside a 64-row tile image; LDS addresses are 32-bit)
+    const int kswz = (lr >> 1) & 7;
+    const int tg = lane >> 4, ti = lane & 15;
+    const int tr_row = 4 * (tg >> 1) + (ti >> 2);
+    const int vswz = ((tr_row >> 1) & 1) << 2;
+    const int tr_c = 2 * (tg & 1) + ((ti & 3) >> 1), tr_b = 8 * (ti & 1);
+    unsigned koff[4], voff[2];                        // K: row lr, k-step ks;  V: row tr_row, d-block d   (+ 4096 u, + 2048 sx, + 1024 for the second half: immediates)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(lr * RB + (((2 * ks + lh) ^ kswz) << 4));
+#pragma unroll
+    for (int d = 0; d < 2; ++d) voff[d] = (unsigned)(tr_row * RB + (((4 * d + tr_c) ^ vswz) << 4) + tr_b);
+    const unsigned ks_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Ks3[0][0];
+    const unsigned vs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Vs3[0][0];
+
+    // the fragment set in use: kf[ks] = K rows of a sub-tile (A operand of QK^T, k-step ks); vf[j] = V^T of 16 keys x 32 d (A operand of P.V; j = 2 sx + d), read as two halves
+    f16x8 kf[4], vf[4];
+    u32x2 vlo[4], vhi[4];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // read fragment F (0..3: K k-step F; 4..7: V piece F - 4) of sub-tile U: K from the tile image at kb, V from the one at vb
+    auto issue = [&](auto F_c, auto UK_c, auto UV_c, unsigned kb, unsigned vb) __attribute__((always_inline)) {
+        constexpr int F = decltype(F_c)::value, UK = decltype(UK_c)::value, UV = decltype(UV_c)::value;
+        if constexpr (F < 4) sp_read_b128<4096 * UK>(kf[F], kb + koff[F]);
+        else {
+            constexpr int j = F - 4;
+            const unsigned a = vb + voff[j & 1];
+            sp_read_tr64<4096 * UV + 2048 * (j >> 1)>(vlo[j], a);
+            sp_read_tr64<4096 * UV + 2048 * (j >> 1) + 1024>(vhi[j], a);
+        }
+    };
+    // LDS instructions issued after fragment F of a set when its first use waits for it: fragments F + 1 .. 6 were issued before the quarter (K: 1 instruction, V: 2), fragment 7
+    // in the quarter's first slice, after its MFMA
+    auto younger = [](int F) constexpr { int n = 0; for (int g = F + 1; g <= 6; ++g) n += g < 4 ? 1 : 2; if (F >= 1 && F <= 6) n += 2; return n; };
+
+    // One quarter.  Softmax of `sc` (16 scores per lane of one block's 32-key sub-tile) -> pfS, beside the other block's 8 MFMAs on the fragment set in registers:
+    // QK^T of its next sub-tile (qfM -> sM) and P.V of its pending P (pfM, oM).  FIRST: the set's first use (wait for every fragment; fragment 7 is read in slice 0);
+    // otherwise the next set is read behind this one: fragment i - 1 in slice i (K sub-tile UK of the image at kb, V sub-tile UV of the image at vb).
+    auto quarter = [&](auto FIRST_c, auto UK_c, auto UV_c, unsigned kb, unsigned vb,
+                       f32x16& sc, float& m_run, f32x16* oS, f32x2& vsum, f16x8* pfS,
+                       const f16x8* qfM, f32x16& sM, f32x16* oM, const f16x8* pfM) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(FIRST_c)::value;
+        float msc = 0.f;
+        sp_for<0, 8>([&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (FIRST) {
+                if constexpr (i < 4) sp_wait<younger(i)>(kf[i]);
+                else {
+                    sp_wait2<younger(i)>(vlo[i - 4], vhi[i - 4]);
+                    vf[i - 4] = __builtin_bit_cast(f16x8, u32x4{vlo[i - 4][0], vlo[i - 4][1], vhi[i - 4][0], vhi[i - 4][1]});
+                }
+            }
+            if constexpr (i == 0) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfM[0], zero, 0, 0, 0);
+            else if constexpr (i < 4) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i], qfM[i], sM, 0, 0, 0);
+            else oM[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i - 4], pfM[(i - 4) >> 1], oM[i & 1], 0, 0, 0);
+            if constexpr (FIRST) { if constexpr (i == 0) issue(sp_ic<7>{}, UK_c, UV_c, kb, vb); }
+            else { if constexpr (i >= 1) issue(sp_ic<i - 1>{}, UK_c, UV_c, kb, vb); }
+            if constexpr (i == 0) {
+                float m1 = max3f(sc[0], sc[1], sc[2]), m2 = max3f(sc[3], sc[4], sc[5]), m3 = max3f(sc[6], sc[7], sc[8]), m4 = max3f(sc[9], sc[10], sc[11]);
+                m1 = max3f(m1, sc[12], sc[13]); m2 = max3f(m2, sc[14], sc[15]);
+                float mx = max3f(m1, m2, m3);
+                {   // the other lane half's maximum without an LDS round trip (v_permlane32_swap on two copies; the fences: see gemm_pp.hpp xor32)
+                    unsigned c, a = __builtin_bit_cast(unsigned, max3f(mx, m4, m4));
+                    asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(a));
+                    const auto r = __builtin_amdgcn_permlane32_swap(a, c, false, false);
+                    unsigned r0 = r[0], r1 = r[1];
+                    asm volatile("" : "+v"(r0), "+v"(r1));
+                    mx = max3f(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), __builtin_bit_cast(float, r1));
+                }
+                const bool grow = (mx - m_run) * p.sc > 6.0f;       // deferred rescale, as attn_kernel: decided for the whole wave before this sub-tile's P is formed
+                if (__any(grow)) {
+                    const float m_new = max3f(m_run, mx, mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
+                    m_run = m_new;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oS[d][e] *= alpha;
+                    vsum *= alpha;
+                }
+                msc = -m_run * p.sc;
+            }
+            {   // exp chunk i: scores 2 i, 2 i + 1; after chunks 3 and 7 the 8 finished scores become one B fragment (the accumulator registers in their permuted k order)
+                const f32x2 r = exp2_pair(sc[2 * i], sc[2 * i + 1], p.sc, msc);
+                float r0 = r.x, r1 = r.y;
+                asm volatile("" : "+v"(r0), "+v"(r1));          // the chunk stays in its slice: without a side effect the optimiser sinks a quarter's exps below the next quarter's first slice
+                sc[2 * i] = r0; sc[2 * i + 1] = r1;
+                vsum += f32x2{r0, r1};
+                if constexpr ((i & 3) == 3) {
+                    f16x8 f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (_Float16)sc[8 * (i >> 2) + j];
+                    asm volatile("" : "+v"(f));
+                    pfS[i >> 2] = f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using U0 = sp_ic<0>; using U1 = sp_ic<1>;
+
+    // ---- prologue: tiles 0 and 1 staged and landed; X(0) = K(0) u 0 (V(-1) does not exist: zero fragments against a zero P); QK^T A(0,0)
+    stage(0, 0); stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    sp_for<0, 4>([&](auto f_c) __attribute__((always_inline)) { issue(f_c, U0{}, U0{}, ks_base, vs_base); });
+    sp_for<0, 4>([&](auto f_c) __attribute__((always_inline)) { constexpr int f = decltype(f_c)::value; sp_wait<3 - f>(kf[f]); vf[f] = hzero; });
+    f32x16 sA = zero, sB = zero;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sA = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[0][ks], sA, 0, 0, 0);
+
+    int cur = 0;                                              // ring slot of tile t
+    for (int t = 0; t < nt; ++t) {
+        const int nx1 = cur == 2 ? 0 : cur + 1, prv = cur == 0 ? 2 : cur - 1;      // slots of tiles t + 1 and t - 1 (the one tile t + 2 goes to)
+        if (t + 2 < nt) stage(t + 2, prv);
+        const unsigned kc = ks_base + cur * (64 * RB), vc = vs_base + cur * (64 * RB), kn = ks_base + nx1 * (64 * RB);
+        // Q1: softmax A(t,0) | B on X(t);  reads Y(t) = K(t) u 1, V(t) u 0
+        quarter(F_{}, U1{}, U0{}, kc, vc, sA, mA, oA, vsA, pfA, qf[1], sB, oB, pfB);
+        // Q2: softmax B(t,0) | A on Y(t) (first use)
+        quarter(T_{}, U1{}, U0{}, kc, vc, sB, mB, oB, vsB, pfB, qf[0], sA, oA, pfA);
+        // Q3: softmax A(t,1) | B on Y(t);  reads X(t+1) = K(t+1) u 0, V(t) u 1
+        quarter(F_{}, U0{}, U1{}, kn, vc, sA, mA, oA, vsA, pfA, qf[1], sB, oB, pfB);
+        // Q4: softmax B(t,1) | A on X(t+1) (first use; past the last tile K(t+1) is whatever the slot holds: scores nobody reads)
+        quarter(T_{}, U0{}, U1{}, kn, vc, sB, mB, oB, vsB, pfB, qf[0], sA, oA, pfA);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 2, issued a tile of compute ago
+        __syncthreads();                                      // tile t + 2 visible; every wave is done reading tile t - 1's successor slot ... and tile t
+        cur = nx1;
+    }
+    // ---- P.V of block B, last sub-tile (V(nt-1) u 1: the V half of the set in registers)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oB[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[j], pfB[j >> 1], oB[j & 1], 0, 0, 0);
+
+    auto store = [&](const f32x16* oacc, float l_run, int sb) __attribute__((always_inline)) {
+        const float inv = 1.0f / l_run;
+        _Float16* og = p.o + (long)b * p.bso + (long)(qw + 32 * sb + lr) * p.ldo + (long)head * DH;
+        auto piece = [&](int d, int eg) __attribute__((always_inline)) {
+            const f16x4 h = {(_Float16)(oacc[d][4 * eg + 0] * inv), (_Float16)(oacc[d][4 * eg + 1] * inv),
+                             (_Float16)(oacc[d][4 * eg + 2] * inv), (_Float16)(oacc[d][4 * eg + 3] * inv)};
+            return __builtin_bit_cast(u32x2, h);
+        };
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int eg = 0; eg < 4; eg += 2) {
+                if (p.wide_o) {
+                    u32x2 a = piece(d, eg), c = piece(d, eg + 1);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                    *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                } else {
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * eg + 4 * lh) = piece(d, eg);
+                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * (eg + 1) + 4 * lh) = piece(d, eg + 1);
+                }
+            }
+    };
+    const float lA = vsA.x + vsA.y, lB = vsB.x + vsB.y;
+    store(oA, lA + __shfl_xor(lA, 32, 64), 0);
+    store(oB, lB + __shfl_xor(lB, 32, 64), 1);
 }
 
 
@@ -1050,6 +1298,7 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
+int g_attn_sp = 0;          // 64-rows-per-wave launches with whole key tiles run software-pipelined inside the wave (attn64x2s_kernel; 0 = the tile-loop form: A/B, bit-identity test)
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
 #ifdef MLSD_GEMM_EXPERIMENTS
 int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity with the tile-loop kernels; off by default): 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
@@ -1069,6 +1318,10 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
     p.nq = a->Tq / 256; p.G = a->n_head * a->n_batch;
     p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
+    if (g_attn_sp && g_attn_vsum && !(a->Tk & 63) && a->Tk >= 128 && (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30)) {      // whole key tiles: the software-pipelined form
+        hipLaunchKernelGGL(attn64x2s_kernel, grid, dim3(256), 0, st, p);
+        return mlsd_check_launch("attn64x2s_kernel");
+    }
     if (g_attn_vsum) hipLaunchKernelGGL(attn64x2_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn64x2_kernel<false>, grid, dim3(256), 0, st, p);
     return mlsd_check_launch("attn64x2_kernel");
@@ -1181,6 +1434,7 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
 
 MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
+MLSD_API void mlsd_attention_sp(int on) { g_attn_sp = on; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
 #ifdef MLSD_GEMM_EXPERIMENTS

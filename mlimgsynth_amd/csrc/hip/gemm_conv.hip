@@ -1187,17 +1187,21 @@ bool ln_eligible(const mlsd_gemm_args* a)
 
 // launches that END with the cross attention of the q they project (gemm_pp.hpp PP_EPI_XATTN): linear, whole 128 x 320 tiles (5 heads of 64), fp16 "output" that is never
 // stored, K / V^T / output operands, a tile inside one image, at most 77 keys held in LDS.  MLSD_XATTN=0 switches the form off (the plan builder asks mlsd_gemm_xattn_fused).
-bool xattn_on()
+int g_xattn_mode = -1;      // 0 = never, 1 = where it wins (the rule below), 2 = wherever the kernel takes the launch; -1: MLSD_XATTN from the environment (default 1); mlsd_gemm_set_xattn
+int xattn_mode()
 {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MLSD_XATTN"); on = (e && *e == '0') ? 0 : 1; }
-    return on != 0;
+    if (g_xattn_mode < 0) { const char* e = getenv("MLSD_XATTN"); g_xattn_mode = (e && *e >= '0' && *e <= '2') ? *e - '0' : 1; }
+    return g_xattn_mode;
 }
 bool xattn_eligible(const mlsd_gemm_args* a)
 {
-    if (!a->xa_k || !a->xa_vt || !a->xa_out || !xattn_on() || a->conv || a->act != MLSD_ACT_NONE || a->C32 || a->resid || a->rowbias || a->bias_m || a->colstats) return false;
+    if (!a->xa_k || !a->xa_vt || !a->xa_out || !xattn_mode() || a->conv || a->act != MLSD_ACT_NONE || a->C32 || a->resid || a->rowbias || a->bias_m || a->colstats) return false;
     if (a->ln_y16 || a->gn_y16 || (a->M % 128) || (a->N % 320) || (a->K & 63) || a->K < 192) return false;
     if (a->xa_Tq <= 0 || (a->xa_Tq % 128) || (a->M % a->xa_Tq) || a->xa_Tk < 1 || a->xa_Tk > 77) return false;
+    // Only where the 128 x 320 tiles fill more than half of the CUs: below that the projection alone runs on the 128 x 160 two-per-CU kernel (twice the blocks) and the
+    // unfused pair wins -- measured (tools/xattn_bench.py, profiles/r6_xattn_bench.txt): 8192 x 1280 (256 tiles) fused 40.8 us against 50.7; 4096 x 1280 (128 tiles) 35.6 against
+    // 29.8; 2048 x 1280 33.3 against 26.3; in the plan SDXL b1 +1.2 % with the fused form everywhere.  (MLSD_XATTN=2 / mlsd_gemm_set_xattn(2): everywhere, for that A/B and the kernel tests.)
+    if (xattn_mode() != 2 && (long)(a->M / 128) * (a->N / 320) <= g_gemm_ncu / 2) return false;
     if ((a->xa_ldk & 7) || (a->xa_ldo & 7) || ((uintptr_t)a->xa_k & 15) || ((uintptr_t)a->xa_vt & 15) || ((uintptr_t)a->xa_out & 15) || (a->bias && ((uintptr_t)a->bias & 15))) return false;
     return g_gemm_epi != 1 && !(g_gemm_dbg & 2);
 }
@@ -1717,6 +1721,8 @@ MLSD_API int mlsd_gemm_gn_fused(const mlsd_gemm_args* a)
     return splitk_par_ok(a, v == 1 ? 64 : 128, splitk_slices(a, 64, nullptr), (long)((a->M + (v == 1 ? 63 : 127)) / (v == 1 ? 64 : 128)) * ((a->N + 127) / 128)) ? 0 : 1;
 #endif
 }
+
+MLSD_API void mlsd_gemm_set_xattn(int mode) { g_xattn_mode = (mode >= 0 && mode <= 2) ? mode : -1; }
 
 /* 1 if this launch (xa_* fields set) ends with the cross attention of the q it projects: the plan builder then records no attention launch */
 MLSD_API int mlsd_gemm_xattn_fused(const mlsd_gemm_args* a)

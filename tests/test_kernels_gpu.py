@@ -39,6 +39,16 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
+@pytest.fixture()
+def monkeypatch_xattn_everywhere():
+    """The plan fuses a cross attention into its q projection only where the 128 x 320 tiles fill more than half of the CUs (a speed rule: mlsd_gemm_set_xattn); lifted here so
+    that the kernel test can run small launches."""
+    from mlimgsynth_amd import _lib
+    _lib.lib().mlsd_gemm_set_xattn(2)
+    yield
+    _lib.lib().mlsd_gemm_set_xattn(-1)
+
+
 @pytest.fixture(scope="module")
 def K():
     from mlimgsynth_amd import kernels, _lib
@@ -1388,7 +1398,7 @@ def test_attention(K, nb, heads, dh, tq, tk, causal):
     (3, 128, 5, 640, 77, False),        # a tile per image: every tile takes another image's K / V
     (2, 1024, 20, 1280, 77, False),     # SDXL's 1024-token level: 8192 x 1280 x 1280 at batch 2 (one tile per block: 64 blocks here, 256 in the plan)
     (1, 128, 5, 256, 1, False), (1, 128, 5, 256, 64, False), (1, 128, 5, 256, 65, False)])
-def test_gemm_that_ends_with_its_cross_attention(K, nb, tq, heads, kd, tk, use_bias):
+def test_gemm_that_ends_with_its_cross_attention(K, nb, tq, heads, kd, tk, use_bias, monkeypatch_xattn_everywhere):
     """Round 6: the q projection of a cross attention ENDS with that attention (mlsd_gemm_args.xa_*, gemm_pp.hpp PP_EPI_XATTN): q never reaches HBM and
     no attention launch follows.  Against the oracle's orc_linear + orc_attention (all fp32 except the fp16 operand roundings: the attention bound) and against the unfused
     HIP pair on the same operands (same rounding points: they agree to the fp16 rounding of the output); K / V are slices of a wider buffer as in the plan (the batched

@@ -16,6 +16,7 @@ def timeit(fn):
     L.mlsd_event_record(ev[1], None); L.mlsd_event_sync(ev[1])
     ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
     return ms.value / reps * 1e3
+L.mlsd_gemm_set_xattn(2)      # also the launches the plan leaves unfused (fewer tiles than half the CUs)
 L.mlsd_xattn_pack_vt.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
 rng = np.random.default_rng(0)
 for (nb, tq, D, kd) in [(8, 1024, 1280, 1280), (8, 4096, 640, 640), (4, 1024, 1280, 1280), (2, 1024, 1280, 1280)]:
