@@ -346,6 +346,10 @@ int mlsd_count_nonfinite(const float* x, size_t n, int32_t* count, void* stream)
 int mlsd_synth_fill(void* dst, int dtype, int64_t n, uint64_t key, float offset, float kf, int layout,
                     int64_t p0, int64_t p1, int64_t p2, int64_t p3, int64_t p4, void* stream);
 
+/* co-issue probe (round 6, tools/coissue_probe.py): 8 x {one 32x32x16 MFMA if mf, nv (3 / 6) vector instructions of kind vk (1 fma, 2 exp, 3 pk_fma, 4 cvt_pk, 5 max3, 6 pk_add, 7 add,
+ * 8 dot2_f32_f16, 9 pk_mul, 10 pk_fma_f16, 11 exp_f16)} per iteration; nthreads 256 / 512 = one / two waves per SIMD; clocks[nblocks] */
+int mlsd_probe_coissue(const void* src, int iters, int nblocks, int nthreads, int mf, int vk, int nv, void* clocks, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

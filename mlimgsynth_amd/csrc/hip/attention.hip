@@ -44,6 +44,17 @@ __device__ __forceinline__ f32x2 exp2_pair(float a, float b, float sc, float msc
     const f32x2 t = __builtin_elementwise_fma(f32x2{a, b}, f32x2{sc, sc}, f32x2{msc, msc});
     return f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // raw v_exp_f32: arguments <= 6, underflow to 0 is the wanted result
 }
+// The same with two v_fma_f32 (attn64x2s_kernel).  Packed fp32 vector instructions (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32; v_dot2_f32_f16 too) do NOT run in the shadow
+// of an MFMA on gfx950: with a 32x32x16 MFMA in flight three of them cost more than the MFMA's 32 clocks ON TOP of it, while v_fma_f32, v_add_f32, v_exp_f32,
+// v_cvt_pk_f16_f32, v_max3_f32 and v_pk_fma_f16 disappear behind it (tools/coissue_probe.py, profiles/r6_coissue_probe.txt).  The tile-loop kernels keep the packed forms:
+// their vector phases mostly run with the matrix pipe idle, and both forms time the same there (profiles/r6_attn_packed_vs_scalar_ab.txt).  Same bits either way.
+__device__ __forceinline__ f32x2 exp2_pair_s(float a, float b, float sc, float msc)
+{
+    float t0, t1;                                                            // (asm: the vectoriser would pair them again)
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(a), "v"(sc), "v"(msc));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(b), "v"(sc), "v"(msc));
+    return f32x2{__builtin_amdgcn_exp2f(t0), __builtin_amdgcn_exp2f(t1)};
+}
 
 struct AttnP {
     const _Float16 *q, *k, *v;
@@ -564,6 +575,19 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
 // K / V tiles go global -> LDS by LDS-DMA into rings of three buffers: tile t + 2 is issued at the top of iteration t into the buffer tile t - 1 left, drained (`vmcnt(0)`, a
 // whole tile of compute later) and published by the ONE barrier at the end of the iteration; tile t + 1's first fragments are read in Q3(t).
 // Same fragment layouts and per-element arithmetic as the tile-loop kernels (row sums on the VALU), but the running maximum is revisited every 32 keys instead of every 64.
+#ifndef SP_PREMAX
+#define SP_PREMAX 0         // 1 = the sub-tile's maximum already in slices 5-7 of the quarter whose slices 0-3 produce the scores (shortens the next quarter's first slice).
+                            // MEASURED NOT REPEATABLE: the v_max3_f32 there are inline asm (max3f), the compiler places no wait states in front of an asm's reads, and two
+                            // slices behind the last QK^T MFMA they sometimes see the accumulator before its final write (first-use quarters, whose MFMAs start late behind
+                            // their fragment waits): 1-ulp differences between runs in block A only (tools/attn_sp_debug.py).  In the first slice of the NEXT quarter the
+                            // producing MFMAs are seven matrix instructions back in an in-order pipe.  No speed difference either way.
+#endif
+#ifndef SP_SHFL
+#define SP_SHFL 0           // diagnostic: 1 = the lane halves exchange their maximum through ds_bpermute
+#endif
+#ifndef SP_ABL
+#define SP_ABL 0            // diagnostic builds (tools/attn_sp_ablate.sh): 1 = no exp, 2 = no MFMA, 4 = no fragment reads, 8 = no maximum / rescale: WRONG results, timing only
+#endif
 template <int I_> using sp_ic = std::integral_constant<int, I_>;
 template <int B_, int E_, class F_> __device__ __forceinline__ void sp_for(F_&& f) { if constexpr (B_ < E_) { f(sp_ic<B_>{}); sp_for<B_ + 1, E_>(f); } }
 template <int OFF> __device__ __forceinline__ void sp_read_b128(f16x8& r, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF)); }
@@ -618,8 +642,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { oA[d][e] = 0.f; oB[d][e] = 0.f; }
-    float mA = -1.0e30f, mB = -1.0e30f;
-    f32x2 vsA = {0.f, 0.f}, vsB = {0.f, 0.f};
+    float mA = -1.0e30f, mB = -1.0e30f, mxA = 0.f, mxB = 0.f;
     f16x8 pfA[2], pfB[2];                             // P of one 32-key sub-tile as B operands: keys 16 sx ..
     const f16x8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
     pfA[0] = pfA[1] = pfB[0] = pfB[1] = hzero;
@@ -658,59 +681,77 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     // in the quarter's first slice, after its MFMA
     auto younger = [](int F) constexpr { int n = 0; for (int g = F + 1; g <= 6; ++g) n += g < 4 ? 1 : 2; if (F >= 1 && F <= 6) n += 2; return n; };
 
-    // One quarter.  Softmax of `sc` (16 scores per lane of one block's 32-key sub-tile) -> pfS, beside the other block's 8 MFMAs on the fragment set in registers:
-    // QK^T of its next sub-tile (qfM -> sM) and P.V of its pending P (pfM, oM).  FIRST: the set's first use (wait for every fragment; fragment 7 is read in slice 0);
-    // otherwise the next set is read behind this one: fragment i - 1 in slice i (K sub-tile UK of the image at kb, V sub-tile UV of the image at vb).
+    // Row sums l[q] on the matrix pipe (the vector unit is the busier one here, and the packed adds that would halve their cost do not run beside an MFMA: exp2_pair_s above):
+    // v_mfma_f32_16x16x32_f16 with P as the B operand -- its lane (n = lane & 15, k group g = lane >> 4) is the 32x32x16 P fragment's lane (query n + 16 (g & 1), key half
+    // g >> 1) -- and a 0 / 1 selector as A: output row m takes the k groups with g & 1 == (m >> 2) & 1, so that lane l (rows 4 (l >> 4) .., column l & 15) ends with the sum
+    // of ITS OWN query l & 31 in every element (the rescale factor of a lane then applies to the sum it holds).  16 matrix clocks and 4 accumulator registers per block.
+    const _Float16 selv = (((lane >> 4) & 1) == (((lane & 15) >> 2) & 1)) ? (_Float16)1.f : (_Float16)0.f;
+    const f16x8 sel = {selv, selv, selv, selv, selv, selv, selv, selv};
+    f32x4 lsA = {0.f, 0.f, 0.f, 0.f}, lsB = {0.f, 0.f, 0.f, 0.f};
+    // the other lane half's value without an LDS round trip (v_permlane32_swap on two copies; the fences: see gemm_pp.hpp xor32)
+    auto half_max = [&](float v) __attribute__((always_inline)) {
+        if constexpr (SP_SHFL != 0) return max3f(v, __shfl_xor(v, 32, 64), v);
+        unsigned c, a = __builtin_bit_cast(unsigned, v);
+        asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(a));
+        const auto r = __builtin_amdgcn_permlane32_swap(a, c, false, false);
+        unsigned r0 = r[0], r1 = r[1];
+        asm volatile("" : "+v"(r0), "+v"(r1));
+        return max3f(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), __builtin_bit_cast(float, r1));
+    };
+
+    // One quarter.  Softmax of `sc` (16 scores per lane of one block's 32-key sub-tile; mxS = their maximum over the sub-tile, found in the quarter that produced them)
+    // -> pfS, beside the other block's MFMAs on the fragment set in registers: QK^T of its next sub-tile (qfM -> sM, maximum -> mxM), P.V of its pending P (pfM, oM) and that
+    // P's row sums (lsM).  FIRST: the set's first use (wait for every fragment; fragment 7 is read in slice 0); otherwise the next set is read behind this one: fragment
+    // i - 1 in slice i (K sub-tile UK of the image at kb, V sub-tile UV of the image at vb).
     auto quarter = [&](auto FIRST_c, auto UK_c, auto UV_c, unsigned kb, unsigned vb,
-                       f32x16& sc, float& m_run, f32x16* oS, f32x2& vsum, f16x8* pfS,
-                       const f16x8* qfM, f32x16& sM, f32x16* oM, const f16x8* pfM) __attribute__((always_inline)) {
+                       f32x16& sc, float mxS, float& m_run, f32x16* oS, f32x4& lsS, f16x8* pfS,
+                       const f16x8* qfM, f32x16& sM, float& mxM, f32x16* oM, f32x4& lsM, const f16x8* pfM) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_c)::value;
-        float msc = 0.f;
+        float msc = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
         sp_for<0, 8>([&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value;
-            if constexpr (FIRST) {
+            if constexpr (FIRST && !(SP_ABL & 4)) {
                 if constexpr (i < 4) sp_wait<younger(i)>(kf[i]);
                 else {
                     sp_wait2<younger(i)>(vlo[i - 4], vhi[i - 4]);
                     vf[i - 4] = __builtin_bit_cast(f16x8, u32x4{vlo[i - 4][0], vlo[i - 4][1], vhi[i - 4][0], vhi[i - 4][1]});
                 }
             }
-            if constexpr (i == 0) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfM[0], zero, 0, 0, 0);
+            if constexpr (SP_ABL & 2) { }
+            else if constexpr (i == 0) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfM[0], zero, 0, 0, 0);
             else if constexpr (i < 4) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i], qfM[i], sM, 0, 0, 0);
-            else oM[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i - 4], pfM[(i - 4) >> 1], oM[i & 1], 0, 0, 0);
-            if constexpr (FIRST) { if constexpr (i == 0) issue(sp_ic<7>{}, UK_c, UV_c, kb, vb); }
+            else {
+                oM[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i - 4], pfM[(i - 4) >> 1], oM[i & 1], 0, 0, 0);
+                if constexpr (i & 1) lsM = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, pfM[(i - 4) >> 1], lsM, 0, 0, 0);
+            }
+            if constexpr (SP_ABL & 4) { }
+            else if constexpr (FIRST) { if constexpr (i == 0) issue(sp_ic<7>{}, UK_c, UV_c, kb, vb); }
             else { if constexpr (i >= 1) issue(sp_ic<i - 1>{}, UK_c, UV_c, kb, vb); }
-            if constexpr (i == 0) {
-                float m1 = max3f(sc[0], sc[1], sc[2]), m2 = max3f(sc[3], sc[4], sc[5]), m3 = max3f(sc[6], sc[7], sc[8]), m4 = max3f(sc[9], sc[10], sc[11]);
-                m1 = max3f(m1, sc[12], sc[13]); m2 = max3f(m2, sc[14], sc[15]);
-                float mx = max3f(m1, m2, m3);
-                {   // the other lane half's maximum without an LDS round trip (v_permlane32_swap on two copies; the fences: see gemm_pp.hpp xor32)
-                    unsigned c, a = __builtin_bit_cast(unsigned, max3f(mx, m4, m4));
-                    asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(a));
-                    const auto r = __builtin_amdgcn_permlane32_swap(a, c, false, false);
-                    unsigned r0 = r[0], r1 = r[1];
-                    asm volatile("" : "+v"(r0), "+v"(r1));
-                    mx = max3f(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), __builtin_bit_cast(float, r1));
+            if constexpr (i == 0 && !(SP_ABL & 8)) {
+                if constexpr (!SP_PREMAX) {
+                    float a1 = max3f(sc[0], sc[1], sc[2]), a2 = max3f(sc[3], sc[4], sc[5]), a3 = max3f(sc[6], sc[7], sc[8]), a4 = max3f(sc[9], sc[10], sc[11]);
+                    a1 = max3f(a1, sc[12], sc[13]); a2 = max3f(a2, sc[14], sc[15]);
+                    a1 = max3f(a1, a2, a3);
+                    mxS = half_max(max3f(a1, a4, a4));
                 }
-                const bool grow = (mx - m_run) * p.sc > 6.0f;       // deferred rescale, as attn_kernel: decided for the whole wave before this sub-tile's P is formed
+                const bool grow = (mxS - m_run) * p.sc > 6.0f;       // deferred rescale, as attn_kernel: decided for the whole wave before this sub-tile's P is formed
                 if (__any(grow)) {
-                    const float m_new = max3f(m_run, mx, mx);
+                    const float m_new = max3f(m_run, mxS, mxS);
                     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
                     m_run = m_new;
 #pragma unroll
                     for (int d = 0; d < 2; ++d)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) oS[d][e] *= alpha;
-                    vsum *= alpha;
+                    lsS *= alpha;
                 }
                 msc = -m_run * p.sc;
             }
             {   // exp chunk i: scores 2 i, 2 i + 1; after chunks 3 and 7 the 8 finished scores become one B fragment (the accumulator registers in their permuted k order)
-                const f32x2 r = exp2_pair(sc[2 * i], sc[2 * i + 1], p.sc, msc);
+                const f32x2 r = (SP_ABL & 1) ? f32x2{sc[2 * i] * p.sc + msc, sc[2 * i + 1] * p.sc + msc} : exp2_pair_s(sc[2 * i], sc[2 * i + 1], p.sc, msc);
                 float r0 = r.x, r1 = r.y;
                 asm volatile("" : "+v"(r0), "+v"(r1));          // the chunk stays in its slice: without a side effect the optimiser sinks a quarter's exps below the next quarter's first slice
                 sc[2 * i] = r0; sc[2 * i + 1] = r1;
-                vsum += f32x2{r0, r1};
                 if constexpr ((i & 3) == 3) {
                     f16x8 f;
 #pragma unroll
@@ -718,6 +759,11 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                     asm volatile("" : "+v"(f));
                     pfS[i >> 2] = f;
                 }
+            }
+            if constexpr (!(SP_ABL & 8) && SP_PREMAX) {         // the maximum of the scores slices 0-3 produced, for the quarter that will exponentiate them
+                if constexpr (i == 5) { m1 = max3f(sM[0], sM[1], sM[2]); m2 = max3f(sM[3], sM[4], sM[5]); m3 = max3f(sM[6], sM[7], sM[8]); m4 = max3f(sM[9], sM[10], sM[11]); asm volatile("" : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4)); }
+                if constexpr (i == 6) { m1 = max3f(m1, sM[12], sM[13]); m2 = max3f(m2, sM[14], sM[15]); m1 = max3f(m1, m2, m3); m1 = max3f(m1, m4, m4); asm volatile("" : "+v"(m1)); }
+                if constexpr (i == 7) { mxM = half_max(m1); asm volatile("" : "+v"(mxM)); }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -734,6 +780,12 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     f32x16 sA = zero, sB = zero;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) sA = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[0][ks], sA, 0, 0, 0);
+    {
+        float m1 = max3f(sA[0], sA[1], sA[2]), m2 = max3f(sA[3], sA[4], sA[5]), m3 = max3f(sA[6], sA[7], sA[8]), m4 = max3f(sA[9], sA[10], sA[11]);
+        m1 = max3f(m1, sA[12], sA[13]); m2 = max3f(m2, sA[14], sA[15]);
+        m1 = max3f(m1, m2, m3);
+        mxA = half_max(max3f(m1, m4, m4));
+    }
 
     int cur = 0;                                              // ring slot of tile t
     for (int t = 0; t < nt; ++t) {
@@ -741,13 +793,13 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
         if (t + 2 < nt) stage(t + 2, prv);
         const unsigned kc = ks_base + cur * (64 * RB), vc = vs_base + cur * (64 * RB), kn = ks_base + nx1 * (64 * RB);
         // Q1: softmax A(t,0) | B on X(t);  reads Y(t) = K(t) u 1, V(t) u 0
-        quarter(F_{}, U1{}, U0{}, kc, vc, sA, mA, oA, vsA, pfA, qf[1], sB, oB, pfB);
+        quarter(F_{}, U1{}, U0{}, kc, vc, sA, mxA, mA, oA, lsA, pfA, qf[1], sB, mxB, oB, lsB, pfB);
         // Q2: softmax B(t,0) | A on Y(t) (first use)
-        quarter(T_{}, U1{}, U0{}, kc, vc, sB, mB, oB, vsB, pfB, qf[0], sA, oA, pfA);
+        quarter(T_{}, U1{}, U0{}, kc, vc, sB, mxB, mB, oB, lsB, pfB, qf[0], sA, mxA, oA, lsA, pfA);
         // Q3: softmax A(t,1) | B on Y(t);  reads X(t+1) = K(t+1) u 0, V(t) u 1
-        quarter(F_{}, U0{}, U1{}, kn, vc, sA, mA, oA, vsA, pfA, qf[1], sB, oB, pfB);
+        quarter(F_{}, U0{}, U1{}, kn, vc, sA, mxA, mA, oA, lsA, pfA, qf[1], sB, mxB, oB, lsB, pfB);
         // Q4: softmax B(t,1) | A on X(t+1) (first use; past the last tile K(t+1) is whatever the slot holds: scores nobody reads)
-        quarter(T_{}, U0{}, U1{}, kn, vc, sB, mB, oB, vsB, pfB, qf[0], sA, oA, pfA);
+        quarter(T_{}, U0{}, U1{}, kn, vc, sB, mxB, mB, oB, lsB, pfB, qf[0], sA, mxA, oA, lsA, pfA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 2, issued a tile of compute ago
         __syncthreads();                                      // tile t + 2 visible; every wave is done reading tile t - 1's successor slot ... and tile t
         cur = nx1;
@@ -755,6 +807,8 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     // ---- P.V of block B, last sub-tile (V(nt-1) u 1: the V half of the set in registers)
 #pragma unroll
     for (int j = 0; j < 4; ++j) oB[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[j], pfB[j >> 1], oB[j & 1], 0, 0, 0);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) lsB = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, pfB[sx], lsB, 0, 0, 0);
 
     auto store = [&](const f32x16* oacc, float l_run, int sb) __attribute__((always_inline)) {
         const float inv = 1.0f / l_run;
@@ -779,9 +833,8 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                 }
             }
     };
-    const float lA = vsA.x + vsA.y, lB = vsB.x + vsB.y;
-    store(oA, lA + __shfl_xor(lA, 32, 64), 0);
-    store(oB, lB + __shfl_xor(lB, 32, 64), 1);
+    store(oA, lsA[0], 0);
+    store(oB, lsB[0], 1);
 }
 
 

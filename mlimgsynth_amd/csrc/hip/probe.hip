@@ -158,7 +158,78 @@ __global__ __launch_bounds__(512) void probe_mfma_rate(const _Float16* __restric
     if (t[0] + t[1] + t[2] + t[3] == 1.2345678e33f) sink[0] = t[0];       // (keeps the loop alive)
 }
 
+// Co-issue probe (round 6): does a wave's vector work run in the shadow of its own (and its SIMD neighbour's) MFMAs?  Per iteration 8 slices of {one v_mfma_f32_32x32x16_f16
+// (8 passes = 32 matrix clocks) if MF, NV vector instructions of kind VK on registers no MFMA touches}; a scheduling barrier between slices keeps the emitted order.
+// VK: 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 v_max3_f32, 6 v_pk_add_f32, 7 v_add_f32, 8 v_dot2_f32_f16, 9 v_pk_mul_f32, 10 v_pk_fma_f16, 11 v_exp_f16.  clocks[block] = shader clocks of the loop (s_memtime domain is avoided: readcyclecounter).
+template <bool MF, int VK, int NV>
+__global__ __launch_bounds__(512) void probe_coissue(const _Float16* __restrict__ src, int iters, unsigned long long* __restrict__ clocks, float* __restrict__ sink)
+{
+    const int tid = threadIdx.x;
+    const f16x8* s8 = reinterpret_cast<const f16x8*>(src) + (size_t)(blockIdx.x & 63) * 2048 + (tid & 511) * 4;
+    const f16x8 a0 = s8[0], a1 = s8[1], b0 = s8[2], b1 = s8[3];
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float x[8];
+    f32x2 y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = (float)a0[j] * 0.01f; y[j] = f32x2{(float)b0[j] * 0.01f, (float)b1[j] * 0.01f}; }
+    const float c1 = 0.999f, c2 = 1e-3f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (MF) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16((j & 1) ? a1 : a0, (j & 2) ? b1 : b0, acc[j & 3], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int r = (j * NV + k) & 7;
+                if constexpr (VK == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(c1), "v"(c2));
+                else if constexpr (VK == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(x[r]));
+                else if constexpr (VK == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
+                else if constexpr (VK == 4) { unsigned h; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x[r]), "v"(x[(r + 1) & 7])); asm volatile("" :: "v"(h)); }
+                else if constexpr (VK == 5) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]));
+                else if constexpr (VK == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
+                else if constexpr (VK == 7) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[r]) : "v"(c2));
+                else if constexpr (VK == 8) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(x[r]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]));
+                else if constexpr (VK == 9) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
+                else if constexpr (VK == 10) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(x[r]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]));
+                else if constexpr (VK == 11) asm volatile("v_exp_f16 %0, %0" : "+v"(x[r]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) clocks[blockIdx.x] = t1 - t0;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[j][e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += x[j] + y[j].x + y[j].y;
+    if (t == 1.2345678e33f) sink[0] = t;
+}
+
 extern "C" {
+
+/* Co-issue probe: nblocks x nthreads (256 = one wave per SIMD, 512 = two); mf = 1: 8 MFMAs of 32x32x16 per iteration; vk / nv: kind and number of vector instructions behind
+ * each MFMA slot (nv in {0, 3, 6}); clocks[nblocks] = shader clocks of the loop. */
+MLSD_API int mlsd_probe_coissue(const void* src, int iters, int nblocks, int nthreads, int mf, int vk, int nv, void* clocks, void* sink, void* stream)
+{
+    if (!src || iters < 1 || nblocks < 1 || (nthreads != 256 && nthreads != 512)) return mlsd_set_error(-1, "mlsd_probe_coissue: bad arguments");
+    const dim3 g(nblocks), b(nthreads);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* s = (const _Float16*)src; unsigned long long* c = (unsigned long long*)clocks; float* k = (float*)sink;
+#define CO_(MF, VK, NV) if (mf == MF && vk == VK && nv == NV) { hipLaunchKernelGGL((probe_coissue<MF != 0, VK, NV>), g, b, 0, st, s, iters, c, k); return mlsd_check_launch("probe_coissue"); }
+#define COK_(VK) CO_(0, VK, 3) CO_(1, VK, 3) CO_(0, VK, 6) CO_(1, VK, 6)
+    CO_(1, 0, 0) COK_(1) COK_(2) COK_(3) COK_(4) COK_(5) COK_(6) COK_(7) COK_(8) COK_(9) COK_(10) COK_(11)
+#undef COK_
+#undef CO_
+    return mlsd_set_error(-1, "mlsd_probe_coissue: no such variant");
+}
 
 /* nblocks x 512 threads (8 waves: two per SIMD), `iters` x 8 MFMAs of 16x16x32 per wave; src: >= 64 x 2048 x 16 bytes of fp16 operands; clocks[nblocks].
  * FLOP of a launch = nblocks * 8 * iters * 8 * 16384 */

@@ -1461,6 +1461,45 @@ def test_gemm_that_ends_with_its_cross_attention(K, nb, tq, heads, kd, tk, use_b
         kernels.gemm(bad)
 
 
+@pytest.mark.parametrize("nb,heads,tq,tk", [(1, 2, 256, 128), (2, 3, 256, 256), (1, 9, 512, 1024), (2, 10, 1024, 1024), (1, 2, 256, 192)])
+def test_attention_software_pipelined_64_row_kernel(K, nb, heads, tq, tk):
+    """Round 6 (second attempt): attn64x2s_kernel -- the two 32-row query blocks of a wave half a step apart on 32-key sub-tiles, every quarter one
+    block's softmax beside the other block's MFMAs; K / V fragments and their waits in inline asm, row sums on the matrix pipe through a 0 / 1 selector, rings of three
+    LDS-DMA buffers (2, 3, 4 and 16 key tiles here: the prologue, the tile the ring wraps on, the last tile's unread successor slot).  Off by default (it times level with
+    the tile loop on the benchmarked shapes: profiles/r6_attention_variants.txt); the switch is mlsd_attention_sp.  Against the oracle at the attention bound, against the
+    tile-loop kernel at the rounding of the output (same rounding points; the running maximum is revisited every 32 keys instead of 64), q / k / v as column slices of one
+    fused projection buffer as in the plan, bit-repeatable."""
+    kernels, _lib = K
+    L = _lib.lib()
+    dh = 64
+    D = heads * dh
+    rng = np.random.default_rng(tq + tk)
+    qkv = f16r(rng.standard_normal((nb, max(tq, tk), 3 * D)) * 1.5)
+    q, k, v = qkv[:, :tq, :D], qkv[:, :tk, D:2 * D], qkv[:, :tk, 2 * D:]
+    ref = np.stack([O.from_ot(O.L().orc_attention(O.to_ot(np.ascontiguousarray(q[i])[None, None]), O.to_ot(np.ascontiguousarray(k[i])[None, None]),
+                                                   O.to_ot(np.ascontiguousarray(v[i])[None, None]), heads, 0)).reshape(tq, D) for i in range(nb)])
+    dqkv = dev(_lib, qkv.astype(np.float16))
+    T = max(tq, tk)
+    do = _lib.DeviceBuffer(nb * tq * D * 2)
+    a = kernels.AttnArgs(q=dqkv.ptr, k=dqkv.ptr + 2 * D, v=dqkv.ptr + 4 * D, out=do.ptr, ldq=3 * D, ldk=3 * D, ldv=3 * D, ldo=D, bsq=T * 3 * D, bsk=T * 3 * D,
+                         bsv=T * 3 * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
+    outs = {}
+    try:
+        L.mlsd_attention_x2_min_tq(256)
+        for name, sp in (("loop", 0), ("sp", 1), ("sp again", 1)):
+            L.mlsd_attention_sp(sp)
+            _lib.check(L.mlsd_memset(_lib.vp(do.ptr), 0x7C, ctypes.c_size_t(do.nbytes), None))
+            kernels.attention(a)
+            outs[name] = do.download((nb, tq, D), np.float16)
+    finally:
+        L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_sp(0)
+    got = outs["sp"].astype(np.float32)
+    assert np.isfinite(got).all() and not (outs["sp"].view(np.uint16) == 0x7C7C).any()
+    assert rel(got, ref) < 2e-3, rel(got, ref)
+    assert rel(got, outs["loop"].astype(np.float32)) < 5e-4
+    assert np.array_equal(outs["sp"].view(np.uint16), outs["sp again"].view(np.uint16))
+
+
 @pytest.mark.parametrize("dh,tq,tk", [(64, 256, 77), (64, 200, 130), (40, 192, 77), (80, 130, 77), (160, 64, 64)])
 def test_attention_output_store_width(K, dh, tq, tk):
     """The attention epilogues store 16 bytes per lane (v_permlane32_swap of column-group pairs) when the output rows are

@@ -16,7 +16,8 @@ def timeit(fn):
     ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
     return ms.value / reps
 rng = np.random.default_rng(0)
-for (nb, heads, tq, tk) in [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (4, 10, 4096, 4096), (4, 20, 1024, 1024), (2, 20, 1024, 1024), (2, 10, 4096, 4096)]:
+SHAPES = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (4, 10, 4096, 4096), (4, 20, 1024, 1024), (2, 20, 1024, 1024), (2, 10, 4096, 4096)]
+for (nb, heads, tq, tk) in SHAPES[:int(os.environ.get('SP_SHAPES', '6'))]:
     dh = 64; D = heads * dh
     q = rng.standard_normal((nb, tq, D)).astype(np.float16); k = rng.standard_normal((nb, tk, D)).astype(np.float16); v = rng.standard_normal((nb, tk, D)).astype(np.float16)
     dq, dk, dv = _lib.from_numpy(q), _lib.from_numpy(k), _lib.from_numpy(v)
