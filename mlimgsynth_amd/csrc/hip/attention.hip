@@ -582,6 +582,10 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
                             // their fragment waits): 1-ulp differences between runs in block A only (tools/attn_sp_debug.py).  In the first slice of the NEXT quarter the
                             // producing MFMAs are seven matrix instructions back in an in-order pipe.  No speed difference either way.
 #endif
+#ifndef SP_QSCALE
+#define SP_QSCALE 1         // 1 = Q fragments pre-multiplied by log2(e) / sqrt(d) (rounded to fp16 once more) and -m as the C operand of the first QK^T MFMA: the accumulators ARE the
+                            // exp2 arguments, no v_fma_f32 per score (16 of ~75 vector instructions of a quarter); 0 = the tile-loop kernels' form (fp32 scale after the MFMA)
+#endif
 #ifndef SP_SHFL
 #define SP_SHFL 0           // diagnostic: 1 = the lane halves exchange their maximum through ds_bpermute
 #endif
@@ -619,8 +623,13 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
             qf[sb][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh));
+            if constexpr (SP_QSCALE != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[sb][ks][j] = (_Float16)((float)qf[sb][ks][j] * p.sc);
+            }
+        }
 
     const int nt = p.Tk / 64;
     const int srow = lane >> 3, sslot = lane & 7;
@@ -643,6 +652,12 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { oA[d][e] = 0.f; oB[d][e] = 0.f; }
     float mA = -1.0e30f, mB = -1.0e30f, mxA = 0.f, mxB = 0.f;
+    // SP_QSCALE: -m' of a block's queries as the 16-register C operand of its QK^T (m' = the reference maximum in the exp2 domain, 0 before the first sub-tile); the growth
+    // threshold of the deferred rescale: -3e38 before the block's first sub-tile (its maximum becomes the reference whatever it is), 6 afterwards
+    f32x16 negA, negB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { negA[e] = 0.f; negB[e] = 0.f; }
+    float thrA = -3.0e38f, thrB = -3.0e38f;
     f16x8 pfA[2], pfB[2];                             // P of one 32-key sub-tile as B operands: keys 16 sx ..
     const f16x8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
     pfA[0] = pfA[1] = pfB[0] = pfB[1] = hzero;
@@ -704,8 +719,8 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     // P's row sums (lsM).  FIRST: the set's first use (wait for every fragment; fragment 7 is read in slice 0); otherwise the next set is read behind this one: fragment
     // i - 1 in slice i (K sub-tile UK of the image at kb, V sub-tile UV of the image at vb).
     auto quarter = [&](auto FIRST_c, auto UK_c, auto UV_c, unsigned kb, unsigned vb,
-                       f32x16& sc, float mxS, float& m_run, f32x16* oS, f32x4& lsS, f16x8* pfS,
-                       const f16x8* qfM, f32x16& sM, float& mxM, f32x16* oM, f32x4& lsM, const f16x8* pfM) __attribute__((always_inline)) {
+                       f32x16& sc, float mxS, float& m_run, f32x16& negS, float& thrS, f32x16* oS, f32x4& lsS, f16x8* pfS,
+                       const f16x8* qfM, f32x16& sM, float& mxM, const f32x16& negM, f32x16* oM, f32x4& lsM, const f16x8* pfM) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_c)::value;
         float msc = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
         sp_for<0, 8>([&](auto i_c) __attribute__((always_inline)) {
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                 }
             }
             if constexpr (SP_ABL & 2) { }
-            else if constexpr (i == 0) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfM[0], zero, 0, 0, 0);
+            else if constexpr (i == 0) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfM[0], SP_QSCALE ? negM : zero, 0, 0, 0);
             else if constexpr (i < 4) sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i], qfM[i], sM, 0, 0, 0);
             else {
                 oM[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i - 4], pfM[(i - 4) >> 1], oM[i & 1], 0, 0, 0);
@@ -734,6 +749,22 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                     a1 = max3f(a1, a2, a3);
                     mxS = half_max(max3f(a1, a4, a4));
                 }
+                if constexpr (SP_QSCALE != 0) {
+                    // the scores ARE exp2 arguments relative to the block's reference maximum: mxS > 6 (or the block's first sub-tile) moves the reference
+                    const bool grow = mxS > thrS;
+                    if (__any(grow)) {
+                        const float delta = fmaxf(mxS, thrS - 6.0f);                       // first sub-tile: mxS itself, afterwards max(mxS, 0)
+                        const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 64.0f));   // (first sub-tile: O = l = 0, the factor only has to stay finite)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) oS[d][e] *= alpha;
+                        lsS *= alpha;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { sc[e] -= delta; negS[e] -= delta; }
+                    }
+                    thrS = 6.0f;
+                } else {
                 const bool grow = (mxS - m_run) * p.sc > 6.0f;       // deferred rescale, as attn_kernel: decided for the whole wave before this sub-tile's P is formed
                 if (__any(grow)) {
                     const float m_new = max3f(m_run, mxS, mxS);
@@ -746,9 +777,11 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                     lsS *= alpha;
                 }
                 msc = -m_run * p.sc;
+                }
             }
             {   // exp chunk i: scores 2 i, 2 i + 1; after chunks 3 and 7 the 8 finished scores become one B fragment (the accumulator registers in their permuted k order)
-                const f32x2 r = (SP_ABL & 1) ? f32x2{sc[2 * i] * p.sc + msc, sc[2 * i + 1] * p.sc + msc} : exp2_pair_s(sc[2 * i], sc[2 * i + 1], p.sc, msc);
+                const f32x2 r = (SP_ABL & 1) ? f32x2{sc[2 * i] * p.sc + msc, sc[2 * i + 1] * p.sc + msc}
+                              : SP_QSCALE ? f32x2{__builtin_amdgcn_exp2f(sc[2 * i]), __builtin_amdgcn_exp2f(sc[2 * i + 1])} : exp2_pair_s(sc[2 * i], sc[2 * i + 1], p.sc, msc);
                 float r0 = r.x, r1 = r.y;
                 asm volatile("" : "+v"(r0), "+v"(r1));          // the chunk stays in its slice: without a side effect the optimiser sinks a quarter's exps below the next quarter's first slice
                 sc[2 * i] = r0; sc[2 * i + 1] = r1;
@@ -793,13 +826,13 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
         if (t + 2 < nt) stage(t + 2, prv);
         const unsigned kc = ks_base + cur * (64 * RB), vc = vs_base + cur * (64 * RB), kn = ks_base + nx1 * (64 * RB);
         // Q1: softmax A(t,0) | B on X(t);  reads Y(t) = K(t) u 1, V(t) u 0
-        quarter(F_{}, U1{}, U0{}, kc, vc, sA, mxA, mA, oA, lsA, pfA, qf[1], sB, mxB, oB, lsB, pfB);
+        quarter(F_{}, U1{}, U0{}, kc, vc, sA, mxA, mA, negA, thrA, oA, lsA, pfA, qf[1], sB, mxB, negB, oB, lsB, pfB);
         // Q2: softmax B(t,0) | A on Y(t) (first use)
-        quarter(T_{}, U1{}, U0{}, kc, vc, sB, mxB, mB, oB, lsB, pfB, qf[0], sA, mxA, oA, lsA, pfA);
+        quarter(T_{}, U1{}, U0{}, kc, vc, sB, mxB, mB, negB, thrB, oB, lsB, pfB, qf[0], sA, mxA, negA, oA, lsA, pfA);
         // Q3: softmax A(t,1) | B on Y(t);  reads X(t+1) = K(t+1) u 0, V(t) u 1
-        quarter(F_{}, U0{}, U1{}, kn, vc, sA, mxA, mA, oA, lsA, pfA, qf[1], sB, mxB, oB, lsB, pfB);
+        quarter(F_{}, U0{}, U1{}, kn, vc, sA, mxA, mA, negA, thrA, oA, lsA, pfA, qf[1], sB, mxB, negB, oB, lsB, pfB);
         // Q4: softmax B(t,1) | A on X(t+1) (first use; past the last tile K(t+1) is whatever the slot holds: scores nobody reads)
-        quarter(T_{}, U0{}, U1{}, kn, vc, sB, mxB, mB, oB, lsB, pfB, qf[0], sA, mxA, oA, lsA, pfA);
+        quarter(T_{}, U0{}, U1{}, kn, vc, sB, mxB, mB, negB, thrB, oB, lsB, pfB, qf[0], sA, mxA, negA, oA, lsA, pfA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 2, issued a tile of compute ago
         __syncthreads();                                      // tile t + 2 visible; every wave is done reading tile t - 1's successor slot ... and tile t
         cur = nx1;
@@ -1351,7 +1384,7 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
-int g_attn_sp = 0;          // 64-rows-per-wave launches with whole key tiles run software-pipelined inside the wave (attn64x2s_kernel; 0 = the tile-loop form: A/B, bit-identity test)
+int g_attn_sp = -1;         // (-1: MLSD_ATTN_SP from the environment, default 1)  d_head 64 launches with whole key tiles (Tk % 64 == 0, >= 128) and Tq % 256 == 0, Tq >= 1024 run software-pipelined inside the wave (attn64x2s_kernel; 0 = the tile-loop kernels, 2 = from Tq = 256 on: A/B and kernel tests, mlsd_attention_sp)
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
 #ifdef MLSD_GEMM_EXPERIMENTS
 int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity with the tile-loop kernels; off by default): 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
@@ -1359,6 +1392,13 @@ int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity 
 int g_attn_tk96 = 1;        // Tk <= 96 without a causal mask: the one-pass kernel (0 = the general kernels; A/B timing)
 int g_attn_tk96_qb = 0;     // query blocks of 128 rows per workgroup (0 = by the launch size)
 int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of ones.P MFMAs: +4..7 % on the SDXL shapes (tools/attn_bench.py); 0 = matrix-pipe sums
+
+bool attn_sp_takes(const mlsd_attn_args* a)
+{
+    if (g_attn_sp < 0) { const char* e = getenv("MLSD_ATTN_SP"); g_attn_sp = (e && *e >= '0' && *e <= '2') ? *e - '0' : 1; }
+    return g_attn_sp && a->d_head == 64 && !a->causal && !(a->Tq & 255) && a->Tq >= (g_attn_sp == 2 ? 256 : 1024) && !(a->Tk & 63) && a->Tk >= 128 &&
+           (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) && !((a->ldq | a->ldk | a->ldv) & 7);
+}
 
 int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
 {
@@ -1371,7 +1411,7 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
     p.nq = a->Tq / 256; p.G = a->n_head * a->n_batch;
     p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
-    if (g_attn_sp && g_attn_vsum && !(a->Tk & 63) && a->Tk >= 128 && (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30)) {      // whole key tiles: the software-pipelined form
+    if (attn_sp_takes(a)) {      // whole key tiles: the software-pipelined form
         hipLaunchKernelGGL(attn64x2s_kernel, grid, dim3(256), 0, st, p);
         return mlsd_check_launch("attn64x2s_kernel");
     }
@@ -1476,7 +1516,7 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
         }
 #endif
         // every q/k/v row must be 16-byte aligned for the LDS-DMA pieces (strides are multiples of 8 halfs: checked above)
-        if (!g_attn_force_old && !a->causal && a->Tq >= g_attn_x2_min_tq && !(a->Tq & 255) &&
+        if (!g_attn_force_old && !a->causal && (a->Tq >= g_attn_x2_min_tq || attn_sp_takes(a)) && !(a->Tq & 255) &&
             !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15)) return launch_attn64x2(a, st);
         return launch_attn<64>(a, st);
     case 80: return launch_attn<80>(a, st);
@@ -1487,7 +1527,7 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
 
 MLSD_API void mlsd_attention_force_old(int on) { g_attn_force_old = on; }
 MLSD_API void mlsd_attention_x2_min_tq(int tq) { g_attn_x2_min_tq = tq; }
-MLSD_API void mlsd_attention_sp(int on) { g_attn_sp = on; }
+MLSD_API void mlsd_attention_sp(int mode) { g_attn_sp = (mode >= 0 && mode <= 2) ? mode : -1; }
 MLSD_API void mlsd_attention_vsum(int on) { g_attn_vsum = on; }
 MLSD_API void mlsd_attention_wide_stores(int on) { g_attn_wide_o = on; }
 #ifdef MLSD_GEMM_EXPERIMENTS

@@ -1465,10 +1465,11 @@ def test_gemm_that_ends_with_its_cross_attention(K, nb, tq, heads, kd, tk, use_b
 def test_attention_software_pipelined_64_row_kernel(K, nb, heads, tq, tk):
     """Round 6 (second attempt): attn64x2s_kernel -- the two 32-row query blocks of a wave half a step apart on 32-key sub-tiles, every quarter one
     block's softmax beside the other block's MFMAs; K / V fragments and their waits in inline asm, row sums on the matrix pipe through a 0 / 1 selector, rings of three
-    LDS-DMA buffers (2, 3, 4 and 16 key tiles here: the prologue, the tile the ring wraps on, the last tile's unread successor slot).  Off by default (it times level with
-    the tile loop on the benchmarked shapes: profiles/r6_attention_variants.txt); the switch is mlsd_attention_sp.  Against the oracle at the attention bound, against the
-    tile-loop kernel at the rounding of the output (same rounding points; the running maximum is revisited every 32 keys instead of 64), q / k / v as column slices of one
-    fused projection buffer as in the plan, bit-repeatable."""
+    LDS-DMA buffers (2, 3, 4 and 16 key tiles here: the prologue, the tile the ring wraps on, the last tile's unread successor slot); Q pre-scaled by log2(e) / sqrt(d)
+    in fp16 and -m as the C operand of the QK^T MFMAs (the accumulators are the exp2 arguments).  The plan's kernel for SDXL's self attentions from 1024 tokens on
+    (mlsd_attention_sp(2) lets it take the small shapes here).  Against the oracle at the attention bound (float64: 3.5 - 4.6e-4 against the tile loop's 2.9e-4,
+    tools/attn_sp_accuracy.py), against the tile-loop kernel (one more rounding of q; the running maximum is revisited every 32 keys instead of 64), operands scaled by
+    1.5 so that the reference maximum moves after the first sub-tile, q / k / v as column slices of one fused projection buffer as in the plan, bit-repeatable."""
     kernels, _lib = K
     L = _lib.lib()
     dh = 64
@@ -1486,17 +1487,17 @@ def test_attention_software_pipelined_64_row_kernel(K, nb, heads, tq, tk):
     outs = {}
     try:
         L.mlsd_attention_x2_min_tq(256)
-        for name, sp in (("loop", 0), ("sp", 1), ("sp again", 1)):
+        for name, sp in (("loop", 0), ("sp", 2), ("sp again", 2)):
             L.mlsd_attention_sp(sp)
             _lib.check(L.mlsd_memset(_lib.vp(do.ptr), 0x7C, ctypes.c_size_t(do.nbytes), None))
             kernels.attention(a)
             outs[name] = do.download((nb, tq, D), np.float16)
     finally:
-        L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_sp(0)
+        L.mlsd_attention_x2_min_tq(2048); L.mlsd_attention_sp(1)
     got = outs["sp"].astype(np.float32)
     assert np.isfinite(got).all() and not (outs["sp"].view(np.uint16) == 0x7C7C).any()
     assert rel(got, ref) < 2e-3, rel(got, ref)
-    assert rel(got, outs["loop"].astype(np.float32)) < 5e-4
+    assert rel(got, outs["loop"].astype(np.float32)) < 1e-3       # (measured 5.0 - 5.3e-4: q is rounded to fp16 once more, after the scale)
     assert np.array_equal(outs["sp"].view(np.uint16), outs["sp again"].view(np.uint16))
 
 

@@ -26,7 +26,7 @@ for (nb, heads, tq, tk) in SHAPES[:int(os.environ.get('SP_SHAPES', '6'))]:
                          d_head=dh, Tq=tq, Tk=tk, causal=0)
     outs = {}
     for name, old, x2min, sp in (("32 rows/wave tile loop", 1, 2048, 0), ("64 rows/wave tile loop", 0, 256, 0), ("64 rows/wave software-pipelined", 0, 256, 1)):
-        L.mlsd_attention_force_old(old); L.mlsd_attention_x2_min_tq(x2min); L.mlsd_attention_sp(sp)
+        L.mlsd_attention_force_old(old); L.mlsd_attention_x2_min_tq(x2min); L.mlsd_attention_sp(2 if sp else 0)
         ts = sorted(timeit(lambda: kernels.attention(a)) for _ in range(3))
         outs[name] = do.download((nb, tq, D), np.float16)
         print(f"attn b{nb} h{heads} {tq}x{tk} {name:34s}: {ts[0]*1e3:8.1f} us (median {ts[1]*1e3:8.1f})  {4.0*nb*heads*tq*tk*dh/ts[0]/1e9:7.1f} TFLOP/s", flush=True)

@@ -12,7 +12,7 @@ for (nb, heads, tq, tk, scale) in [(2, 10, 1024, 1024, 1.5), (8, 10, 4096, 4096,
     a = kernels.AttnArgs(q=dq.ptr, k=dk.ptr, v=dv.ptr, out=do.ptr, ldq=D, ldk=D, ldv=D, ldo=D, bsq=tq * D, bsk=tk * D, bsv=tk * D, bso=tq * D, n_batch=nb, n_head=heads, d_head=dh, Tq=tq, Tk=tk, causal=0)
     L.mlsd_attention_x2_min_tq(256)
     L.mlsd_attention_sp(0); kernels.attention(a); loop = do.download((nb, tq, D), np.float16).astype(np.float32)
-    L.mlsd_attention_sp(1)
+    L.mlsd_attention_sp(2)
     runs = []
     for i in range(6):
         kernels.attention(a); runs.append(do.download((nb, tq, D), np.float16).astype(np.float32))

@@ -18,7 +18,7 @@ PP_EPI = {0: "generic", 1: "f16", 2: "f32", 3: "f32+res", 4: "geglu16", 5: "f32+
 TT_EPI = {1: "f16", 2: "f32", 3: "f32+res", 4: "f32+ln", 5: "f32+res+ln", 6: "f32+ln+chain", 7: "f32+res+ln+chain"}
 
 # every GEMM / attention kernel family of csrc/hip: a name that contains one of these MUST be parsed by its family rule in known()
-FAMILIES = ("gemm_pp_kernel", "gemm_tt_kernel", "gemm_w4_kernel", "gemm_skinny_kernel", "gemm_kernel", "attn64x2_kernel", "attn64pp_kernel",
+FAMILIES = ("gemm_pp_kernel", "gemm_tt_kernel", "gemm_w4_kernel", "gemm_skinny_kernel", "gemm_kernel", "attn64x2s_kernel", "attn64x2_kernel", "attn64pp_kernel",
             "attn_tk96_kernel", "attn_q_kernel", "attn_kernel", "conv_smalln_kernel")
 
 
@@ -75,7 +75,7 @@ def known(name):
     for fn in FAMILIES:
         a = _targs(name, fn) or _mangled_targs(name, fn)
         if a is None:
-            if fn in ("attn64x2_kernel", "attn64pp_kernel") and fn in name: a = []
+            if fn in ("attn64x2s_kernel", "attn64x2_kernel", "attn64pp_kernel") and fn in name: a = []
             else: continue
         try:
             if fn == "gemm_pp_kernel":
@@ -110,6 +110,8 @@ def known(name):
                 return f"attention<{a[0]},one pass>", ""
             if fn == "conv_smalln_kernel":
                 return "gemm<conv3x3n16,conv>", f"cin {a[0]}, ring {a[1]}"
+            if fn == "attn64x2s_kernel":
+                return "attention<64,64 rows/wave pipelined>", ""
             if fn == "attn64x2_kernel":
                 return "attention<64,64 rows/wave>", ""
             if fn == "attn64pp_kernel":
