@@ -744,10 +744,14 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
             else { if constexpr (i >= 1) issue(sp_ic<i - 1>{}, UK_c, UV_c, kb, vb); }
             if constexpr (i == 0 && !(SP_ABL & 8)) {
                 if constexpr (!SP_PREMAX) {
-                    float a1 = max3f(sc[0], sc[1], sc[2]), a2 = max3f(sc[3], sc[4], sc[5]), a3 = max3f(sc[6], sc[7], sc[8]), a4 = max3f(sc[9], sc[10], sc[11]);
-                    a1 = max3f(a1, sc[12], sc[13]); a2 = max3f(a2, sc[14], sc[15]);
-                    a1 = max3f(a1, a2, a3);
-                    mxS = half_max(max3f(a1, a4, a4));
+                    // one asm statement: the compiler puts a wait state behind every asm it cannot see into (7 s_nop per quarter with one v_max3_f32 per statement)
+                    float a1, a2, a3, a4;
+                    asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15\n\t"
+                        "v_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %1, %1, %18, %19\n\tv_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %3"
+                        : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4)
+                        : "v"(sc[0]), "v"(sc[1]), "v"(sc[2]), "v"(sc[3]), "v"(sc[4]), "v"(sc[5]), "v"(sc[6]), "v"(sc[7]), "v"(sc[8]), "v"(sc[9]), "v"(sc[10]), "v"(sc[11]),
+                          "v"(sc[12]), "v"(sc[13]), "v"(sc[14]), "v"(sc[15]));
+                    mxS = half_max(a1);
                 }
                 if constexpr (SP_QSCALE != 0) {
                     // the scores ARE exp2 arguments relative to the block's reference maximum: mxS > 6 (or the block's first sub-tile) moves the reference
