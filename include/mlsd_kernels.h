@@ -141,7 +141,7 @@ typedef struct mlsd_gemm_args {
 	 * resident at once (M % 128 == 0, N % 320 == 0, (M/128)(N/320) <= 256), fp32 output (+ residual), at most 8 column tiles per row block.  The column tiles of a row
 	 * block exchange their row statistics inside the launch as self-tagged records (round 6: no counters, nothing to reset): ln_ws = scratch OF THIS LAUNCH'S OWN
 	 * (zeroed once, never shared with another launch: >= M * (N / tile columns) * 16 bytes -- 16 bytes per row and column tile); ln_cnt = a block of 8192 32-bit words
-	 * zeroed once, ln_cnt[ln_slot] (0 <= ln_slot < 8191) = this launch's epoch, advanced by the launch itself; word 8191 = sticky give-up indicator like sk_flags[4095].
+	 * zeroed once and NEVER shared between two ops or shapes (a tile takes the tag of its records from its own record of the op's previous launch); ln_cnt word 8191 = sticky give-up indicator like sk_flags[4095] (ln_slot: unused since the records carry their generation).
 	 * mlsd_gemm FAILS when ln_y16 is set and the launch cannot honour it. */
 	void* ln_y16; int64_t ldln;
 	const float *ln_gamma, *ln_beta;

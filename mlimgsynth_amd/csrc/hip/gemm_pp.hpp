@@ -155,8 +155,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) stay on the SALU
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
-    unsigned ln_epoch = 0;      // *_LN epilogues: the epoch of this launch's record scratch (its records carry epoch + 1)
-    if constexpr (EPI == PP_EPI_F32_LN || EPI == PP_EPI_F32_RES_LN) ln_epoch = __hip_atomic_load(p.ln_cnt + p.ln_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nblk = p.nbm * p.nbn;
     const int G = gridDim.x;
     const int nkt = p.K / BK;
@@ -547,6 +545,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
         if constexpr (BM == 128 && BN == 320 && !CONV && !SK) {
             constexpr bool RES = decltype(RES_)::value;
             constexpr int NR = 2 * RA;                              // 16-row blocks of the wave's 64 rows
+            // the tag of the records this tile wrote in the PREVIOUS launch of this op (0 = never): this launch's carry that + 1.  Every wave reads the tag of the first row IT
+            // publishes (step 4), several barriers before it does: nobody else writes that record, and the row block's partner tiles left the previous launch with the same tag
+            // (gemm_tt.hip has the story of the per-launch epoch word this replaces)
+            const int rbk = tcur.m0 / BM, bnk = tcur.n0 / BN, nbn = p.nbn;
+            const unsigned tag = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.ln_ws) + (((long)rbk * nbn + bnk) * BM + wr * 64) * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             auto row_of = [&](int r) __attribute__((always_inline)) { return (r / RA) * (WM / 2) + (r % RA) * 16; };
             // 1. v = acc + bias (+ residual) -> C32, kept in the accumulators
             f32x4 rr[RES ? NR : 1][RES ? NCB : 1];
@@ -605,13 +608,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                 mean_t[r] = mu; m2_t[r] = m2;
             }
             // 4. publish + gather (round 6: no ticket, no counters -- the records carry their own validity).  Per row ONE 16-byte record {mean, tag, m2, tag} = two self-tagged
-            //    8-byte granules, written through (sc1), tag = this launch's epoch + 1: the epoch is the launch's own word (ln_cnt[ln_slot], read at kernel entry, advanced by
-            //    tile (0, 0) once it holds its partners' records) and the scratch is the launch's own (mlblock.c wire_ln_fold), so a record with the right tag can only be
-            //    this launch's.  ONE wave per (block, wave row) loads the partners' records with agent-scope loads until both tags of all of them match (bounded; every wave
+            //    8-byte granules, written through (sc1), tag = the tag of this tile's records of the op's previous launch + 1 (read at the top of this epilogue); the scratch
+            //    is the op's own (mlblock.c wire_ln_fold), so a record with the right tag can only be this launch's.  ONE wave per (block, wave row) loads the partners' records with agent-scope loads until both tags of all of them match (bounded; every wave
             //    polling starved the arrivals themselves in round 3), hands them to the other waves through LDS; the others wait at the barrier.  The chain is now: record
             //    visible in L2 -> load returns it (was: store acknowledged -> ticket -> counter seen -> partials loaded), and there is nothing to reset.
-            const int rbk = tcur.m0 / BM, bnk = tcur.n0 / BN, nbn = p.nbn;
-            const unsigned tag = ln_epoch + 1u;
             u32x4* gws = reinterpret_cast<u32x4*>(p.ln_ws) + ((long)rbk * nbn * BM);           // [tile column][128 rows] records
             const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)gws, 0, nbn * BM * 16, 0x00020000);
             if (wc == 0 && lg == 0) {
@@ -663,7 +663,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p)
                     if (act0) e[lg] = own0 ? f32x2{mean_t[r], m2_t[r]} : f32x2{__uint_as_float(rec0[r][0]), __uint_as_float(rec0[r][2])};
                     if (act1) e[lg + 4] = own1 ? f32x2{mean_t[r], m2_t[r]} : f32x2{__uint_as_float(rec1[r][0]), __uint_as_float(rec1[r][2])};
                 }
-                if (rbk == 0 && bnk == 0 && wr == 0 && lane == 0) __hip_atomic_store(p.ln_cnt + p.ln_slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch of this op uses tag + 1
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the ds_writes have LANDED before the barrier lets the readers through
             __builtin_amdgcn_s_barrier();

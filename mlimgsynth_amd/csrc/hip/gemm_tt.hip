@@ -71,8 +71,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
     const int m0 = bmi * BM, n0 = bni * BN;
     // priority class: blocks 0..255 (the first one on every CU), 512..767, ... run ahead of the others
     if (p.prio && !((v >> 8) & 1)) __builtin_amdgcn_s_setprio(2);
+    // *_LN endings: the tag of the records this tile wrote in the PREVIOUS launch of this op (its own scratch region: mlblock.c wire_ln_fold; 0 = never) -- this launch's
+    // records carry that + 1.  Every wave reads the tag of the first row IT publishes, long before it publishes: no other block or wave can have changed it, and the partner
+    // tiles of the row block left the previous launch with the same tag.  (First form of round 6: one epoch word per launch, read at kernel entry and advanced by tile (0, 0)
+    // once it had its partners' records -- a block that ENTERED after that took the next launch's tag and starved its row block: about one give-up in 20 000 launches of the
+    // 512-block grids in tools/soak_r5.py.)
     unsigned ln_epoch = 0;
-    if constexpr (EPI == TT_F32_LN || EPI == TT_F32_RES_LN) ln_epoch = __hip_atomic_load(p.ln_cnt + p.ln_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every lane the same word: the tag of this launch's records is epoch + 1)
+    if constexpr (EPI == TT_F32_LN || EPI == TT_F32_RES_LN)
+        ln_epoch = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.ln_ws) + (((long)bmi * p.nbn + bni) * BM + wr * 64) * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.tbuf && tid == 0) {
         p.tbuf[(long)v * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         p.tbuf[(long)v * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -259,9 +265,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
             mean_t[i] = mu; m2_t[i] = m2;
         }
         // ---- the partner tiles' row statistics (round 6: no ticket, no counters -- the records carry their own validity).  Every tile writes, per row, ONE 16-byte record
-        // {mean, tag, m2, tag} = two self-tagged 8-byte granules (write-through store), tag = this launch's epoch + 1.  The epoch is this launch's own word (ln_cnt[ln_slot]),
-        // read at kernel entry and advanced by tile (0, 0) once it has its partners' records; the scratch is the launch's own too (mlblock.c), so a record with the right tag
-        // can only be this launch's.  One wave per wave row loads the partners' records with agent-scope loads UNTIL both tags of all of them match (bounded), hands them to
+        // {mean, tag, m2, tag} = two self-tagged 8-byte granules (write-through store), tag = the tag of this tile's records of the op's previous launch + 1 (read at kernel
+        // entry, above); the scratch is the op's own (mlblock.c), so a record with the right tag can only be this launch's.  One wave per wave row loads the partners' records with agent-scope loads UNTIL both tags of all of them match (bounded), hands them to
         // the other waves through LDS, and everything else is as before: same fp32 values, combined in tile order.  Nothing to reset, nothing to clear after a give-up.
         const int nbn = p.nbn;
         const unsigned tag = ln_epoch + 1u;
@@ -316,7 +321,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_kernel(const TTP p)
                 if (act0) e[lg] = own0 ? f32x2{mean_t[i], m2_t[i]} : f32x2{__uint_as_float(rec0[i][0]), __uint_as_float(rec0[i][2])};
                 if (act1) e[lg + 4] = own1 ? f32x2{mean_t[i], m2_t[i]} : f32x2{__uint_as_float(rec1[i][0]), __uint_as_float(rec1[i][2])};
             }
-            if (bmi == 0 && bni == 0 && wr == 0 && lane == 0) __hip_atomic_store(p.ln_cnt + p.ln_slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch of this op uses tag + 1
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the ds_writes have LANDED before the barrier lets the readers through
         __builtin_amdgcn_s_barrier();

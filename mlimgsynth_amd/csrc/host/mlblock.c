@@ -25,7 +25,7 @@
 #define VARIANT_TT 31           /* two tiles in flight per CU (gemm_tt.hip, round 5) */
 #define VARIANT_SKINNY 30       /* the skinny-M weight-streaming kernel (gemm_skinny.hpp): always runs through the split-K workspace */
 #define SK_FLAG_WORDS 4096      /* stream-K: a flag per persistent block (256); split-K reduced in the launch: a ticket counter per output tile; word 4095: sticky give-up */
-#define LN_CNT_WORDS 8192       /* LayerNorm fold: one epoch word per folded launch (round 6: self-tagged records instead of arrival / departure counters); word 8191: sticky give-up */
+#define LN_CNT_WORDS 8192       /* LayerNorm fold: word 8191 = sticky give-up (round 6: self-tagged records instead of arrival / departure counters; a tile takes its tag from its own record of the op's previous launch: nothing else lives here) */
 
 #define VEC_PUSH(C, arr, n, cap, T) \
 	(((n) == (cap) ? ((cap) = (cap) ? (cap)*2 : 64, (arr) = (T*)realloc((arr), sizeof(T)*(cap))) : 0), &(arr)[(n)++])
@@ -137,7 +137,7 @@ MLB_API int mlctx_handoff_check(MLCtx* C)
 	if (!w && !w2) return 0;
 	mlsd_stream_sync(C->stream);
 	if (C->sk_flags) mlsd_memset(C->sk_flags, 0, SK_FLAG_WORDS * 4, C->stream);
-	if (C->ln_cnt) mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream);      /* epochs back to 0 ... */
+	if (C->ln_cnt) mlsd_memset(C->ln_cnt, 0, LN_CNT_WORDS * 4, C->stream);      /* the sticky word ... */
 	if (C->ln_ws) mlsd_memset(C->ln_ws, 0, C->ln_ws_bytes, C->stream);              /* ... and every record with them: a half-written generation must not meet its own tag again */
 	mlsd_stream_sync(C->stream);
 	return mlsd_set_error(-8, "an in-launch hand-off (%s) timed out (block not resident: is the GPU shared with another process?); results of this plan are invalid",
@@ -1158,7 +1158,7 @@ static void wire_ln_fold(MLCtx* C)
 	if (e && *e && *e != '0') return;
 	if (C->cu_budget > 0 && C->cu_budget < 256) return;      /* the tiles of a row block must be resident together: not on a CU-masked stream */
 	/* pass 0 sizes the scratch (round 6: a region PER folded launch -- its tiles exchange self-tagged records there, and a tag only has to tell this launch's own
-	 * generations apart: 16 bytes per row and column tile, 512 KB for 8192 x 1280), pass 1 hands the LayerNorms over: region + epoch word (ln_cnt[slot]) each */
+	 * generations apart: 16 bytes per row and column tile, 512 KB for 8192 x 1280), pass 1 hands the LayerNorms over: one region each (the region is what makes a tag unambiguous: it must never be shared between ops) */
 	for (int pass=0; pass<2; ++pass) {
 		size_t need_max = 0, ws_off = 0;
 		int any_splitk = 0, slot = 0;

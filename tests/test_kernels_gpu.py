@@ -1009,7 +1009,7 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
     dC0, dC1 = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 4)
     dY0, dY1 = _lib.DeviceBuffer(M * N * 2), _lib.DeviceBuffer(M * N * 2)
     ws = dev(_lib, np.zeros((M // 128) * (N // 320) * 128 * 4, np.uint32))       # 16 bytes per row and column tile, zeroed once (the records' tags start above 0)
-    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 0: this launch's epoch (ln_slot = 0), word 8191: sticky give-up
+    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 8191: sticky give-up
 
     def mk(dst, ln):
         a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, bias=dB.ptr, C32=dst.ptr, ldc32=N, tile_variant=19)
@@ -1036,7 +1036,7 @@ def test_gemm_that_ends_with_the_layernorm(K, M, N, Kd, res):
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
         c_ = cnt.download((8192,), np.uint32)
-        assert c_[8191] == 0 and c_[0] == rep + 1 and not c_[1:8191].any(), rep      # no give-up; the launch advanced its epoch, touched nothing else
+        assert not c_.any(), rep      # no give-up, and nothing else is ever written there (the records carry the launches' generation themselves)
     # a launch that cannot honour the request fails instead of silently skipping the LayerNorm
     a2 = mk(dC1, True); a2.act = kernels.ACT_SILU
     with pytest.raises(_lib.MlsdError):
@@ -1065,8 +1065,9 @@ def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
     stale pair -- tests/test_determinism_gpu.py saw it as one image in a few generations differing in the last bits.)"""
     kernels, _lib = K
     rng = np.random.default_rng(5)
-    ws = dev(_lib, np.zeros((2 << 20) // 4, np.uint32)); cnt = dev(_lib, np.zeros(8192, np.uint32))
+    cnt = dev(_lib, np.zeros(8192, np.uint32))
     for (variant, M, N, Kd) in [(30, 8192, 1280, 2560), (30, 16384, 640, 640), (30, 4096, 1280, 1280), (18, 8192, 1280, 1280), (18, 32768, 640, 640)]:
+        ws = dev(_lib, np.zeros((2 << 20) // 4, np.uint32))      # a region per op, as in a plan: a tile takes its tag from its own record of the op's previous launch
         sets = []
         for k in range(2):
             sets.append(dict(A=dev(_lib, (rng.standard_normal((M, Kd)) * (1 + k)).astype(np.float16)), R=dev(_lib, (rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)),
@@ -1086,7 +1087,7 @@ def test_gemm_layernorm_ending_on_alternating_operands(K, alt):
         for k in range(2):
             assert np.array_equal(sets[k]["C"].download((M * N,), np.uint32), first[k][0])
     c_ = cnt.download((8192,), np.uint32)
-    assert c_[8191] == 0 and c_[0] == 5 * 402 and not c_[1:8191].any()        # no give-up; 402 launches of each of the 5 shapes advanced the one epoch word
+    assert not c_.any()        # no give-up; nothing else is ever written there
 
 
 @pytest.mark.parametrize("M,N,Kd,res", [(4096, 1280, 1280, 1), (4096, 1280, 5120, 1), (8192, 1280, 1280, 0), (128, 160, 128, 1), (2048, 640, 640, 1), (16384, 640, 640, 1), (1024, 320, 2560, 0)])
@@ -1150,7 +1151,7 @@ def test_gemm_two_tiles_per_cu(K, M, N, Kd, res):
         if first is None: first = raw
         assert np.array_equal(raw, first), rep
         c_ = cnt.download((8192,), np.uint32)
-        assert c_[8191] == 0 and c_[0] == rep + 1 and not c_[1:8191].any(), rep      # no give-up; the launch advanced its epoch, touched nothing else
+        assert not c_.any(), rep      # no give-up, and nothing else is ever written there (the records carry the launches' generation themselves)
 
 
 @pytest.mark.parametrize("N,Kd,f16", [(1280, 1280, 1), (640, 640, 1), (1280, 2560, 0), (320, 960, 0)])
@@ -1300,13 +1301,13 @@ def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     dG, dBt = dev(_lib, np.ones(N, np.float32)), dev(_lib, np.zeros(N, np.float32))
     dC, dY = _lib.DeviceBuffer(M * N * 4), _lib.DeviceBuffer(M * N * 2)
     ws = dev(_lib, np.zeros((M // 128) * (N // 320) * 128 * 4, np.uint32))       # 16 bytes per row and column tile, zeroed once (the records' tags start above 0)
-    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 0: this launch's epoch (ln_slot = 0), word 8191: sticky give-up
+    cnt = dev(_lib, np.zeros(8192, np.uint32))                                    # word 8191: sticky give-up
     a = kernels.GemmArgs(A=dA.ptr, lda=Kd, W_=dW.ptr, ldb=Kd, M=M, N=N, K=Kd, C32=dC.ptr, ldc32=N, tile_variant=19,
                          ln_y16=dY.ptr, ldln=N, ln_gamma=dG.ptr, ln_beta=dBt.ptr, ln_eps=1e-5, ln_ws=ws.ptr, ln_cnt=cnt.ptr)
     kernels.gemm(a)                                             # whole chip: clean
     ref = dC.download((M, N), np.uint32)
     c0 = cnt.download((8192,), np.uint32)
-    assert c0[8191] == 0 and c0[0] == 1 and not c0[1:8191].any()
+    assert not c0.any()
     s = _lib.vp()
     mask = (ctypes.c_uint32 * 8)(0xFF, 0, 0, 0, 0, 0, 0, 0)                  # 8 CUs: one tile of each row block resident at a time
     _lib.check(L.mlsd_stream_create_masked(ctypes.byref(s), mask, 8), "masked stream")
@@ -1317,7 +1318,7 @@ def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
         _lib.check(L.mlsd_stream_sync(s), "sync")
         dt = time.time() - t0
         c = cnt.download((8192,), np.uint32)
-        print(f"masked launch took {dt:.2f} s; sticky word {c[8191]:#x}; epoch word {c[0]}")
+        print(f"masked launch took {dt:.2f} s; sticky word {c[8191]:#x}")
         assert c[8191] == 0xDEAD, "the launch did not report its give-up"
         assert dt < 60
         assert np.array_equal(dC.download((M, N), np.uint32), ref)
@@ -1329,7 +1330,7 @@ def test_layernorm_fold_gives_up_on_a_cu_masked_stream_and_says_so(K):
     _lib.check(L.mlsd_memset(_lib.vp(ws.ptr), 0, ctypes.c_size_t(ws.nbytes), None))
     kernels.gemm(a)
     c1 = cnt.download((8192,), np.uint32)
-    assert c1[8191] == 0 and c1[0] == 1
+    assert not c1.any()
     assert np.array_equal(dC.download((M, N), np.uint32), ref)
 
 

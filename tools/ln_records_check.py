@@ -24,7 +24,7 @@ for variant, BN in ((19, 320), (31, 160)):
     print("  max err", err.max(), "bad rows", int((err.max(1) > 0.02).sum()), "of", M, " first bad rows", np.nonzero(err.max(1) > 0.02)[0][:20])
     rec = ws.download(((M // 128), nbn, 128, 4), np.uint32)
     cn = cnt.download((8192,), np.uint32)
-    print("  epoch word", cn[0], "sticky", hex(cn[8191]), " tags ok:", bool((rec[..., 1] == 1).all() and (rec[..., 3] == 1).all()), " tag values seen", np.unique(rec[..., 1])[:5])
+    print("  sticky", hex(cn[8191]), " tags ok:", bool((rec[..., 1] == 1).all() and (rec[..., 3] == 1).all()), " tag values seen", np.unique(rec[..., 1])[:5])
     mean_rec = rec[..., 0].copy().view(np.float32)      # [rb][tile][row]
     ct = c.reshape(M // 128, 128, nbn, BN)
     mean_ref = ct.mean(3).transpose(0, 2, 1)

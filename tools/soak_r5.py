@@ -30,6 +30,7 @@ for (M, N, K, res) in CASES:
     # TWO operand sets with different values, launched alternately: a tile that read a partner's partials of the PREVIOUS launch would produce other bits than its set's first launch
     # (with one set the stale values are the fresh ones: the first version of this soak could not see the bug it was written for)
     bad0 = bad
+    ws = _lib.from_numpy(np.zeros((2 << 20) // 4, np.uint32))      # a region per op, as in a plan (a tile takes its tag from its own record of the op's previous launch); the two operand sets share it
     sets = []
     for k in range(2):
         sets.append(dict(A=_lib.from_numpy((rng.standard_normal((M, K)) * (1 + k)).astype(np.float16)), R=_lib.from_numpy((rng.standard_normal((M, N)) * 3 + 1 + 5 * k).astype(np.float32)),
@@ -54,7 +55,7 @@ for (M, N, K, res) in CASES:
             now = get(sets[r & 1])
             if not (np.array_equal(now[0], first[r & 1][0]) and np.array_equal(now[1], first[r & 1][1])):
                 bad += 1; print("MISMATCH", name, M, N, K, "at launch", r, "operand set", r & 1)
-    if cnt.download((8192,), np.uint32)[8191]:      # (word 0 is the launches' epoch now: only the sticky give-up word must stay clear)
+    if cnt.download((8192,), np.uint32)[8191]:      # (only the sticky give-up word must stay clear)
         bad += 1; print("COUNTERS LEFT", name, M, N, K)
     print(f"{name} {M}x{N}x{K} ({N // (160 if VARIANT == 31 else 320)} partner tiles, {(M // 128) * (N // (160 if VARIANT == 31 else 320))} tiles): {reps} launches on two alternating operand sets, every fifth checked: {'MISMATCHES (above)' if bad > bad0 else 'ok'}", flush=True)
 Lh = engine._proto2()
