@@ -118,6 +118,8 @@ def known(name):
                 return "attention<64,ping-pong>", ""
         except (ValueError, IndexError, TypeError):
             return None
+    if "xattn_pack_vt_kernel" in name:
+        return "xattn_pack_vt", ""                  # V^T images of the fused cross attentions: once per context (round 6)
     if "gemm" in name or "attn" in name or "conv_smalln" in name:
         return None                                 # a tile family this table does not know: the CPU test fails on it
     k = _ident(name)
