@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void probe_mfma_rate(const _Float16* __restric
 
 // Co-issue probe (round 6): does a wave's vector work run in the shadow of its own (and its SIMD neighbour's) MFMAs?  Per iteration 8 slices of {one v_mfma_f32_32x32x16_f16
 // (8 passes = 32 matrix clocks) if MF, NV vector instructions of kind VK on registers no MFMA touches}; a scheduling barrier between slices keeps the emitted order.
-// VK: 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 v_max3_f32, 6 v_pk_add_f32, 7 v_add_f32, 8 v_dot2_f32_f16, 9 v_pk_mul_f32, 10 v_pk_fma_f16, 11 v_exp_f16.  clocks[block] = shader clocks of the loop (s_memtime domain is avoided: readcyclecounter).
+// VK: 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 v_max3_f32, 6 v_pk_add_f32, 7 v_add_f32, 8 v_dot2_f32_f16, 9 v_pk_mul_f32, 10 v_pk_fma_f16, 11 v_exp_f16, 12 v_lshl_add_u64, 13 v_mad_u64_u32, 14 v_mul_lo_u32, 15 v_add_u32, 16 v_add_co_u32 + v_addc_co_u32, 17 v_add_f64.  clocks[block] = shader clocks of the loop (s_memtime domain is avoided: readcyclecounter).
 template <bool MF, int VK, int NV>
 __global__ __launch_bounds__(512) void probe_coissue(const _Float16* __restrict__ src, int iters, unsigned long long* __restrict__ clocks, float* __restrict__ sink)
 {
@@ -197,6 +197,12 @@ __global__ __launch_bounds__(512) void probe_coissue(const _Float16* __restrict_
                 else if constexpr (VK == 9) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
                 else if constexpr (VK == 10) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(x[r]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]));
                 else if constexpr (VK == 11) asm volatile("v_exp_f16 %0, %0" : "+v"(x[r]));
+                else if constexpr (VK == 12) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
+                else if constexpr (VK == 13) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(y[r]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]) : "vcc");
+                else if constexpr (VK == 14) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[r]) : "v"(x[(r + 3) & 7]));
+                else if constexpr (VK == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[r]) : "v"(x[(r + 3) & 7]));
+                else if constexpr (VK == 16) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(x[r]), "+v"(x[(r + 1) & 7]) : "v"(x[(r + 3) & 7]), "v"(x[(r + 5) & 7]) : "vcc");
+                else if constexpr (VK == 17) asm volatile("v_add_f64 %0, %0, %1" : "+v"(y[r]) : "v"(y[(r + 4) & 7]));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -225,7 +231,7 @@ MLSD_API int mlsd_probe_coissue(const void* src, int iters, int nblocks, int nth
     const _Float16* s = (const _Float16*)src; unsigned long long* c = (unsigned long long*)clocks; float* k = (float*)sink;
 #define CO_(MF, VK, NV) if (mf == MF && vk == VK && nv == NV) { hipLaunchKernelGGL((probe_coissue<MF != 0, VK, NV>), g, b, 0, st, s, iters, c, k); return mlsd_check_launch("probe_coissue"); }
 #define COK_(VK) CO_(0, VK, 3) CO_(1, VK, 3) CO_(0, VK, 6) CO_(1, VK, 6)
-    CO_(1, 0, 0) COK_(1) COK_(2) COK_(3) COK_(4) COK_(5) COK_(6) COK_(7) COK_(8) COK_(9) COK_(10) COK_(11)
+    CO_(1, 0, 0) COK_(1) COK_(2) COK_(3) COK_(4) COK_(5) COK_(6) COK_(7) COK_(8) COK_(9) COK_(10) COK_(11) COK_(12) COK_(13) COK_(14) COK_(15) COK_(16) COK_(17)
 #undef COK_
 #undef CO_
     return mlsd_set_error(-1, "mlsd_probe_coissue: no such variant");

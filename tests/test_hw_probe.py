@@ -107,3 +107,28 @@ def test_hbm_copy_bandwidth_sane():
     with open(os.path.join(OUT, "probe_copy_bw.txt"), "w") as f:
         f.write(f"{gbs:.1f} GB/s\n")
     assert gbs > 1000
+
+
+def test_packed_fp32_vector_instructions_do_not_run_beside_an_mfma():
+    """The fact attn64x2s_kernel is designed around (round 6, tools/coissue_probe.py, profiles/r6_coissue_probe.txt): with a v_mfma_f32_32x32x16_f16 in flight (32 matrix
+    clocks), three v_fma_f32 / v_exp_f32 on other registers cost almost nothing on top of it, three v_pk_fma_f32 cost more than the MFMA again.  Shader clocks of the probe
+    loop per {MFMA + 3 instructions} slice, one wave per SIMD; generous margins (measured 34.5 alone, 35.5 / 37.5 with fma / exp, 61.0 with the packed form)."""
+    from mlimgsynth_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    src = _lib.from_numpy(rng.standard_normal(64 * 2048 * 8).astype(np.float16))
+    NB, iters = 256, 4000
+    clk = _lib.DeviceBuffer(NB * 8); sink = _lib.DeviceBuffer(16)
+
+    def clocks(mf, vk, nv):
+        for _ in range(2):
+            _lib.check(L.mlsd_probe_coissue(_lib.vp(src.ptr), iters, NB, 256, mf, vk, nv, _lib.vp(clk.ptr), _lib.vp(sink.ptr), None), "probe")
+        _lib.check(L.mlsd_device_sync())
+        return float(np.median(clk.download((NB,), np.uint64))) / (iters * 8)
+
+    alone = clocks(1, 0, 0)
+    fma, exp, pk = clocks(1, 1, 3), clocks(1, 2, 3), clocks(1, 3, 3)
+    print(f"clocks per slice: MFMA alone {alone:.1f}, + 3 v_fma_f32 {fma:.1f}, + 3 v_exp_f32 {exp:.1f}, + 3 v_pk_fma_f32 {pk:.1f}")
+    assert 30 < alone < 40
+    assert fma < alone + 6 and exp < alone + 8          # in the MFMA's shadow
+    assert pk > alone + 15                              # serialised against it

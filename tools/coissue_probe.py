@@ -22,12 +22,12 @@ def run(nt, mf, vk, nv):
     ms = ctypes.c_float(); L.mlsd_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))
     c = float(np.median(clk.download((NB,), np.uint64)))
     return c / (iters * 8), c / (ms.value / 4 * 1e-3) / 1e9
-names = {1: "v_fma_f32", 2: "v_exp_f32", 3: "v_pk_fma_f32", 4: "v_cvt_pk_f16_f32", 5: "v_max3_f32", 6: "v_pk_add_f32", 7: "v_add_f32", 8: "v_dot2_f32_f16", 9: "v_pk_mul_f32", 10: "v_pk_fma_f16", 11: "v_exp_f16"}
+names = {1: "v_fma_f32", 2: "v_exp_f32", 3: "v_pk_fma_f32", 4: "v_cvt_pk_f16_f32", 5: "v_max3_f32", 6: "v_pk_add_f32", 7: "v_add_f32", 8: "v_dot2_f32_f16", 9: "v_pk_mul_f32", 10: "v_pk_fma_f16", 11: "v_exp_f16", 12: "v_lshl_add_u64", 13: "v_mad_u64_u32", 14: "v_mul_lo_u32", 15: "v_add_u32", 16: "v_add_co+v_addc_co", 17: "v_add_f64"}
 for nt in (256, 512):
     w = nt // 256
     m, g = run(nt, 1, 0, 0)
     print(f"{w} wave(s) per SIMD: MFMA 32x32x16 alone {m:6.1f} clocks per slice and wave ({g:.2f} GHz)")
-    for vk in sorted(names):
+    for vk in [int(v) for v in os.environ.get('COISSUE_KINDS', '').split(',') if v] or sorted(names):
         for nv in (3, 6):
             v, gv = run(nt, 0, vk, nv)
             b, gb = run(nt, 1, vk, nv)
