@@ -38,12 +38,15 @@ int mlsd_check_launch(const char* what);
 // epilogues where a libm-grade tanhf (~30 VALU instructions) costs a quarter of a short-K main loop.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * fast_sigmoid(x); }
-// tanh-approximation GELU (ggml_gelu): 0.5 x (1 + tanh(u)) == x * sigmoid(2u)
+// tanh-approximation GELU (ggml_gelu): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) x (1 + 0.044715 x^2).
+// Round 6: the constants folded into the exp2 argument -- sigmoid(2u) = 1 / (1 + 2^(x (k1 + k2 x^2))), k1 = -2 sqrt(2/pi) log2(e), k2 = 0.044715 k1 -- : mul, fma, mul, v_exp_f32,
+// add, v_rcp_f32, mul = 5 full-rate instructions + 2 transcendentals instead of 9 + 2 (the build runs with -ffp-contract=off: c * x * (1 + a * x * x), * 2, * log2(e) stayed six
+// separate instructions).  The GEGLU epilogue of the 256 x 256 ping-pong tile does this 64 times per lane with the matrix pipe idle (~13 % of the SDXL feed-forward launches).
 __device__ __forceinline__ float gelu_tanh_f(float x)
 {
-    const float c = 0.7978845608028654f, a = 0.044715f;
-    const float u = c * x * (1.0f + a * x * x);
-    return x * fast_sigmoid(2.0f * u);
+    const float k1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k2 = 0.044715f * k1;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(k2, x * x, k1));      // 2^(-2u log2 e): inf for very negative x (-> 0), 0 for large x (-> x)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_quick_f(float x) { return x * fast_sigmoid(1.702f * x); }
 
