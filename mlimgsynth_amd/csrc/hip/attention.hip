@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
 #define SP_SHFL 0           // diagnostic: 1 = the lane halves exchange their maximum through ds_bpermute
 #endif
 #ifndef SP_ABL
-#define SP_ABL 0            // diagnostic builds (tools/attn_sp_ablate.sh): 1 = no exp, 2 = no MFMA, 4 = no fragment reads, 8 = no maximum / rescale: WRONG results, timing only
+#define SP_ABL 0            // diagnostic builds (tools/attn_sp_ablate.sh): 1 = no exp, 2 = no MFMA, 4 = no fragment reads, 8 = no maximum / rescale, 16 = no fp32 -> fp16 conversion of P: WRONG results, timing only
 #endif
 template <int I_> using sp_ic = std::integral_constant<int, I_>;
 template <int B_, int E_, class F_> __device__ __forceinline__ void sp_for(F_&& f) { if constexpr (B_ < E_) { f(sp_ic<B_>{}); sp_for<B_ + 1, E_>(f); } }
@@ -791,8 +791,11 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
                 sc[2 * i] = r0; sc[2 * i + 1] = r1;
                 if constexpr ((i & 3) == 3) {
                     f16x8 f;
+                    if constexpr (SP_ABL & 16) f = __builtin_bit_cast(f16x8, u32x4{__builtin_bit_cast(unsigned, sc[8 * (i >> 2)]), __builtin_bit_cast(unsigned, sc[8 * (i >> 2) + 1]), __builtin_bit_cast(unsigned, sc[8 * (i >> 2) + 2]), __builtin_bit_cast(unsigned, sc[8 * (i >> 2) + 3])});
+                    else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) f[j] = (_Float16)sc[8 * (i >> 2) + j];
+                    }
                     asm volatile("" : "+v"(f));
                     pfS[i >> 2] = f;
                 }
