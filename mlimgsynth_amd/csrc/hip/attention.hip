@@ -599,9 +599,13 @@ template <int OFF> __device__ __forceinline__ void sp_read_tr64(u32x2& r, unsign
 template <int N> __device__ __forceinline__ void sp_wait(f16x8& r) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N)); }
 template <int N> __device__ __forceinline__ void sp_wait2(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
+// DHV = the head dimension: 64, or 40 (SD1.5's 4096-token level) run AS 64 -- the Q fragments are zero beyond column 40, so whatever the K rows hold there (the next
+// head's columns, or a clamped duplicate at the end of the row) multiplies zero; the V columns beyond 40 produce output rows that are never stored.  5 of 8 matrix
+// instructions of a QK^T / P.V pair do useful work then: still 1.3 - 1.5 x the general kernel at d = 40 (which pads to 48 / 64 as well).
+template <int DHV>
 __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
 {
-    constexpr int DH = 64, RB = 128;
+    constexpr int DH = DHV, RB = 128;
     __shared__ __attribute__((aligned(1024))) unsigned char Ks3[3][64 * RB];
     __shared__ __attribute__((aligned(1024))) unsigned char Vs3[3][64 * RB];
 
@@ -624,7 +628,9 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[sb][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh));
+            uint4 qv = make_uint4(0, 0, 0, 0);
+            if (DHV == 64 || 16 * ks + 8 * lh + 8 <= DHV) qv = *reinterpret_cast<const uint4*>(Qg + (long)(qw + 32 * sb + lr) * p.ldq + 16 * ks + 8 * lh);
+            qf[sb][ks] = __builtin_bit_cast(f16x8, qv);
             if constexpr (SP_QSCALE != 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[sb][ks][j] = (_Float16)((float)qf[sb][ks][j] * p.sc);
@@ -633,12 +639,14 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
 
     const int nt = p.Tk / 64;
     const int srow = lane >> 3, sslot = lane & 7;
+    // (DHV < 64: a row of a head is DHV * 2 / 16 chunks of data; the chunks behind it are the following heads' columns -- never read past the last head's)
+    const int cmax = DHV == 64 ? 7 : min(7, (p.n_head - head) * (DHV * 2 / 16) - 1);
     // LDS-DMA of this wave's 16 rows of a tile: two 1-KiB pieces per operand (chunk swizzles applied to the SOURCE, as in the kernel above)
     auto stage = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = wave * 16 + i * 8 + srow;
-            const int ck = sslot ^ ((row >> 1) & 7), cv = sslot ^ (((row >> 1) & 1) << 2);
+            const int ck = min(sslot ^ ((row >> 1) & 7), cmax), cv = min(sslot ^ (((row >> 1) & 1) << 2), cmax);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + (long)(t * 64 + row) * p.ldk + ck * 8),
                                              (__attribute__((address_space(3))) void*)(Ks3[buf] + (wave * 16 + i * 8) * RB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (long)(t * 64 + row) * p.ldv + cv * 8),
@@ -862,14 +870,15 @@ __global__ __launch_bounds__(256, 2) void attn64x2s_kernel(const AttnP p)
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int eg = 0; eg < 4; eg += 2) {
+                if (32 * d + 8 * eg >= DHV) continue;                  // (DHV = 40: columns 40 .. 63 do not exist)
                 if (p.wide_o) {
                     u32x2 a = piece(d, eg), c = piece(d, eg + 1);
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
-                    *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    if (32 * d + 8 * eg + 8 * lh + 8 <= DHV) *reinterpret_cast<u32x4*>(og + 32 * d + 8 * eg + 8 * lh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
                 } else {
                     *reinterpret_cast<u32x2*>(og + 32 * d + 8 * eg + 4 * lh) = piece(d, eg);
-                    *reinterpret_cast<u32x2*>(og + 32 * d + 8 * (eg + 1) + 4 * lh) = piece(d, eg + 1);
+                    if (32 * d + 8 * (eg + 1) + 8 <= DHV) *reinterpret_cast<u32x2*>(og + 32 * d + 8 * (eg + 1) + 4 * lh) = piece(d, eg + 1);
                 }
             }
     };
@@ -1403,7 +1412,7 @@ int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of on
 bool attn_sp_takes(const mlsd_attn_args* a)
 {
     if (g_attn_sp < 0) { const char* e = getenv("MLSD_ATTN_SP"); g_attn_sp = (e && *e >= '0' && *e <= '2') ? *e - '0' : 1; }
-    return g_attn_sp && a->d_head == 64 && !a->causal && !(a->Tq & 255) && a->Tq >= (g_attn_sp == 2 ? 256 : 1024) && !(a->Tk & 63) && a->Tk >= 128 &&
+    return g_attn_sp && (a->d_head == 64 || a->d_head == 40) && !a->causal && !(a->Tq & 255) && a->Tq >= (g_attn_sp == 2 ? 256 : 1024) && !(a->Tk & 63) && a->Tk >= 128 &&
            (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) && !((a->ldq | a->ldk | a->ldv) & 7);
 }
 
@@ -1419,7 +1428,8 @@ int launch_attn64x2(const mlsd_attn_args* a, hipStream_t st)
     p.wide_o = g_attn_wide_o && !(a->ldo & 7) && !(a->bso & 7) && !((uintptr_t)a->out & 15);
     const dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * p.nq));
     if (attn_sp_takes(a)) {      // whole key tiles: the software-pipelined form
-        hipLaunchKernelGGL(attn64x2s_kernel, grid, dim3(256), 0, st, p);
+        if (a->d_head == 40) { p.sc = (float)(1.4426950408889634 / sqrt(40.0)); hipLaunchKernelGGL(attn64x2s_kernel<40>, grid, dim3(256), 0, st, p); }
+        else hipLaunchKernelGGL(attn64x2s_kernel<64>, grid, dim3(256), 0, st, p);
         return mlsd_check_launch("attn64x2s_kernel");
     }
     if (g_attn_vsum) hipLaunchKernelGGL(attn64x2_kernel<true>, grid, dim3(256), 0, st, p);
@@ -1511,7 +1521,9 @@ MLSD_API int mlsd_attention(const mlsd_attn_args* a, void* stream)
     }
     switch (a->d_head) {
     case 32: return launch_attn<32>(a, st);
-    case 40: return launch_attn<40>(a, st);
+    case 40:
+        if (!g_attn_force_old && attn_sp_takes(a)) return launch_attn64x2(a, st);      // round 6: SD1.5's 4096-token level on the software-pipelined kernel, run as d = 64
+        return launch_attn<40>(a, st);
     case 64:
 #ifdef MLSD_GEMM_EXPERIMENTS
         if (g_attn_pp && !g_attn_force_old && !a->causal && !(a->Tq & 255) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) &&
