@@ -129,6 +129,6 @@ def test_packed_fp32_vector_instructions_do_not_run_beside_an_mfma():
     alone = clocks(1, 0, 0)
     fma, exp, pk = clocks(1, 1, 3), clocks(1, 2, 3), clocks(1, 3, 3)
     print(f"clocks per slice: MFMA alone {alone:.1f}, + 3 v_fma_f32 {fma:.1f}, + 3 v_exp_f32 {exp:.1f}, + 3 v_pk_fma_f32 {pk:.1f}")
-    assert 30 < alone < 40
-    assert fma < alone + 6 and exp < alone + 8          # in the MFMA's shadow
-    assert pk > alone + 15                              # serialised against it
+    assert 24 < alone < 48                               # 32 matrix clocks + loop overhead
+    assert fma < 1.25 * alone and exp < 1.3 * alone     # in the MFMA's shadow (measured 1.03 x / 1.09 x)
+    assert pk > 1.4 * alone                             # serialised against it (measured 1.77 x)
