@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnP p)
 //     Q4(t):  softmax B(t,1)   |   QK^T A(t+1,0)  (4)  +  P.V A(t,1)    (4)        fragments X(t+1) = K(t+1) u 0, V(t) u 1  (first use)
 // written as 8 slices of {1 MFMA, at most one fragment read, 1/8 of the softmax} with a scheduling barrier between slices, so that the emitted stream IS the interleave
 // (maximum + rescale decision in the first slice, then 8 exp chunks of 2 scores).  Every K / V fragment is read from LDS ONCE and serves both query blocks in two consecutive
-// quarters (32 registers), as in the tile-loop kernel: a first form that re-read them per block moved 8 KB per quarter and wave through a 128 B / clock port.  The reads of a
+// quarters (32 registers), as in the tile-loop kernel: a first form that re-read them per block issued twice the LDS reads.  The reads of a
 // fragment set are issued one per slice in the quarter BEFORE its first use, into the registers the previous set leaves one slice earlier (the last one in the first slice of the
 // first use): seven slices of flight.
 // LDS reads and their waits are inline asm.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 it emits from the builtin while an LDS-DMA is
