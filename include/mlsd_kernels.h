@@ -234,7 +234,7 @@ int mlsd_attention(const mlsd_attn_args* a, void* stream);
 /* diagnostics / A-B timing: 1 = the d_head 64 problems also run on the general kernel instead of the 64-rows-per-wave one */
 void mlsd_attention_force_old(int on);
 void mlsd_attention_x2_min_tq(int tq);     /* smallest Tq (multiple of 256) the 64-rows-per-wave kernel takes (default 2048) */
-void mlsd_attention_sp(int mode);          /* d_head 64 or 40, no mask, Tq % 256 == 0, Tk % 64 == 0 and >= 128: 1 (default) = from Tq = 1024 on the software-pipelined kernel (attn64x2s_kernel, round 6: Q pre-scaled in fp16), 2 = from Tq = 256 on (kernel tests), 0 = the tile-loop kernels (A/B) */
+void mlsd_attention_sp(int mode);          /* d_head 64 or 40, no mask, Tq % 256 == 0, Tk % 64 == 0 and >= 128: 1 (default) = from Tq = 768 on, when the launch has at least 128 blocks of 256 rows, the software-pipelined kernel (attn64x2s_kernel, round 6: Q pre-scaled in fp16), 2 = from Tq = 256 on (kernel tests), 0 = the tile-loop kernels (A/B) */
 void mlsd_attention_pp(int mode);          /* d_head 64 ping-pong kernel: 0 off, 1 by shape (default), 2 always 32 rows per wave, 3 always 64, 4 = 32 rows with one block per CU; + 16 / 32: s_setprio 1 around the MFMA clusters / the vector phase (A-B timing) */
 void mlsd_attention_tk96(int on, int qb);  /* Tk <= 96 one-pass kernel on/off (A-B timing); qb = 128-row query blocks per workgroup, 0 = automatic */
 void mlsd_attention_wide_stores(int on);  /* diagnostics / A-B timing: 0 = the output in 8-byte pieces per lane */

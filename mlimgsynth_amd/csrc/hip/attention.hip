@@ -1400,7 +1400,7 @@ int g_attn_force_old = 0;   // diagnostics / A-B timing: 1 = never use attn64x2_
 // the 256-row blocks quantise badly on short sequences (Tq 1024 x 160 groups = 640 blocks on 512 slots: measured slower than
 // the general kernel), so they take Tq >= 2048 only
 int g_attn_x2_min_tq = 2048;
-int g_attn_sp = -1;         // (-1: MLSD_ATTN_SP from the environment, default 1)  d_head 64 launches with whole key tiles (Tk % 64 == 0, >= 128) and Tq % 256 == 0, Tq >= 1024 run software-pipelined inside the wave (attn64x2s_kernel; 0 = the tile-loop kernels, 2 = from Tq = 256 on: A/B and kernel tests, mlsd_attention_sp)
+int g_attn_sp = -1;         // (-1: MLSD_ATTN_SP from the environment, default 1)  d_head 64 launches with whole key tiles (Tk % 64 == 0, >= 128) and Tq % 256 == 0, Tq >= 768 and at least 128 blocks run software-pipelined inside the wave (attn64x2s_kernel; 0 = the tile-loop kernels, 2 = from Tq = 256 on: A/B and kernel tests, mlsd_attention_sp)
 int g_attn_wide_o = 1;      // 16-byte output stores (0 = 8-byte pieces; A/B timing)
 #ifdef MLSD_GEMM_EXPERIMENTS
 int g_attn_pp = 0;          // ping-pong kernel for d_head 64 (measured: parity with the tile-loop kernels; off by default): 0 = off, 1 = by shape (Tq % 512 == 0 and >= 2048: 64 rows per wave; Tq % 256 == 0: 32, two blocks per CU), 2 = always 32 rows, 3 = always 64 rows, 4 = 32 rows, one block per CU
@@ -1412,7 +1412,7 @@ int g_attn_vsum = 1;        // row sums on the VALU (v_pk_add_f32) instead of on
 bool attn_sp_takes(const mlsd_attn_args* a)
 {
     if (g_attn_sp < 0) { const char* e = getenv("MLSD_ATTN_SP"); g_attn_sp = (e && *e >= '0' && *e <= '2') ? *e - '0' : 1; }
-    return g_attn_sp && (a->d_head == 64 || a->d_head == 40) && !a->causal && !(a->Tq & 255) && a->Tq >= (g_attn_sp == 2 ? 256 : 1024) && !(a->Tk & 63) && a->Tk >= 128 &&
+    return g_attn_sp && (a->d_head == 64 || a->d_head == 40) && !a->causal && !(a->Tq & 255) && (g_attn_sp == 2 ? a->Tq >= 256 : (a->Tq >= 768 && (long)a->n_head * a->n_batch * (a->Tq / 256) >= 128)) &&      /* (default: from 768 tokens on and at least 128 blocks of 256 rows -- below that the 128-row blocks of the tile-loop kernel fill the chip better: tools/attn_sp_small_shapes.py) */ !(a->Tk & 63) && a->Tk >= 128 &&
            (long)a->Tk * a->ldk < (1L << 30) && (long)a->Tk * a->ldv < (1L << 30) && !(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) && !((a->ldq | a->ldk | a->ldv) & 7);
 }
 
